@@ -1,0 +1,1615 @@
+// oracle.cpp — CPU ORACLE for compose -> shortest_path (test infrastructure, NOT product code).
+//
+// A single-threaded C++17 restatement of rustfst 1.3.1 (reference @ /root/reference) for
+// VectorFst<TropicalWeight>.  Every block cites the reference file:line it follows.  It keeps
+// the reference's data-structure choices (per-state arc vectors, hash-map state table keyed on
+// (fs,s1,s2), FIFO BFS materialisation, DFS connect, AutoQueue with distance=None, approximate
+// TropicalWeight ==) so it can also stand in as the CPU baseline ("port", not rustfst binaries).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may load this library.
+// PARITY PIN STATUS: see oracle.h.
+#include "oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- constants (lib.rs:236,269,292,298)
+constexpr uint32_t EPS_LABEL = 0;
+constexpr uint32_t NO_LABEL = 0xFFFFFFFFu;
+constexpr uint32_t NO_STATE_ID = 0xFFFFFFFFu;
+constexpr float KDELTA = 1.0f / 1024.0f;
+constexpr float INF = std::numeric_limits<float>::infinity();
+
+thread_local std::string t_err;
+thread_local float t_delta = KDELTA;  // ORACLE_EQ_REF_KDELTA -> KDELTA, ORACLE_EQ_EXACT -> 0
+thread_local const char* t_queue_kind = "";
+
+struct DeltaGuard {
+  float saved;
+  explicit DeltaGuard(int eq_mode) : saved(t_delta) { t_delta = eq_mode == ORACLE_EQ_EXACT ? 0.0f : KDELTA; }
+  ~DeltaGuard() { t_delta = saved; }
+};
+
+// ---------------------------------------------------------------- TropicalWeight (T1)
+// semirings/tropical_weight.rs:53-71 and the eq macro semirings/semiring.rs:159-168
+inline bool weq(float a, float b) { return a <= b + t_delta && b <= a + t_delta; }
+inline float wplus(float a, float b) { return b < a ? b : a; }  // plus_assign :53-58 (exact <)
+inline float wtimes(float a, float b) {                          // times_assign :60-70
+  if (a == INF) return a;
+  if (b == INF) return b;
+  return a + b;
+}
+inline bool wis_zero(float a) { return weq(a, INF); }  // semiring.rs:71-73
+inline bool wis_one(float a) { return weq(a, 0.0f); }  // semiring.rs:68-70
+
+// ---------------------------------------------------------------- FstProperties (properties.rs:22-103)
+namespace P {
+constexpr uint64_t ACCEPTOR = 0x0000000000010000ull, NOT_ACCEPTOR = 0x0000000000020000ull;
+constexpr uint64_t I_DETERMINISTIC = 0x0000000000040000ull, NOT_I_DETERMINISTIC = 0x0000000000080000ull;
+constexpr uint64_t O_DETERMINISTIC = 0x0000000000100000ull, NOT_O_DETERMINISTIC = 0x0000000000200000ull;
+constexpr uint64_t EPSILONS = 0x0000000000400000ull, NO_EPSILONS = 0x0000000000800000ull;
+constexpr uint64_t I_EPSILONS = 0x0000000001000000ull, NO_I_EPSILONS = 0x0000000002000000ull;
+constexpr uint64_t O_EPSILONS = 0x0000000004000000ull, NO_O_EPSILONS = 0x0000000008000000ull;
+constexpr uint64_t I_LABEL_SORTED = 0x0000000010000000ull, NOT_I_LABEL_SORTED = 0x0000000020000000ull;
+constexpr uint64_t O_LABEL_SORTED = 0x0000000040000000ull, NOT_O_LABEL_SORTED = 0x0000000080000000ull;
+constexpr uint64_t WEIGHTED = 0x0000000100000000ull, UNWEIGHTED = 0x0000000200000000ull;
+constexpr uint64_t CYCLIC = 0x0000000400000000ull, ACYCLIC = 0x0000000800000000ull;
+constexpr uint64_t INITIAL_CYCLIC = 0x0000001000000000ull, INITIAL_ACYCLIC = 0x0000002000000000ull;
+constexpr uint64_t TOP_SORTED = 0x0000004000000000ull, NOT_TOP_SORTED = 0x0000008000000000ull;
+constexpr uint64_t ACCESSIBLE = 0x0000010000000000ull, NOT_ACCESSIBLE = 0x0000020000000000ull;
+constexpr uint64_t COACCESSIBLE = 0x0000040000000000ull, NOT_COACCESSIBLE = 0x0000080000000000ull;
+constexpr uint64_t STRING = 0x0000100000000000ull, NOT_STRING = 0x0000200000000000ull;
+constexpr uint64_t WEIGHTED_CYCLES = 0x0000400000000000ull, UNWEIGHTED_CYCLES = 0x0000800000000000ull;
+constexpr uint64_t ALL = 0x0000ffffffff0000ull;  // all_properties(): binary bits are not flags (:520-534)
+constexpr uint64_t STATIC_EXPANDED_MUTABLE = 0x3;  // properties.rs:5-6
+
+// properties.rs:105-124
+constexpr uint64_t NULL_PROPS = ACCEPTOR | I_DETERMINISTIC | O_DETERMINISTIC | NO_EPSILONS | NO_I_EPSILONS |
+                                NO_O_EPSILONS | I_LABEL_SORTED | O_LABEL_SORTED | UNWEIGHTED | ACYCLIC |
+                                INITIAL_ACYCLIC | TOP_SORTED | ACCESSIBLE | COACCESSIBLE | STRING |
+                                UNWEIGHTED_CYCLES;
+// properties.rs:166-194
+constexpr uint64_t SET_START_MASK = ACCEPTOR | NOT_ACCEPTOR | I_DETERMINISTIC | NOT_I_DETERMINISTIC |
+                                    O_DETERMINISTIC | NOT_O_DETERMINISTIC | EPSILONS | NO_EPSILONS | I_EPSILONS |
+                                    NO_I_EPSILONS | O_EPSILONS | NO_O_EPSILONS | I_LABEL_SORTED |
+                                    NOT_I_LABEL_SORTED | O_LABEL_SORTED | NOT_O_LABEL_SORTED | WEIGHTED |
+                                    UNWEIGHTED | CYCLIC | ACYCLIC | TOP_SORTED | NOT_TOP_SORTED | COACCESSIBLE |
+                                    NOT_COACCESSIBLE | WEIGHTED_CYCLES | UNWEIGHTED_CYCLES;
+// properties.rs:197-225
+constexpr uint64_t SET_FINAL_MASK = ACCEPTOR | NOT_ACCEPTOR | I_DETERMINISTIC | NOT_I_DETERMINISTIC |
+                                    O_DETERMINISTIC | NOT_O_DETERMINISTIC | EPSILONS | NO_EPSILONS | I_EPSILONS |
+                                    NO_I_EPSILONS | O_EPSILONS | NO_O_EPSILONS | I_LABEL_SORTED |
+                                    NOT_I_LABEL_SORTED | O_LABEL_SORTED | NOT_O_LABEL_SORTED | CYCLIC | ACYCLIC |
+                                    INITIAL_CYCLIC | INITIAL_ACYCLIC | TOP_SORTED | NOT_TOP_SORTED | ACCESSIBLE |
+                                    NOT_ACCESSIBLE | WEIGHTED_CYCLES | UNWEIGHTED_CYCLES;
+// properties.rs:228-259
+constexpr uint64_t ADD_STATE_MASK = ACCEPTOR | NOT_ACCEPTOR | I_DETERMINISTIC | NOT_I_DETERMINISTIC |
+                                    O_DETERMINISTIC | NOT_O_DETERMINISTIC | EPSILONS | NO_EPSILONS | I_EPSILONS |
+                                    NO_I_EPSILONS | O_EPSILONS | NO_O_EPSILONS | I_LABEL_SORTED |
+                                    NOT_I_LABEL_SORTED | O_LABEL_SORTED | NOT_O_LABEL_SORTED | WEIGHTED |
+                                    UNWEIGHTED | CYCLIC | ACYCLIC | INITIAL_CYCLIC | INITIAL_ACYCLIC | TOP_SORTED |
+                                    NOT_TOP_SORTED | NOT_ACCESSIBLE | NOT_COACCESSIBLE | NOT_STRING |
+                                    WEIGHTED_CYCLES | UNWEIGHTED_CYCLES;
+// properties.rs:262-278
+constexpr uint64_t ADD_ARC_MASK = NOT_ACCEPTOR | NOT_I_DETERMINISTIC | NOT_O_DETERMINISTIC | EPSILONS | I_EPSILONS |
+                                  O_EPSILONS | NOT_I_LABEL_SORTED | NOT_O_LABEL_SORTED | WEIGHTED | CYCLIC |
+                                  INITIAL_CYCLIC | NOT_TOP_SORTED | ACCESSIBLE | COACCESSIBLE | WEIGHTED_CYCLES;
+// properties.rs:286-300
+constexpr uint64_t DELETE_STATES_MASK = ACCEPTOR | I_DETERMINISTIC | O_DETERMINISTIC | NO_EPSILONS | NO_I_EPSILONS |
+                                        NO_O_EPSILONS | I_LABEL_SORTED | O_LABEL_SORTED | UNWEIGHTED | ACYCLIC |
+                                        INITIAL_ACYCLIC | TOP_SORTED | UNWEIGHTED_CYCLES;
+
+// mutate_properties.rs:7-13
+inline uint64_t set_start_properties(uint64_t in) {
+  uint64_t out = in & SET_START_MASK;
+  if (in & ACYCLIC) out |= INITIAL_ACYCLIC;
+  return out;
+}
+// mutate_properties.rs:15-37
+inline uint64_t set_final_properties(uint64_t in, const float* old_w, const float* new_w) {
+  uint64_t out = in;
+  if (old_w && !wis_zero(*old_w) && !wis_one(*old_w)) out &= ~WEIGHTED;
+  if (new_w && !wis_zero(*new_w) && !wis_one(*new_w)) {
+    out |= WEIGHTED;
+    out &= ~UNWEIGHTED;
+  }
+  out &= SET_FINAL_MASK | WEIGHTED | UNWEIGHTED;
+  return out;
+}
+inline uint64_t add_state_properties(uint64_t in) { return in & ADD_STATE_MASK; }  // :39-41
+// mutate_properties.rs:43-100
+inline uint64_t add_tr_properties(uint64_t in, uint32_t state, const oracle_tr& tr, const oracle_tr* prev) {
+  uint64_t out = in;
+  if (tr.ilabel != tr.olabel) {
+    out |= NOT_ACCEPTOR;
+    out &= ~ACCEPTOR;
+  }
+  if (tr.ilabel == EPS_LABEL) {
+    out |= I_EPSILONS;
+    out &= ~NO_I_EPSILONS;
+    if (tr.olabel == EPS_LABEL) {
+      out |= EPSILONS;
+      out &= ~NO_EPSILONS;
+    }
+  }
+  if (tr.olabel == EPS_LABEL) {
+    out |= O_EPSILONS;
+    out &= ~NO_O_EPSILONS;
+  }
+  if (prev) {
+    if (prev->ilabel > tr.ilabel) {
+      out |= NOT_I_LABEL_SORTED;
+      out &= ~I_LABEL_SORTED;
+    }
+    if (prev->olabel > tr.olabel) {
+      out |= NOT_O_LABEL_SORTED;
+      out &= ~O_LABEL_SORTED;
+    }
+  }
+  if (!wis_zero(tr.weight) && !wis_one(tr.weight)) {
+    out |= WEIGHTED;
+    out &= ~UNWEIGHTED;
+  }
+  if (tr.nextstate <= state) {
+    out |= NOT_TOP_SORTED;
+    out &= ~TOP_SORTED;
+  }
+  out &= ADD_ARC_MASK | ACCEPTOR | NO_EPSILONS | NO_I_EPSILONS | NO_O_EPSILONS | I_LABEL_SORTED | O_LABEL_SORTED |
+         UNWEIGHTED | TOP_SORTED;
+  if (out & TOP_SORTED) out |= ACYCLIC | INITIAL_ACYCLIC;
+  return out;
+}
+inline uint64_t delete_states_properties(uint64_t in) { return in & DELETE_STATES_MASK; }  // :102-104
+// mutate_properties.rs:151-184
+inline uint64_t compose_properties(uint64_t p1, uint64_t p2) {
+  uint64_t out = 0;
+  if ((p1 & ACCEPTOR) && (p2 & ACCEPTOR)) {
+    out |= ACCEPTOR | ACCESSIBLE;
+    out |= (NO_EPSILONS | NO_I_EPSILONS | NO_O_EPSILONS | ACYCLIC | INITIAL_ACYCLIC) & p1 & p2;
+    if ((p1 & NO_I_EPSILONS) && (p2 & NO_I_EPSILONS)) out |= (I_DETERMINISTIC | O_DETERMINISTIC) & p1 & p2;
+  } else {
+    out |= ACCESSIBLE;
+    out |= (ACCEPTOR | NO_I_EPSILONS | ACYCLIC | INITIAL_ACYCLIC) & p1 & p2;
+    if ((p1 & NO_I_EPSILONS) && (p2 & NO_I_EPSILONS)) out |= I_DETERMINISTIC & p1 & p2;
+  }
+  return out;
+}
+// mutate_properties.rs:662-672
+inline uint64_t shortest_path_properties(uint64_t props, bool tree) {
+  uint64_t out = props | ACYCLIC | INITIAL_ACYCLIC | ACCESSIBLE | UNWEIGHTED_CYCLES;
+  if (!tree) out |= COACCESSIBLE;
+  return out;
+}
+}  // namespace P
+
+using Tr = oracle_tr;
+
+// ---------------------------------------------------------------- VectorFst (T3)
+// fst_impls/vector_fst/data_structure.rs:16-34
+struct State {
+  bool has_final = false;  // Option<W>
+  float final_w = INF;
+  std::vector<Tr> trs;  // TrsVec(Arc<Vec<Tr>>)
+  size_t niepsilons = 0, noepsilons = 0;
+};
+
+}  // namespace
+
+struct oracle_fst {
+  std::vector<State> states;
+  bool has_start = false;
+  uint32_t start = 0;
+  uint64_t properties = P::NULL_PROPS;  // VectorFst::new(): mutable_fst.rs:25-33
+
+  size_t num_states() const { return states.size(); }
+  // mutable_fst.rs:35-44
+  bool set_start(uint32_t s) {
+    if (s >= states.size()) {
+      t_err = "The state " + std::to_string(s) + " doesn't exist";
+      return false;
+    }
+    has_start = true;
+    start = s;
+    properties = P::set_start_properties(properties);
+    return true;
+  }
+  // mutable_fst.rs:52-65
+  bool set_final(uint32_t s, float w) {
+    if (s >= states.size()) {
+      t_err = "Stateid " + std::to_string(s) + " doesn't exist";
+      return false;
+    }
+    State& st = states[s];
+    properties = P::set_final_properties(properties, st.has_final ? &st.final_w : nullptr, &w);
+    st.has_final = true;
+    st.final_w = w;
+    return true;
+  }
+  // mutable_fst.rs:82-87
+  uint32_t add_state() {
+    states.emplace_back();
+    properties = P::add_state_properties(properties);
+    return (uint32_t)(states.size() - 1);
+  }
+  // mutable_fst.rs:89-93
+  void add_states(size_t n) {
+    states.resize(states.size() + n);
+    properties = P::add_state_properties(properties);
+  }
+  // mutable_fst.rs:235-244 + data_structure.rs:76-92
+  bool add_tr(uint32_t source, const Tr& tr) {
+    if (source >= states.size()) {
+      t_err = "State " + std::to_string(source) + " doesn't exist";
+      return false;
+    }
+    State& st = states[source];
+    if (tr.ilabel == EPS_LABEL) st.niepsilons++;
+    if (tr.olabel == EPS_LABEL) st.noepsilons++;
+    st.trs.push_back(tr);
+    const Tr* prev = st.trs.size() > 1 ? &st.trs[st.trs.size() - 2] : nullptr;
+    properties = P::add_tr_properties(properties, source, st.trs.back(), prev);
+    return true;
+  }
+  // mutable_fst.rs:255-281
+  void set_trs_unchecked(uint32_t source, std::vector<Tr> trs) {
+    uint64_t props = properties;
+    State& st = states[source];
+    st.trs = std::move(trs);
+    size_t ni = 0, no = 0;
+    for (size_t i = 0; i < st.trs.size(); ++i) {
+      props = P::add_tr_properties(props, source, st.trs[i], i >= 1 ? &st.trs[i - 1] : nullptr);
+      if (st.trs[i].ilabel == EPS_LABEL) ni++;
+      if (st.trs[i].olabel == EPS_LABEL) no++;
+    }
+    st.niepsilons = ni;
+    st.noepsilons = no;
+    properties = props;
+  }
+  // mutable_fst.rs:132-189 (stable compaction; arcs into deleted states dropped in order)
+  void del_states(const std::vector<uint32_t>& dstates) {
+    std::vector<int32_t> new_id(states.size(), 0);
+    for (uint32_t s : dstates) new_id[s] = -1;
+    size_t nstates = 0;
+    for (size_t s = 0; s < states.size(); ++s) {
+      if (new_id[s] != -1) {
+        new_id[s] = (int32_t)nstates;
+        if (s != nstates) std::swap(states[nstates], states[s]);
+        nstates++;
+      }
+    }
+    states.resize(nstates);
+    for (size_t s = 0; s < states.size(); ++s) {
+      State& st = states[s];
+      size_t w = 0;
+      for (size_t i = 0; i < st.trs.size(); ++i) {
+        int32_t t = new_id[st.trs[i].nextstate];
+        if (t != -1) {
+          st.trs[i].nextstate = (uint32_t)t;
+          if (w != i) st.trs[w] = st.trs[i];
+          w++;
+        } else {
+          if (st.trs[i].ilabel == EPS_LABEL) st.niepsilons--;
+          if (st.trs[i].olabel == EPS_LABEL) st.noepsilons--;
+        }
+      }
+      st.trs.resize(w);
+    }
+    if (has_start) {
+      int32_t ns = new_id[start];
+      if (ns == -1)
+        has_start = false;
+      else
+        start = (uint32_t)ns;
+    }
+    properties = P::delete_states_properties(properties);
+  }
+  void set_properties(uint64_t p) { properties = p; }  // mutable_fst.rs:407-409
+  void set_properties_with_mask(uint64_t p, uint64_t mask) {  // :411-414
+    properties &= ~mask;
+    properties |= p & mask;
+  }
+};
+
+namespace {
+using Fst = oracle_fst;
+
+// ---------------------------------------------------------------- compose (A1-A9)
+enum class MatchType { MatchInput, MatchOutput, MatchBoth, MatchNone, MatchUnknown };  // matchers/mod.rs:57-69
+
+// SortedMatcher::match_type(test) — matchers/sorted_matcher.rs:56-85.
+// Returns false + t_err when properties_check fails (fst_traits/fst.rs:166-176).
+bool sorted_matcher_match_type(const Fst& fst, MatchType mt, bool test, MatchType* out) {
+  const uint64_t true_prop = mt == MatchType::MatchInput ? P::I_LABEL_SORTED : P::O_LABEL_SORTED;
+  const uint64_t false_prop = mt == MatchType::MatchInput ? P::NOT_I_LABEL_SORTED : P::NOT_O_LABEL_SORTED;
+  const uint64_t props = fst.properties;
+  if (test) {
+    // FstProperties::knows: for each trinary pair in the mask at least one bit must be set
+    if (!(props & (true_prop | false_prop))) {
+      t_err = "Properties are not known";
+      return false;
+    }
+  }
+  if (props & true_prop)
+    *out = mt;
+  else if (props & false_prop)
+    *out = MatchType::MatchNone;
+  else
+    *out = MatchType::MatchUnknown;
+  return true;
+}
+
+// ComposeFstOp::match_type — compose/compose_fst_op.rs:169-197 (SortedMatcher flags are empty)
+bool compose_match_type(const Fst& f1, const Fst& f2, MatchType* out) {
+  MatchType type1, type2, t;
+  sorted_matcher_match_type(f1, MatchType::MatchOutput, false, &type1);
+  sorted_matcher_match_type(f2, MatchType::MatchInput, false, &type2);
+  if (type1 == MatchType::MatchOutput && type2 == MatchType::MatchInput) {
+    *out = MatchType::MatchBoth;
+  } else if (type1 == MatchType::MatchOutput) {
+    *out = MatchType::MatchOutput;
+  } else if (type2 == MatchType::MatchInput) {
+    *out = MatchType::MatchInput;
+  } else {
+    if (!sorted_matcher_match_type(f1, MatchType::MatchOutput, true, &t)) return false;
+    if (t == MatchType::MatchOutput) {
+      *out = MatchType::MatchOutput;
+      return true;
+    }
+    if (!sorted_matcher_match_type(f2, MatchType::MatchInput, true, &t)) return false;
+    if (t == MatchType::MatchInput) {
+      *out = MatchType::MatchInput;
+      return true;
+    }
+    t_err =
+        "ComposeFst: 1st argument cannot match on output labels and 2nd argument cannot match on input labels "
+        "(sort?).";
+    return false;
+  }
+  return true;
+}
+
+// ComposeStateTuple — compose/compose_state_tuple.rs:10-15
+struct Tuple {
+  uint32_t fs, s1, s2;
+  bool operator==(const Tuple& o) const { return fs == o.fs && s1 == o.s1 && s2 == o.s2; }
+};
+struct TupleHash {
+  size_t operator()(const Tuple& t) const {
+    uint64_t h = ((uint64_t)t.s1 << 32) | t.s2;
+    h ^= (uint64_t)t.fs * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return (size_t)h;
+  }
+};
+// StateTable / BiHashMap — lazy/state_table.rs:20-64,102-125 (ids in first-lookup order)
+struct StateTable {
+  std::unordered_map<Tuple, uint32_t, TupleHash> tuple_to_id;
+  std::vector<Tuple> id_to_tuple;
+  uint32_t find_id(const Tuple& t) {
+    auto it = tuple_to_id.find(t);
+    if (it != tuple_to_id.end()) return it->second;
+    uint32_t n = (uint32_t)id_to_tuple.size();
+    id_to_tuple.push_back(t);
+    tuple_to_id.emplace(t, n);
+    return n;
+  }
+  Tuple find_tuple(uint32_t id) const { return id_to_tuple[id]; }
+};
+
+// IteratorSortedMatcher — matchers/sorted_matcher.rs:124-184
+struct MatcherIter {
+  const std::vector<Tr>* trs;
+  uint32_t match_label;
+  size_t pos;
+  bool current_loop;
+  bool by_ilabel;
+  MatcherIter(const std::vector<Tr>& t, uint32_t label, bool match_input) : trs(&t), by_ilabel(match_input) {
+    current_loop = label == EPS_LABEL;                   // :127
+    match_label = label == NO_LABEL ? EPS_LABEL : label;  // :131-135
+    if (current_loop) {
+      pos = 0;  // :138-139
+    } else {    // superslice lower_bound_by :141-142
+      size_t lo = 0, hi = t.size();
+      while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        uint32_t key = by_ilabel ? t[mid].ilabel : t[mid].olabel;
+        if (key < match_label)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      pos = lo;
+    }
+  }
+  // next() :168-184.  Returns 0 = exhausted, 1 = EpsLoop, 2 = real arc (*out)
+  int next(const Tr** out) {
+    if (current_loop) {
+      current_loop = false;
+      return 1;
+    }
+    if (pos < trs->size()) {
+      const Tr& tr = (*trs)[pos];
+      uint32_t key = by_ilabel ? tr.ilabel : tr.olabel;
+      if (key == match_label) {
+        pos++;
+        *out = &tr;
+        return 2;
+      }
+    }
+    return 0;
+  }
+};
+
+// SequenceComposeFilter — compose_filters/sequence_compose_filter.rs:118-175
+struct SequenceFilter {
+  const Fst* fst1;
+  uint32_t s1 = NO_STATE_ID, s2 = NO_STATE_ID, fs = NO_STATE_ID;
+  bool alleps1 = false, noeps1 = false;
+  void set_state(uint32_t s1_, uint32_t s2_, uint32_t fs_) {  // :134-148
+    if (!(s1 == s1_ && s2 == s2_ && fs == fs_)) {
+      s1 = s1_;
+      s2 = s2_;
+      fs = fs_;
+      const State& st = fst1->states[s1];
+      size_t na1 = st.trs.size();
+      size_t ne1 = st.noepsilons;
+      bool fin1 = st.has_final;
+      alleps1 = na1 == ne1 && !fin1;
+      noeps1 = ne1 == 0;
+    }
+  }
+  uint32_t filter_tr(const Tr& arc1, const Tr& arc2) const {  // :150-171
+    if (arc1.olabel == NO_LABEL) {
+      if (alleps1) return NO_STATE_ID;
+      return noeps1 ? 0u : 1u;
+    } else if (arc2.ilabel == NO_LABEL) {
+      return fs != 0 ? NO_STATE_ID : 0u;
+    } else if (arc1.olabel == EPS_LABEL) {
+      return NO_STATE_ID;
+    }
+    return 0u;
+  }
+};
+
+// ComposeFstOp — compose/compose_fst_op.rs
+struct ComposeOp {
+  const Fst& fst1;
+  const Fst& fst2;
+  MatchType match_type;
+  uint64_t properties;
+  StateTable table;
+
+  ComposeOp(const Fst& a, const Fst& b, MatchType mt)
+      : fst1(a), fst2(b), match_type(mt), properties(P::compose_properties(a.properties, b.properties)) {}
+
+  // compute_start :389-404
+  bool compute_start(uint32_t* out) {
+    if (!fst1.has_start) return false;
+    if (!fst2.has_start) return false;
+    *out = table.find_id(Tuple{0u, fst1.start, fst2.start});
+    return true;
+  }
+  // match_input :199-219 (SortedMatcher::priority = num_trs, sorted_matcher.rs:91-93)
+  bool match_input(uint32_t s1, uint32_t s2) const {
+    switch (match_type) {
+      case MatchType::MatchInput: return true;
+      case MatchType::MatchOutput: return false;
+      default: return fst1.states[s1].trs.size() <= fst2.states[s2].trs.size();
+    }
+  }
+  // add_tr :267-285
+  Tr add_tr(Tr arc1, const Tr& arc2, uint32_t fs) {
+    Tuple tuple{fs, arc1.nextstate, arc2.nextstate};
+    arc1.weight = wtimes(arc1.weight, arc2.weight);
+    return Tr{arc1.ilabel, arc2.olabel, arc1.weight, table.find_id(tuple)};
+  }
+  // match_tr :324-353 + match_tr_selected :287-322
+  void match_tr(uint32_t sa, const Tr& tr, bool mi, SequenceFilter& filter, std::vector<Tr>& trs) {
+    const uint32_t label = mi ? tr.olabel : tr.ilabel;
+    // Fst1Matcher2 (mi): matcher2 on fst2 by ilabel; Fst2Matcher1: matcher1 on fst1 by olabel
+    const std::vector<Tr>& sa_trs = mi ? fst2.states[sa].trs : fst1.states[sa].trs;
+    MatcherIter it(sa_trs, label, /*by_ilabel=*/mi);
+    const Tr* real = nullptr;
+    for (;;) {
+      int k = it.next(&real);
+      if (k == 0) break;
+      Tr arca;
+      if (k == 1) {  // eps_loop(sa, match_type): matchers/mod.rs:98-105
+        arca = mi ? Tr{NO_LABEL, EPS_LABEL, 0.0f, sa} : Tr{EPS_LABEL, NO_LABEL, 0.0f, sa};
+      } else {
+        arca = *real;
+      }
+      Tr arcb = tr;
+      if (mi) {
+        uint32_t fs = filter.filter_tr(arcb, arca);
+        if (fs != NO_STATE_ID) trs.push_back(add_tr(arcb, arca, fs));
+      } else {
+        uint32_t fs = filter.filter_tr(arca, arcb);
+        if (fs != NO_STATE_ID) trs.push_back(add_tr(arca, arcb, fs));
+      }
+    }
+  }
+  // ordered_expand :221-265
+  std::vector<Tr> ordered_expand(uint32_t sa, uint32_t sb, bool mi, SequenceFilter& filter) {
+    Tr tr_loop = mi ? Tr{EPS_LABEL, NO_LABEL, 0.0f, sb} : Tr{NO_LABEL, EPS_LABEL, 0.0f, sb};
+    std::vector<Tr> trs;
+    match_tr(sa, tr_loop, mi, filter, trs);
+    const std::vector<Tr>& sb_trs = mi ? fst1.states[sb].trs : fst2.states[sb].trs;
+    for (const Tr& tr : sb_trs) match_tr(sa, tr, mi, filter, trs);
+    return trs;
+  }
+  // compute_trs :406-418
+  std::vector<Tr> compute_trs(uint32_t state) {
+    Tuple tuple = table.find_tuple(state);
+    SequenceFilter filter{&fst1};
+    filter.set_state(tuple.s1, tuple.s2, tuple.fs);
+    if (match_input(tuple.s1, tuple.s2)) return ordered_expand(tuple.s2, tuple.s1, true, filter);
+    return ordered_expand(tuple.s1, tuple.s2, false, filter);
+  }
+  // compute_final_weight :420-449
+  bool compute_final_weight(uint32_t state, float* out) const {
+    Tuple tuple = table.find_tuple(state);
+    const State& a = fst1.states[tuple.s1];
+    if (!a.has_final) return false;
+    const State& b = fst2.states[tuple.s2];
+    if (!b.has_final) return false;
+    float f = wtimes(a.final_w, b.final_w);
+    if (wis_zero(f)) return false;
+    *out = f;
+    return true;
+  }
+};
+
+void connect_impl(Fst& fst);
+
+// compose_with_config (AutoFilter / SequenceFilter + SortedMatcher) — compose_static.rs:166-266;
+// LazyFst::compute — lazy/lazy_fst.rs:226-269
+bool compose_impl(const Fst& fst1, const Fst& fst2, bool connect, Fst& fst_out, uint64_t* arcs_pre_trim) {
+  MatchType mt;
+  if (!compose_match_type(fst1, fst2, &mt)) return false;
+  ComposeOp op(fst1, fst2, mt);
+  fst_out = Fst();
+  uint32_t start_state;
+  uint64_t n_arcs = 0;
+  if (op.compute_start(&start_state)) {
+    fst_out.add_states((size_t)start_state + 1);
+    fst_out.set_start(start_state);
+    std::deque<uint32_t> queue;
+    std::vector<bool> visited((size_t)start_state + 1, false);
+    visited[start_state] = true;
+    queue.push_back(start_state);
+    while (!queue.empty()) {
+      uint32_t s = queue.front();
+      queue.pop_front();
+      std::vector<Tr> trs = op.compute_trs(s);
+      for (const Tr& tr : trs) {
+        if ((size_t)tr.nextstate >= visited.size()) visited.resize((size_t)tr.nextstate + 1, false);
+        if (!visited[tr.nextstate]) {
+          queue.push_back(tr.nextstate);
+          visited[tr.nextstate] = true;
+        }
+        size_t n = fst_out.num_states();
+        if ((size_t)tr.nextstate >= n) fst_out.add_states((size_t)tr.nextstate - n + 1);
+      }
+      n_arcs += trs.size();
+      fst_out.set_trs_unchecked(s, std::move(trs));
+      float fw;
+      if (op.compute_final_weight(s, &fw)) fst_out.set_final(s, fw);
+    }
+    fst_out.set_properties(op.properties);  // lazy_fst.rs:260
+  }
+  // (start None: `return Ok(fst_out)` with F2::new() properties, lazy_fst.rs:229-232)
+  if (arcs_pre_trim) *arcs_pre_trim = n_arcs;
+  if (connect) connect_impl(fst_out);  // compose_static.rs:261-263
+  return true;
+}
+
+// ---------------------------------------------------------------- dfs_visit (dfs_visit.rs:97-187)
+// AnyTrFilter keeps every arc (tr_filters.rs).
+template <class V>
+void dfs_visit(const Fst& fst, V& visitor, bool access_only) {
+  visitor.init_visit(fst);
+  if (!fst.has_start) {
+    visitor.finish_visit();
+    return;
+  }
+  const uint32_t start = fst.start;
+  const size_t nstates = fst.num_states();
+  enum : uint8_t { White, Grey, Black };
+  std::vector<uint8_t> color(nstates, White);
+  struct DfsState {
+    uint32_t state_id;
+    size_t pos;
+  };
+  std::vector<DfsState> stack;
+  bool dfs = true;
+  uint32_t root = start;
+  for (;;) {
+    if (!dfs || (size_t)root >= nstates) break;
+    color[root] = Grey;
+    stack.push_back({root, 0});
+    dfs = visitor.init_state(root, root);
+    while (!stack.empty()) {
+      DfsState& ds = stack.back();
+      const uint32_t s = ds.state_id;
+      const std::vector<Tr>& trs = fst.states[s].trs;
+      if (!dfs || ds.pos >= trs.size()) {
+        color[s] = Black;
+        stack.pop_back();
+        if (!stack.empty()) {
+          DfsState& parent = stack.back();
+          visitor.finish_state(s, true, parent.state_id);
+          parent.pos++;
+        } else {
+          visitor.finish_state(s, false, 0);
+        }
+        continue;
+      }
+      const Tr& tr = trs[ds.pos];
+      switch (color[tr.nextstate]) {
+        case White:
+          dfs = visitor.tree_tr(s, tr);
+          if (!dfs) break;
+          color[tr.nextstate] = Grey;
+          dfs = visitor.init_state(tr.nextstate, root);
+          stack.push_back({tr.nextstate, 0});  // (ds is invalid from here)
+          break;
+        case Grey:
+          dfs = visitor.back_tr(s, tr);
+          ds.pos++;
+          break;
+        default:
+          dfs = visitor.forward_or_cross_tr(s, tr);
+          ds.pos++;
+          break;
+      }
+    }
+    if (access_only) break;
+    root = root == start ? 0 : root + 1;
+    while ((size_t)root < nstates && color[root] != White) root++;
+  }
+  visitor.finish_visit();
+}
+// NOTE on the `White` branch: the reference `break`s out of the inner while when tree_tr returns
+// false (dfs_visit.rs:150-153); no visitor used on this path returns false from tree_tr.
+
+// SccVisitor — visitors/scc_visitors.rs:10-180 (ConnectVisitor connect.rs:69-189 is the same
+// machinery without scc ids; one struct serves both)
+struct SccVisitor {
+  const Fst* fst = nullptr;
+  bool compute_scc;
+  std::vector<int32_t> scc;
+  std::vector<bool> access, coaccess;
+  uint32_t start = NO_STATE_ID;
+  size_t nstates = 0;
+  std::vector<int32_t> dfnumber, lowlink;
+  std::vector<bool> onstack;
+  std::vector<uint32_t> scc_stack;
+  int32_t nscc = 0;
+  explicit SccVisitor(const Fst& f, bool compute_scc_) : fst(&f), compute_scc(compute_scc_) {
+    size_t n = f.num_states();
+    if (compute_scc) scc.assign(n, -1);
+    access.assign(n, false);
+    coaccess.assign(n, false);
+    start = f.has_start ? f.start : NO_STATE_ID;
+    dfnumber.assign(n, -1);
+    lowlink.assign(n, -1);
+    onstack.assign(n, false);
+  }
+  void init_visit(const Fst&) {}
+  bool init_state(uint32_t s, uint32_t root) {  // connect.rs:106-115 / scc_visitors.rs:68-88
+    scc_stack.push_back(s);
+    dfnumber[s] = (int32_t)nstates;
+    lowlink[s] = (int32_t)nstates;
+    onstack[s] = true;
+    access[s] = root == start;
+    nstates++;
+    return true;
+  }
+  bool tree_tr(uint32_t, const Tr&) { return true; }
+  bool back_tr(uint32_t s, const Tr& tr) {  // connect.rs:121-131
+    uint32_t t = tr.nextstate;
+    if (dfnumber[t] < lowlink[s]) lowlink[s] = dfnumber[t];
+    if (coaccess[t]) coaccess[s] = true;
+    return true;
+  }
+  bool forward_or_cross_tr(uint32_t s, const Tr& tr) {  // connect.rs:133-146
+    uint32_t t = tr.nextstate;
+    if (dfnumber[t] < dfnumber[s] && onstack[t] && dfnumber[t] < lowlink[s]) lowlink[s] = dfnumber[t];
+    if (coaccess[t]) coaccess[s] = true;
+    return true;
+  }
+  void finish_state(uint32_t s, bool has_parent, uint32_t parent) {  // connect.rs:148-185 / scc_visitors.rs:128-170
+    if (fst->states[s].has_final) coaccess[s] = true;
+    if (dfnumber[s] == lowlink[s]) {
+      bool scc_coaccess = false;
+      size_t i = scc_stack.size();
+      uint32_t t;
+      do {
+        i--;
+        t = scc_stack[i];
+        if (coaccess[t]) scc_coaccess = true;
+      } while (s != t);
+      do {
+        t = scc_stack.back();
+        if (compute_scc) scc[t] = nscc;
+        if (scc_coaccess) coaccess[t] = true;
+        onstack[t] = false;
+        scc_stack.pop_back();
+      } while (s != t);
+      nscc++;
+    }
+    if (has_parent) {
+      if (coaccess[s]) coaccess[parent] = true;
+      if (lowlink[s] < lowlink[parent]) lowlink[parent] = lowlink[s];
+    }
+  }
+  void finish_visit() {  // scc_visitors.rs:172-179
+    if (compute_scc)
+      for (auto& c : scc) c = nscc - 1 - c;
+  }
+};
+
+// connect — connect.rs:51-66
+void connect_impl(Fst& fst) {
+  SccVisitor visitor(fst, false);
+  dfs_visit(fst, visitor, false);
+  std::vector<uint32_t> dstates;
+  for (size_t s = 0; s < visitor.access.size(); ++s)
+    if (!visitor.access[s] || !visitor.coaccess[s]) dstates.push_back((uint32_t)s);
+  fst.del_states(dstates);
+  fst.set_properties_with_mask(P::ACCESSIBLE | P::COACCESSIBLE, P::ACCESSIBLE | P::COACCESSIBLE);
+}
+
+// TopOrderVisitor — top_sort.rs:12-61
+struct TopOrderVisitor {
+  std::vector<uint32_t> order, finish;
+  bool acyclic = true;
+  void init_visit(const Fst&) {}
+  bool init_state(uint32_t, uint32_t) { return true; }
+  bool tree_tr(uint32_t, const Tr&) { return true; }
+  bool back_tr(uint32_t, const Tr&) {
+    acyclic = false;
+    return false;
+  }
+  bool forward_or_cross_tr(uint32_t, const Tr&) { return true; }
+  void finish_state(uint32_t s, bool, uint32_t) { finish.push_back(s); }
+  void finish_visit() {
+    if (acyclic) {
+      order.assign(finish.size(), 0);
+      for (size_t s = 0; s < finish.size(); ++s) order[finish[finish.size() - s - 1]] = (uint32_t)s;
+    }
+  }
+};
+
+// ---------------------------------------------------------------- queues (B2)
+enum class QueueType { Trivial, Fifo, Lifo, ShortestFirst };  // queue.rs:6-26 (subset used)
+
+struct Queue {  // queue.rs:30-38
+  virtual ~Queue() = default;
+  virtual void enqueue(uint32_t s) = 0;
+  virtual bool dequeue(uint32_t* s) = 0;
+  virtual void update(uint32_t) {}
+  virtual bool is_empty() const = 0;
+  virtual void clear() = 0;
+};
+struct FifoQueue : Queue {  // queues/fifo_queue.rs
+  std::deque<uint32_t> q;
+  void enqueue(uint32_t s) override { q.push_back(s); }
+  bool dequeue(uint32_t* s) override {
+    if (q.empty()) return false;
+    *s = q.front();
+    q.pop_front();
+    return true;
+  }
+  bool is_empty() const override { return q.empty(); }
+  void clear() override { q.clear(); }
+};
+struct LifoQueue : Queue {  // queues/lifo_queue.rs
+  std::vector<uint32_t> q;
+  void enqueue(uint32_t s) override { q.push_back(s); }
+  bool dequeue(uint32_t* s) override {
+    if (q.empty()) return false;
+    *s = q.back();
+    q.pop_back();
+    return true;
+  }
+  bool is_empty() const override { return q.empty(); }
+  void clear() override { q.clear(); }
+};
+struct TrivialQueue : Queue {  // queues/trivial_queue.rs
+  bool has = false;
+  uint32_t st = 0;
+  void enqueue(uint32_t s) override {
+    has = true;
+    st = s;
+  }
+  bool dequeue(uint32_t* s) override {
+    if (!has) return false;
+    *s = st;
+    has = false;
+    return true;
+  }
+  bool is_empty() const override { return !has; }
+  void clear() override { has = false; }
+};
+struct StateOrderQueue : Queue {  // queues/state_order_queue.rs
+  size_t front = 0;
+  bool has_back = false;
+  size_t back = 0;
+  std::vector<bool> enqueued;
+  void enqueue(uint32_t s) override {
+    size_t state = s;
+    if (!has_back || front > back) {
+      front = state;
+      back = state;
+      has_back = true;
+    } else if (state > back) {
+      back = state;
+    } else if (state < front) {
+      front = state;
+    }
+    while (enqueued.size() <= state) enqueued.push_back(false);
+    enqueued[state] = true;
+  }
+  bool dequeue(uint32_t* s) override {
+    if (is_empty()) return false;
+    *s = (uint32_t)front;
+    enqueued[front] = false;
+    if (has_back)
+      while (front <= back && !enqueued[front]) front++;
+    return true;
+  }
+  bool is_empty() const override { return has_back ? front > back : true; }
+  void clear() override {
+    if (has_back)
+      for (size_t i = front; i <= back; ++i) enqueued[i] = false;
+    front = 0;
+    has_back = false;
+  }
+};
+struct TopOrderQueue : Queue {  // queues/top_order_queue.rs:12-94
+  std::vector<uint32_t> order;
+  std::vector<int64_t> state;  // Option<StateId>: -1 = None
+  uint32_t front = 0;
+  bool has_back = false;
+  uint32_t back = 0;
+  explicit TopOrderQueue(std::vector<uint32_t> o) : order(std::move(o)), state(order.size(), -1) {}
+  void enqueue(uint32_t s) override {
+    if (!has_back || front > back) {
+      front = order[s];
+      back = order[s];
+      has_back = true;
+    } else if (order[s] > back) {
+      back = order[s];
+    } else if (order[s] < front) {
+      front = order[s];
+    }
+    state[order[s]] = s;
+  }
+  bool dequeue(uint32_t* s) override {
+    if (is_empty()) return false;
+    int64_t old_head = state[front];
+    state[front] = -1;
+    if (has_back)
+      while (front <= back && state[front] < 0) front++;
+    // (the reference returns Option; None cannot happen when !is_empty)
+    if (old_head < 0) return false;
+    *s = (uint32_t)old_head;
+    return true;
+  }
+  bool is_empty() const override { return has_back ? front > back : true; }
+  void clear() override {
+    if (has_back)
+      for (uint32_t i = front; i <= back; ++i) state[i] = -1;
+    front = 0;
+    has_back = false;
+  }
+};
+struct SccQueue : Queue {  // queues/scc_queue.rs:6-84
+  int32_t front = 0, back = -1;
+  std::vector<std::unique_ptr<Queue>> queues;
+  std::vector<uint32_t> sccs;
+  void update_front() {
+    while (front <= back && queues[front]->is_empty()) front++;
+  }
+  void enqueue(uint32_t s) override {
+    int32_t c = (int32_t)sccs[s];
+    if (front > back) {
+      front = c;
+      back = c;
+    } else if (c > back) {
+      back = c;
+    } else if (c < front) {
+      front = c;
+    }
+    queues[sccs[s]]->enqueue(s);
+  }
+  bool dequeue(uint32_t* s) override {
+    if (is_empty()) return false;
+    update_front();
+    return queues[front]->dequeue(s);
+  }
+  void update(uint32_t s) override { queues[sccs[s]]->update(s); }
+  bool is_empty() const override {
+    if (front < back) return false;
+    if (front > back) return true;
+    return queues[front]->is_empty();
+  }
+  void clear() override {
+    for (int32_t i = front; i <= back; ++i) queues[i]->clear();
+    front = 0;
+    back = -1;
+  }
+};
+
+// AutoQueue::new(fst, distance=None, AnyTrFilter) — queues/auto_queue.rs:23-157.
+// With distance=None `less` is None (:52-59) so every intra-SCC arc selects FifoQueue (:130-131).
+std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
+  const uint64_t props = fst.properties;
+  if ((props & P::TOP_SORTED) || !fst.has_start) {
+    t_queue_kind = "state_order";
+    return std::make_unique<StateOrderQueue>();
+  }
+  if (props & P::ACYCLIC) {
+    TopOrderVisitor v;
+    dfs_visit(fst, v, false);
+    // (reference panics if !acyclic, top_order_queue.rs:24-26)
+    t_queue_kind = "top_order";
+    return std::make_unique<TopOrderQueue>(std::move(v.order));
+  }
+  if (props & P::UNWEIGHTED) {  // Tropical is IDEMPOTENT
+    t_queue_kind = "lifo";
+    return std::make_unique<LifoQueue>();
+  }
+  SccVisitor sv(fst, true);
+  dfs_visit(fst, sv, false);
+  std::vector<uint32_t> sccs(sv.scc.size());
+  for (size_t i = 0; i < sccs.size(); ++i) sccs[i] = (uint32_t)sv.scc[i];
+  const size_t n_sccs = (size_t)sv.nscc;
+  std::vector<QueueType> queue_types(n_sccs, QueueType::Trivial);
+  // scc_queue_type :101-157 with compare = None
+  bool all_trivial = true, unweighted = true;
+  for (size_t state = 0; state < fst.num_states(); ++state) {
+    for (const Tr& tr : fst.states[state].trs) {
+      if (sccs[state] == sccs[tr.nextstate]) {
+        QueueType& qt = queue_types[sccs[state]];
+        qt = QueueType::Fifo;  // compare.is_none()
+        if (qt != QueueType::Trivial) all_trivial = false;
+      }
+      if (!wis_zero(tr.weight) && !wis_one(tr.weight)) unweighted = false;
+    }
+  }
+  if (unweighted) {
+    t_queue_kind = "lifo";
+    return std::make_unique<LifoQueue>();
+  }
+  if (all_trivial) {
+    t_queue_kind = "top_order_scc";
+    return std::make_unique<TopOrderQueue>(std::move(sccs));
+  }
+  auto q = std::make_unique<SccQueue>();
+  q->queues.reserve(n_sccs);
+  for (size_t i = 0; i < n_sccs; ++i) {
+    if (queue_types[i] == QueueType::Trivial)
+      q->queues.push_back(std::make_unique<TrivialQueue>());
+    else
+      q->queues.push_back(std::make_unique<FifoQueue>());
+  }
+  q->sccs = std::move(sccs);
+  t_queue_kind = "scc";
+  return q;
+}
+
+// ---------------------------------------------------------------- shortest path n=1 (B1,B3)
+// single_shortest_path — shortest_path.rs:173-239
+struct Parent {
+  bool some = false;
+  uint32_t state = 0;
+  size_t pos = 0;
+};
+void single_shortest_path(const Fst& ifst, std::vector<float>& distance, bool& has_f_parent, uint32_t& f_parent,
+                          std::vector<Parent>& parent) {
+  parent.clear();
+  has_f_parent = false;
+  if (!ifst.has_start) return;
+  std::vector<bool> enqueued;
+  std::unique_ptr<Queue> queue = auto_queue_new(ifst);
+  const uint32_t source = ifst.start;
+  float f_distance = INF;
+  distance.clear();
+  queue->clear();
+  distance.assign(ifst.num_states(), INF);
+  enqueued.assign(ifst.num_states(), false);
+  parent.assign(ifst.num_states(), Parent{});
+  distance[source] = 0.0f;
+  enqueued[source] = true;
+  queue->enqueue(source);
+  uint32_t s;
+  while (queue->dequeue(&s)) {
+    enqueued[s] = false;
+    const float sd = distance[s];
+    const State& st = ifst.states[s];
+    if (st.has_final) {
+      float plus = wplus(f_distance, wtimes(sd, st.final_w));
+      if (!weq(f_distance, plus)) {
+        f_distance = plus;
+        has_f_parent = true;
+        f_parent = s;
+      }
+    }
+    for (size_t pos = 0; pos < st.trs.size(); ++pos) {
+      const Tr& tr = st.trs[pos];
+      const size_t nextstate = tr.nextstate;
+      float& nd = distance[nextstate];
+      const float weight = wtimes(sd, tr.weight);
+      if (!weq(nd, wplus(nd, weight))) {
+        nd = wplus(nd, weight);
+        parent[nextstate] = Parent{true, s, pos};
+        if (!enqueued[nextstate]) {
+          queue->enqueue((uint32_t)nextstate);
+          enqueued[nextstate] = true;
+        } else {
+          queue->update((uint32_t)nextstate);
+        }
+      }
+    }
+  }
+}
+
+// single_shortest_path_backtrace — shortest_path.rs:241-282
+bool backtrace(const Fst& ifst, bool has_f_parent, uint32_t f_parent, const std::vector<Parent>& parent, Fst& ofst) {
+  ofst = Fst();
+  bool has_s_p = false, has_d_p = false, has_d = false;
+  uint32_t s_p = 0, d_p = 0, d = 0;
+  bool has_next = has_f_parent;
+  uint32_t state = f_parent;
+  size_t guard = 0;
+  while (has_next) {
+    if (++guard > ifst.num_states() + 1) {
+      t_err = "backtrace: parent chain is cyclic";
+      return false;
+    }
+    has_d_p = has_s_p;
+    d_p = s_p;
+    s_p = ofst.add_state();
+    has_s_p = true;
+    if (has_d) {
+      size_t pos = parent[d].pos;
+      Tr tr = ifst.states[state].trs[pos];
+      tr.nextstate = d_p;
+      (void)has_d_p;
+      ofst.add_tr(s_p, tr);
+    } else if (ifst.states[f_parent].has_final) {
+      ofst.set_final(s_p, ifst.states[f_parent].final_w);
+    }
+    d = state;
+    has_d = true;
+    has_next = parent[state].some;
+    state = parent[state].state;
+  }
+  if (has_s_p) ofst.set_start(s_p);
+  ofst.set_properties_with_mask(P::shortest_path_properties(ofst.properties, true), P::ALL);
+  return true;
+}
+
+// ---------------------------------------------------------------- canonical (deterministic-tie) shortest path
+struct Canon {
+  std::vector<float> d;
+  std::vector<uint32_t> h;
+  bool has_final = false;
+  uint32_t f_parent = 0;
+  float total = INF;
+  std::vector<Parent> parent;
+};
+inline bool key_less(float d1, uint32_t h1, float d2, uint32_t h2) { return d1 < d2 || (d1 == d2 && h1 < h2); }
+
+void canonical_sssp(const Fst& f, Canon& c) {
+  const size_t n = f.num_states();
+  c.d.assign(n, INF);
+  c.h.assign(n, 0xFFFFFFFFu);
+  c.parent.assign(n, Parent{});
+  if (!f.has_start) return;
+  std::deque<uint32_t> q;
+  std::vector<bool> inq(n, false);
+  c.d[f.start] = 0.0f;
+  c.h[f.start] = 0;
+  q.push_back(f.start);
+  inq[f.start] = true;
+  while (!q.empty()) {
+    uint32_t s = q.front();
+    q.pop_front();
+    inq[s] = false;
+    const float sd = c.d[s];
+    const uint32_t sh = c.h[s];
+    for (const Tr& tr : f.states[s].trs) {
+      float cand = (sd + tr.weight) + 0.0f;  // +0.0f canonicalises -0.0
+      if (!(cand < INF)) continue;           // +inf / NaN never relax (plus(inf) == inf in the reference)
+      uint32_t ch = sh + 1;
+      uint32_t t = tr.nextstate;
+      if (key_less(cand, ch, c.d[t], c.h[t])) {
+        c.d[t] = cand;
+        c.h[t] = ch;
+        if (!inq[t]) {
+          inq[t] = true;
+          q.push_back(t);
+        }
+      }
+    }
+  }
+  // final: min (d[s]+rho(s), s)
+  for (size_t s = 0; s < n; ++s) {
+    const State& st = f.states[s];
+    if (!st.has_final || !(c.d[s] < INF)) continue;
+    float tot = c.d[s] + st.final_w;
+    if (!(tot < INF)) continue;
+    if (!c.has_final || tot < c.total) {
+      c.has_final = true;
+      c.total = tot;
+      c.f_parent = (uint32_t)s;
+    }
+  }
+  // parents: min (s,pos) among layered tight arcs
+  for (size_t s = 0; s < n; ++s) {
+    if (!(c.d[s] < INF)) continue;
+    const State& st = f.states[s];
+    for (size_t pos = 0; pos < st.trs.size(); ++pos) {
+      const Tr& tr = st.trs[pos];
+      uint32_t t = tr.nextstate;
+      float cand = (c.d[s] + tr.weight) + 0.0f;
+      if (!(cand < INF)) continue;
+      if (cand == c.d[t] && c.h[s] + 1 == c.h[t]) {
+        Parent& p = c.parent[t];
+        if (!p.some) p = Parent{true, (uint32_t)s, pos};  // s ascending, pos ascending => first is min
+      }
+    }
+  }
+}
+
+// count path positions with >1 (unlayered) tight incoming arcs, plus a final-state tie
+uint32_t canonical_count_ties(const Fst& f, const Canon& c) {
+  if (!c.has_final) return 0;
+  const size_t n = f.num_states();
+  std::vector<uint8_t> on_path(n, 0);
+  uint32_t cur = c.f_parent;
+  for (size_t guard = 0; guard <= n; ++guard) {
+    on_path[cur] = 1;
+    if (!c.parent[cur].some) break;
+    cur = c.parent[cur].state;
+  }
+  std::vector<uint32_t> tight(n, 0);
+  for (size_t s = 0; s < n; ++s) {
+    if (!(c.d[s] < INF)) continue;
+    for (const Tr& tr : f.states[s].trs) {
+      if (!on_path[tr.nextstate]) continue;
+      float cand = (c.d[s] + tr.weight) + 0.0f;
+      if (cand < INF && cand == c.d[tr.nextstate]) tight[tr.nextstate]++;
+    }
+  }
+  uint32_t ties = 0;
+  for (size_t s = 0; s < n; ++s) {
+    if (!on_path[s]) continue;
+    uint32_t expect = (f.has_start && s == f.start) ? 0u : 1u;
+    if (tight[s] > expect) ties++;
+  }
+  uint32_t nfinal = 0;
+  for (size_t s = 0; s < n; ++s) {
+    const State& st = f.states[s];
+    if (st.has_final && c.d[s] < INF && c.d[s] + st.final_w == c.total) nfinal++;
+  }
+  if (nfinal > 1) ties++;
+  return ties;
+}
+
+// ---------------------------------------------------------------- binary I/O (L1)
+// parsers/bin_fst/fst_header.rs:71-137, vector_fst/serializable_fst.rs:45-168, utils_parsing.rs:10-44
+struct Reader {
+  const uint8_t* p;
+  size_t n, off = 0;
+  bool ok = true;
+  template <class T>
+  T get() {
+    T v{};
+    if (off + sizeof(T) > n) {
+      ok = false;
+      return v;
+    }
+    std::memcpy(&v, p + off, sizeof(T));
+    off += sizeof(T);
+    return v;
+  }
+  std::string str() {
+    int32_t len = get<int32_t>();
+    if (!ok || len < 0 || off + (size_t)len > n) {
+      ok = false;
+      return {};
+    }
+    std::string s((const char*)p + off, (size_t)len);
+    off += (size_t)len;
+    return s;
+  }
+};
+// symbol table skip: parsers/bin_symt/nom_parser.rs (magic i32, name, available_key i64, size i64, {symbol,key}*)
+bool skip_symt(Reader& r) {
+  int32_t magic = r.get<int32_t>();
+  if (!r.ok || magic != 2125658996) return false;
+  r.str();
+  r.get<int64_t>();
+  int64_t num = r.get<int64_t>();
+  for (int64_t i = 0; i < num && r.ok; ++i) {
+    r.str();
+    r.get<int64_t>();
+  }
+  return r.ok;
+}
+
+Fst* load_vector_fst(const uint8_t* data, size_t len) {
+  Reader r{data, len};
+  int32_t magic = r.get<int32_t>();
+  if (!r.ok || magic != 2125659606) {
+    t_err = "bad magic number";
+    return nullptr;
+  }
+  std::string fst_type = r.str(), arc_type = r.str();
+  if (!r.ok || fst_type != "vector" || arc_type != "standard") {
+    t_err = "expected fst_type=vector arc_type=standard, got '" + fst_type + "'/'" + arc_type + "'";
+    return nullptr;
+  }
+  int32_t version = r.get<int32_t>();
+  if (!r.ok || version < 2) {
+    t_err = "unsupported vector fst version";
+    return nullptr;
+  }
+  uint32_t flags = r.get<uint32_t>();
+  uint64_t props = r.get<uint64_t>();
+  int64_t start = r.get<int64_t>();
+  int64_t num_states = r.get<int64_t>();
+  (void)r.get<int64_t>();  // num_trs: ignored by the reference parser (serializable_fst.rs:157)
+  if (!r.ok || (flags & ~7u)) {
+    t_err = "bad header";
+    return nullptr;
+  }
+  if ((flags & 1u) && !skip_symt(r)) {
+    t_err = "bad input symbol table";
+    return nullptr;
+  }
+  if ((flags & 2u) && !skip_symt(r)) {
+    t_err = "bad output symbol table";
+    return nullptr;
+  }
+  auto fst = std::make_unique<Fst>();
+  fst->states.resize((size_t)num_states);
+  for (int64_t s = 0; s < num_states; ++s) {
+    State& st = fst->states[(size_t)s];
+    float fw = r.get<float>();
+    int64_t ntrs = r.get<int64_t>();
+    if (!r.ok || ntrs < 0) {
+      t_err = "truncated state";
+      return nullptr;
+    }
+    // parse_final_weight: utils_parsing.rs:18-26 (approximate != zero)
+    {
+      float saved = t_delta;
+      t_delta = KDELTA;
+      if (!weq(fw, INF)) {
+        st.has_final = true;
+        st.final_w = fw;
+      }
+      t_delta = saved;
+    }
+    st.trs.resize((size_t)ntrs);
+    for (int64_t i = 0; i < ntrs; ++i) {
+      Tr& tr = st.trs[(size_t)i];
+      tr.ilabel = (uint32_t)r.get<int32_t>();
+      tr.olabel = (uint32_t)r.get<int32_t>();
+      tr.weight = r.get<float>();
+      tr.nextstate = (uint32_t)r.get<int32_t>();
+      if (tr.ilabel == EPS_LABEL) st.niepsilons++;
+      if (tr.olabel == EPS_LABEL) st.noepsilons++;
+    }
+    if (!r.ok) {
+      t_err = "truncated arcs";
+      return nullptr;
+    }
+  }
+  fst->has_start = start != -1;
+  fst->start = start == -1 ? 0u : (uint32_t)start;
+  fst->properties = props & P::ALL;  // from_bits_truncate
+  return fst.release();
+}
+
+size_t store_vector_fst(const Fst& f, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> buf;
+  auto put = [&](const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    buf.insert(buf.end(), b, b + n);
+  };
+  auto put_i32 = [&](int32_t v) { put(&v, 4); };
+  auto put_i64 = [&](int64_t v) { put(&v, 8); };
+  auto put_str = [&](const char* s) {
+    put_i32((int32_t)std::strlen(s));
+    put(s, std::strlen(s));
+  };
+  int64_t num_trs = 0;
+  for (const State& st : f.states) num_trs += (int64_t)st.trs.size();
+  put_i32(2125659606);
+  put_str("vector");
+  put_str("standard");
+  put_i32(2);
+  uint32_t flags = 0;
+  put(&flags, 4);
+  uint64_t props = f.properties | P::STATIC_EXPANDED_MUTABLE;
+  put(&props, 8);
+  put_i64(f.has_start ? (int64_t)f.start : -1);
+  put_i64((int64_t)f.states.size());
+  put_i64(num_trs);
+  for (const State& st : f.states) {
+    float fw = st.has_final ? st.final_w : INF;
+    put(&fw, 4);
+    put_i64((int64_t)st.trs.size());
+    for (const Tr& tr : st.trs) {
+      put_i32((int32_t)tr.ilabel);
+      put_i32((int32_t)tr.olabel);
+      put(&tr.weight, 4);
+      put_i32((int32_t)tr.nextstate);
+    }
+  }
+  if (out && cap >= buf.size()) std::memcpy(out, buf.data(), buf.size());
+  return buf.size();
+}
+
+// ---------------------------------------------------------------- helpers for invariants
+float brute_rec(const Fst& f, uint32_t s, float acc, uint32_t depth, uint32_t max_len) {
+  float best = INF;
+  const State& st = f.states[s];
+  if (st.has_final) best = wplus(best, wtimes(acc, st.final_w));
+  if (depth == max_len) return best;
+  for (const Tr& tr : st.trs) best = wplus(best, brute_rec(f, tr.nextstate, wtimes(acc, tr.weight), depth + 1, max_len));
+  return best;
+}
+
+bool path_rec(const Fst& f, uint32_t s, const std::vector<Tr>& labels, size_t i, float acc, float target_final,
+              float* w_out) {
+  if (i == labels.size()) {
+    const State& st = f.states[s];
+    if (!st.has_final) return false;
+    (void)target_final;
+    *w_out = wtimes(acc, st.final_w);
+    return true;
+  }
+  for (const Tr& tr : f.states[s].trs) {
+    if (tr.ilabel == labels[i].ilabel && tr.olabel == labels[i].olabel && std::fabs(tr.weight - labels[i].weight) <= KDELTA) {
+      if (path_rec(f, tr.nextstate, labels, i + 1, wtimes(acc, tr.weight), target_final, w_out)) return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+// ================================================================ C API
+extern "C" {
+
+const char* oracle_last_error(void) { return t_err.c_str(); }
+const char* oracle_last_queue_kind(void) { return t_queue_kind; }
+
+oracle_fst* oracle_fst_new(void) { return new oracle_fst(); }
+void oracle_fst_free(oracle_fst* f) { delete f; }
+uint32_t oracle_fst_add_state(oracle_fst* f) { return f->add_state(); }
+int oracle_fst_set_start(oracle_fst* f, uint32_t s) { return f->set_start(s) ? 0 : 1; }
+int oracle_fst_set_final(oracle_fst* f, uint32_t s, float w) { return f->set_final(s, w) ? 0 : 1; }
+int oracle_fst_add_tr(oracle_fst* f, uint32_t s, uint32_t il, uint32_t ol, float w, uint32_t ns) {
+  return f->add_tr(s, Tr{il, ol, w, ns}) ? 0 : 1;
+}
+
+// tr_sort — algorithms/tr_sort.rs:50-62 (stable sort_by; sets the sorted bit, keeps arcsort-invariant bits)
+void oracle_fst_tr_sort(oracle_fst* f, int by_olabel) {
+  for (auto& st : f->states) {
+    if (by_olabel)
+      std::stable_sort(st.trs.begin(), st.trs.end(), [](const Tr& a, const Tr& b) { return a.olabel < b.olabel; });
+    else
+      std::stable_sort(st.trs.begin(), st.trs.end(), [](const Tr& a, const Tr& b) { return a.ilabel < b.ilabel; });
+  }
+  // tr_sort.rs: props & arcsort_properties() | (I|O)_LABEL_SORTED
+  const uint64_t arcsort_mask = P::ALL & ~(P::I_LABEL_SORTED | P::NOT_I_LABEL_SORTED | P::O_LABEL_SORTED |
+                                           P::NOT_O_LABEL_SORTED);
+  const bool acceptor = (f->properties & P::ACCEPTOR) != 0;
+  f->properties &= arcsort_mask;
+  f->properties |= by_olabel ? P::O_LABEL_SORTED : P::I_LABEL_SORTED;
+  if (acceptor) f->properties |= by_olabel ? P::I_LABEL_SORTED : P::O_LABEL_SORTED;  // tr_sort.rs:21-27,38-44
+}
+
+oracle_fst* oracle_fst_from_flat(uint32_t n_states, int64_t start, const uint32_t* offsets, const oracle_tr* arcs,
+                                 const float* finals, uint64_t props) {
+  auto* f = new oracle_fst();
+  f->states.resize(n_states);
+  for (uint32_t s = 0; s < n_states; ++s) {
+    State& st = f->states[s];
+    st.trs.assign(arcs + offsets[s], arcs + offsets[s + 1]);
+    for (const Tr& tr : st.trs) {
+      if (tr.ilabel == EPS_LABEL) st.niepsilons++;
+      if (tr.olabel == EPS_LABEL) st.noepsilons++;
+    }
+    if (finals[s] != INF) {
+      st.has_final = true;
+      st.final_w = finals[s];
+    }
+  }
+  f->has_start = start >= 0;
+  f->start = start >= 0 ? (uint32_t)start : 0u;
+  f->properties = props & P::ALL;
+  return f;
+}
+
+void oracle_fst_info(const oracle_fst* f, uint32_t* n_states, uint64_t* n_arcs, int64_t* start, uint64_t* props) {
+  if (n_states) *n_states = (uint32_t)f->states.size();
+  if (n_arcs) {
+    uint64_t n = 0;
+    for (const State& st : f->states) n += st.trs.size();
+    *n_arcs = n;
+  }
+  if (start) *start = f->has_start ? (int64_t)f->start : -1;
+  if (props) *props = f->properties;
+}
+
+void oracle_fst_to_flat(const oracle_fst* f, uint32_t* offsets, oracle_tr* arcs, float* finals) {
+  uint32_t off = 0;
+  for (size_t s = 0; s < f->states.size(); ++s) {
+    const State& st = f->states[s];
+    offsets[s] = off;
+    if (!st.trs.empty()) std::memcpy(arcs + off, st.trs.data(), st.trs.size() * sizeof(Tr));
+    off += (uint32_t)st.trs.size();
+    finals[s] = st.has_final ? st.final_w : INF;
+  }
+  offsets[f->states.size()] = off;
+}
+
+void oracle_fst_eps_counts(const oracle_fst* f, uint32_t* nieps, uint32_t* noeps) {
+  for (size_t s = 0; s < f->states.size(); ++s) {
+    nieps[s] = (uint32_t)f->states[s].niepsilons;
+    noeps[s] = (uint32_t)f->states[s].noepsilons;
+  }
+}
+
+oracle_fst* oracle_fst_load(const uint8_t* data, size_t len) { return load_vector_fst(data, len); }
+size_t oracle_fst_store(const oracle_fst* f, uint8_t* out, size_t cap) { return store_vector_fst(*f, out, cap); }
+
+int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode, oracle_fst** out) {
+  DeltaGuard g(eq_mode);
+  auto res = std::make_unique<oracle_fst>();
+  if (!compose_impl(*f1, *f2, connect != 0, *res, nullptr)) return 1;
+  *out = res.release();
+  return 0;
+}
+
+int oracle_connect(oracle_fst* f) {
+  connect_impl(*f);
+  return 0;
+}
+
+int oracle_shortest_path(const oracle_fst* f, int eq_mode, oracle_fst** out, float* distance, float* total_weight) {
+  DeltaGuard g(eq_mode);
+  std::vector<float> dist;
+  std::vector<Parent> parent;
+  bool has_fp = false;
+  uint32_t fp = 0;
+  t_queue_kind = "none";
+  single_shortest_path(*f, dist, has_fp, fp, parent);
+  auto res = std::make_unique<oracle_fst>();
+  if (!backtrace(*f, has_fp, fp, parent, *res)) return 1;
+  if (distance)
+    for (size_t i = 0; i < f->states.size(); ++i) distance[i] = i < dist.size() ? dist[i] : INF;
+  if (total_weight) *total_weight = has_fp ? wtimes(dist[fp], f->states[fp].final_w) : INF;
+  *out = res.release();
+  return 0;
+}
+
+int oracle_shortest_path_canonical(const oracle_fst* f, oracle_fst** out, float* distance, uint32_t* hops,
+                                   float* total_weight, uint32_t* n_tied_choices) {
+  Canon c;
+  canonical_sssp(*f, c);
+  auto res = std::make_unique<oracle_fst>();
+  {
+    DeltaGuard g(ORACLE_EQ_REF_KDELTA);  // property bits of the output follow the reference's is_one/is_zero
+    if (!backtrace(*f, c.has_final, c.f_parent, c.parent, *res)) return 1;
+  }
+  if (distance) std::copy(c.d.begin(), c.d.end(), distance);
+  if (hops) std::copy(c.h.begin(), c.h.end(), hops);
+  if (total_weight) *total_weight = c.has_final ? c.total : INF;
+  if (n_tied_choices) *n_tied_choices = canonical_count_ties(*f, c);
+  *out = res.release();
+  return 0;
+}
+
+float oracle_bruteforce_min_weight(const oracle_fst* f, uint32_t max_len) {
+  if (!f->has_start) return INF;
+  DeltaGuard g(ORACLE_EQ_EXACT);
+  return brute_rec(*f, f->start, 0.0f, 0, max_len);
+}
+
+int oracle_path_in_fst(const oracle_fst* path, const oracle_fst* f, float* weight_in_f) {
+  if (!path->has_start || !f->has_start) return 0;
+  std::vector<Tr> labels;
+  uint32_t s = path->start;
+  for (size_t guard = 0; guard <= path->states.size(); ++guard) {
+    const State& st = path->states[s];
+    if (st.trs.empty()) break;
+    if (st.trs.size() != 1) return 0;
+    labels.push_back(st.trs[0]);
+    s = st.trs[0].nextstate;
+  }
+  if (!path->states[s].has_final) return 0;
+  float w = INF;
+  bool ok = path_rec(*f, f->start, labels, 0, 0.0f, path->states[s].final_w, &w);
+  if (ok && weight_in_f) *weight_in_f = w;
+  return ok ? 1 : 0;
+}
+
+int oracle_compose_shortest_path_batch(const oracle_fst* const* accs, size_t n, const oracle_fst* t, int n_threads,
+                                       int eq_mode, oracle_fst** outs, uint64_t* composed_arcs_pre_trim,
+                                       double* seconds) {
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  std::vector<uint64_t> arcs_per_thread((size_t)n_threads, 0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto worker = [&](int tid) {
+    DeltaGuard g(eq_mode);
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      oracle_fst composed;
+      uint64_t na = 0;
+      if (!compose_impl(*accs[i], *t, true, composed, &na)) {
+        failed = 1;
+        continue;
+      }
+      arcs_per_thread[(size_t)tid] += na;
+      std::vector<float> dist;
+      std::vector<Parent> parent;
+      bool has_fp = false;
+      uint32_t fp = 0;
+      single_shortest_path(composed, dist, has_fp, fp, parent);
+      auto res = std::make_unique<oracle_fst>();
+      if (!backtrace(composed, has_fp, fp, parent, *res)) {
+        failed = 1;
+        continue;
+      }
+      if (outs)
+        outs[i] = res.release();
+    }
+  };
+  if (n_threads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_threads; ++k) th.emplace_back(worker, k);
+    for (auto& x : th) x.join();
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (composed_arcs_pre_trim) {
+    uint64_t tot = 0;
+    for (uint64_t a : arcs_per_thread) tot += a;
+    *composed_arcs_pre_trim = tot;
+  }
+  return failed.load();
+}
+
+}  // extern "C"

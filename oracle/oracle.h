@@ -1,0 +1,105 @@
+/*
+ * oracle.h — C interface of the CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * The oracle is a single-threaded C++17 restatement of rustfst 1.3.1's
+ * algorithms::compose and algorithms::shortest_path for VectorFst<TropicalWeight>.
+ * It exists only so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check / time the reference algorithm on this box.
+ * Nothing under rustfst_amd/ may include, link or dlopen it.
+ *
+ * PARITY PIN STATUS: pinned on the reference's in-repo known-answer tests
+ * K1 (rustfst-python/tests/algorithms/test_compose.py:13-81), K2
+ * (rustfst-python/tests/algorithms/test_shortest_path.py:5-51), K3 (doctest
+ * compose/compose_static.rs:282-289) and the K4 loader fixtures
+ * (rustfst-tests-data/sigma-matcher-2/{left,right}.fst).  The reference's large
+ * OpenFST-generated goldens cannot be produced here (no rustc/cargo, no OpenFST,
+ * no network), so parity AT SCALE is unpinned and rests on line-faithfulness
+ * plus invariants (see tests/test_oracle.py).
+ */
+#ifndef WFST_ORACLE_H
+#define WFST_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  uint32_t ilabel, olabel;
+  float weight;
+  uint32_t nextstate;
+} oracle_tr; /* == rustfst-ffi CTr (rustfst-ffi/src/tr.rs:8-21), == on-disk arc */
+
+typedef struct oracle_fst oracle_fst; /* opaque VectorFst<TropicalWeight> */
+
+/* equality mode of TropicalWeight `==` (semirings/semiring.rs:159-168) */
+enum { ORACLE_EQ_REF_KDELTA = 0, ORACLE_EQ_EXACT = 1 };
+
+/* status: 0 = OK, 1 = KO (message via oracle_last_error) */
+const char* oracle_last_error(void);
+
+/* ---- VectorFst surface (fst_impls/vector_fst/mutable_fst.rs) ---- */
+oracle_fst* oracle_fst_new(void);
+void oracle_fst_free(oracle_fst*);
+uint32_t oracle_fst_add_state(oracle_fst*);
+int oracle_fst_set_start(oracle_fst*, uint32_t s);
+int oracle_fst_set_final(oracle_fst*, uint32_t s, float w);
+int oracle_fst_add_tr(oracle_fst*, uint32_t s, uint32_t il, uint32_t ol, float w, uint32_t ns);
+/* stable per-state sort by ilabel (olabel=0) or olabel (olabel=1): algorithms/tr_sort.rs:50-62 */
+void oracle_fst_tr_sort(oracle_fst*, int by_olabel);
+
+/* flat CSR interchange (same arrays the product C-ABI takes) */
+oracle_fst* oracle_fst_from_flat(uint32_t n_states, int64_t start, const uint32_t* offsets,
+                                 const oracle_tr* arcs, const float* finals, uint64_t props);
+void oracle_fst_info(const oracle_fst*, uint32_t* n_states, uint64_t* n_arcs, int64_t* start,
+                     uint64_t* props);
+void oracle_fst_to_flat(const oracle_fst*, uint32_t* offsets, oracle_tr* arcs, float* finals);
+/* per-state epsilon counters kept by VectorFstState (data_structure.rs:28-34) */
+void oracle_fst_eps_counts(const oracle_fst*, uint32_t* nieps, uint32_t* noeps);
+
+/* OpenFST binary vector/standard (parsers/bin_fst, vector_fst/serializable_fst.rs) */
+oracle_fst* oracle_fst_load(const uint8_t* data, size_t len);
+size_t oracle_fst_store(const oracle_fst*, uint8_t* out, size_t cap); /* returns needed size */
+
+/* ---- algorithms ---- */
+/* compose_with_config(AutoFilter|SequenceFilter, connect): compose_static.rs:166-266 */
+int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode,
+                   oracle_fst** out);
+/* connect(): connect.rs:51-66 */
+int oracle_connect(oracle_fst*);
+/* shortest_path_with_config(nshortest=1): shortest_path.rs:107-133,173-282.
+ * Optional outputs (may be NULL): distance[n_states], total weight of the chosen path. */
+int oracle_shortest_path(const oracle_fst* f, int eq_mode, oracle_fst** out, float* distance,
+                         float* total_weight);
+/* name of the queue discipline AutoQueue picked for the last oracle_shortest_path call on
+ * this thread (queues/auto_queue.rs:23-99): "state_order","top_order","lifo","top_order_scc","scc" */
+const char* oracle_last_queue_kind(void);
+
+/* CANONICAL single shortest path: the deterministic tie rule the GPU engine implements
+ * (DESIGN.md §Shortest path): (d,h)[t] = lexicographic min over paths of (left-fold f32 sum,
+ * #arcs); final = min id among argmin d[s]+rho(s); parent[t] = min (s,pos) among arcs with
+ * (d[s]+w, h[s]+1) == (d[t],h[t]).  Output numbered like shortest_path.rs:241-282.
+ * n_tied_choices (may be NULL) = number of path positions where >1 candidate tied (0 => the
+ * optimum found is the unique optimum along this path and must equal oracle_shortest_path). */
+int oracle_shortest_path_canonical(const oracle_fst* f, oracle_fst** out, float* distance,
+                                   uint32_t* hops, float* total_weight, uint32_t* n_tied_choices);
+
+/* brute-force minimum path weight by exhaustive DFS up to max_len arcs (tiny FSTs only) */
+float oracle_bruteforce_min_weight(const oracle_fst* f, uint32_t max_len);
+/* is `path` (a linear FST as produced by shortest_path) a successful path of f? 1/0 */
+int oracle_path_in_fst(const oracle_fst* path, const oracle_fst* f, float* weight_in_f);
+
+/* batch: for each acceptor i: compose(a[i], t) -> shortest_path. n_threads >= 1 host threads,
+ * one problem per thread at a time.  outs[i] receives the path FST (caller frees). Returns
+ * wall seconds of the algorithm part in *seconds (may be NULL). */
+int oracle_compose_shortest_path_batch(const oracle_fst* const* accs, size_t n,
+                                       const oracle_fst* t, int n_threads, int eq_mode,
+                                       oracle_fst** outs, uint64_t* composed_arcs_pre_trim,
+                                       double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
