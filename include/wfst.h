@@ -1,0 +1,195 @@
+/*
+ * wfst.h — C-ABI of the MI355X-native WFST compose + shortest-path engine (libwfst_amd.so).
+ *
+ * Drop-in boundary for rustfst's `algorithms::compose` and `algorithms::shortest_path` on
+ * VectorFst<TropicalWeight>.  Conventions are the ones rustfst-ffi already uses, so a Rust shim
+ *  can bind these with `extern "C"` exactly as it binds its own cdylib:
+ *   - every call returns a status (0 = OK, 1 = KO)            rustfst-ffi/src/lib.rs:29-37
+ *   - the error text is thread-local, fetched + freed by the caller
+ *                                                               rustfst-ffi/src/lib.rs:39-85
+ *   - objects are opaque heap handles written into an out-param and released by an explicit
+ *     destroy; inputs are borrowed, outputs are owned by the caller
+ *                                                               rustfst-ffi/src/algorithms/compose.rs:274-334
+ *   - labels / state ids are `unsigned int`, an arc is CTr      rustfst-ffi/src/lib.rs:19-27, src/tr.rs:8-21
+ * Plain pointers and sizes only; no torch / HIP types in any signature (a HIP stream crosses
+ * as `void*`).
+ *
+ * Semantics are the reference's (file:line cited per entry point).  Two documented deviations,
+ * both inside behaviour the reference itself leaves undefined or approximate:
+ *   1. TropicalWeight `==` is exact here; the reference's is |a-b| <= 1/1024
+ *      (rustfst/src/semirings/semiring.rs:159-168).  Identical results whenever weights lie on a
+ *      grid coarser than 1/1024 (all fixtures / benchmarks); otherwise this engine returns the true
+ *      (min,+) optimum.
+ *   2. Among equal-weight shortest paths the winner is the canonical one (fewest arcs, then smallest
+ *      (state,arc position) predecessor); the reference picks "first relaxer in queue order" and its
+ *      own tests refuse to compare such outputs structurally
+ *      (rustfst/src/tests_openfst/algorithms/shortest_path.rs:69-92).
+ */
+#ifndef WFST_AMD_H
+#define WFST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFST_ABI_VERSION 1
+
+typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
+
+/* == rustfst-ffi CTr (src/tr.rs:8-21) == the 16-byte on-disk arc (parsers/bin_fst/utils_parsing.rs:28-44) */
+typedef struct {
+  uint32_t ilabel;
+  uint32_t olabel;
+  float weight; /* TropicalWeight: +inf = zero, 0.0 = one */
+  uint32_t nextstate;
+} wfst_tr;
+
+#define WFST_EPS_LABEL 0u             /* rustfst/src/lib.rs:236 */
+#define WFST_NO_LABEL 0xFFFFFFFFu     /* rustfst/src/lib.rs:292 */
+#define WFST_NO_STATE_ID 0xFFFFFFFFu  /* rustfst/src/lib.rs:298 */
+
+typedef struct wfst_ctx wfst_ctx; /* one per (host thread, GPU); owns a HIP stream + device pools */
+typedef struct wfst_fst wfst_fst; /* an FST resident in HBM as CSR (and/or on the host for small results) */
+
+/* ---- errors: rustfst_ffi_get_last_error / rustfst_destroy_string (rustfst-ffi/src/lib.rs:58-85) ---- */
+wfst_status wfst_last_error(char** msg); /* takes the message (thread-local); caller frees */
+wfst_status wfst_string_destroy(char* msg);
+uint32_t wfst_abi_version(void);
+
+/* ---- context ---- */
+wfst_status wfst_ctx_create(int device, wfst_ctx** out);
+/* use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); not owned */
+wfst_status wfst_ctx_create_on_stream(int device, void* hip_stream, wfst_ctx** out);
+wfst_status wfst_ctx_destroy(wfst_ctx* ctx);
+wfst_status wfst_ctx_synchronize(wfst_ctx* ctx);
+wfst_status wfst_ctx_stream(wfst_ctx* ctx, void** hip_stream);
+
+/* ---- FST handles.  What the Rust shim produces by walking the trait surface
+ * (start / num_states / get_trs / final_weight / properties: rustfst/src/fst_traits/fst.rs:18-226):
+ *   offsets[n_states+1], arcs[offsets[n]] in per-state stored order, finals[n] with +inf = None
+ *   (same sentinel as on disk, vector_fst/serializable_fst.rs:78-80), props = FstProperties bits
+ *   (rustfst/src/fst_properties/properties.rs:22-103), start = -1 for None. ---- */
+wfst_status wfst_fst_upload(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets,
+                            const wfst_tr* arcs, const float* finals, uint64_t props, wfst_fst** out);
+/* same, but the three arrays already live in HBM on ctx's device (e.g. torch tensors); copied */
+wfst_status wfst_fst_upload_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* d_offsets,
+                                   const wfst_tr* d_arcs, const float* d_finals, uint64_t props, wfst_fst** out);
+/* n FSTs in one shot (one device arena, one copy): arrays are concatenated; state_base[i] /
+ * arc_base[i] give FST i's first state / arc; offsets are per-FST relative (each has n_i+1 entries,
+ * concatenated: FST i's offsets start at state_base[i] + i). */
+wfst_status wfst_fst_upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts,
+                                 const uint32_t* offsets_cat, const wfst_tr* arcs_cat, const float* finals_cat,
+                                 const uint64_t* props, wfst_fst** outs);
+/* OpenFST binary "vector"/"standard": vec_fst_from_bytes / vec_fst_to_bytes
+ * (rustfst-ffi/src/fst/vector_fst.rs:319-354; format rustfst/src/parsers/bin_fst/fst_header.rs:71-112,
+ * rustfst/src/fst_impls/vector_fst/serializable_fst.rs:45-168). Symbol tables are skipped. */
+wfst_status wfst_fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len, wfst_fst** out);
+wfst_status wfst_fst_to_openfst_bytes(const wfst_fst* fst, uint8_t** data, size_t* len);
+wfst_status wfst_bytes_destroy(uint8_t* data);
+
+wfst_status wfst_fst_info(const wfst_fst* fst, uint32_t* n_states, uint64_t* n_arcs, int64_t* start,
+                          uint64_t* props);
+/* copy out: offsets[n_states+1], arcs[n_arcs], finals[n_states] (any pointer may be NULL) */
+wfst_status wfst_fst_download(const wfst_fst* fst, uint32_t* offsets, wfst_tr* arcs, float* finals);
+wfst_status wfst_fst_destroy(wfst_fst* fst);
+
+/* ---- compose: fst_compose / fst_compose_with_config (rustfst-ffi/src/algorithms/compose.rs:308-372)
+ *      = rustfst::algorithms::compose::{compose, compose_with_config}
+ *        (rustfst/src/algorithms/compose/compose_static.rs:166-306).
+ * compose_filter uses the ffi numbering (compose.rs:20-33): 0 Auto, 1 Null, 2 Trivial, 3 Sequence,
+ * 4 AltSequence, 5 Match, 6 NoMatch.  Auto and Sequence (SortedMatcher x2) run on the GPU; the others
+ * return KO "unsupported" so the shim can fall back to the Rust path.  cfg == NULL means
+ * ComposeConfig::default() = {Auto, connect = true} (compose_static.rs:56-65).
+ * KO with the reference's message when neither side is known label-sorted
+ * (compose/compose_fst_op.rs:169-197).  Output state ids / arc order are the reference's
+ * (FIFO BFS discovery order, then stable trim: lazy/lazy_fst.rs:226-269, connect.rs:51-66). ---- */
+typedef struct {
+  uint32_t compose_filter;
+  uint32_t connect; /* bool */
+} wfst_compose_config;
+wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fst2,
+                         const wfst_compose_config* cfg, wfst_fst** out);
+
+/* ---- shortest path: fst_shortest_path / fst_shortest_path_with_config
+ *      (rustfst-ffi/src/algorithms/shortest_path.rs:44-83) = rustfst::algorithms::shortest_path
+ *      (rustfst/src/algorithms/shortest_path.rs:76-133).  cfg == NULL means
+ *      ShortestPathConfig::default() = {delta 1e-6, nshortest 1, unique false} (:31-39).
+ *      nshortest == 0 -> empty FST (:118-120); nshortest == 1 on the GPU; nshortest > 1 or unique
+ *      -> KO "unsupported".  Output: linear FST numbered backwards, state 0 final (:241-282). ---- */
+typedef struct {
+  float delta;
+  uint64_t nshortest;
+  uint32_t unique; /* bool */
+} wfst_shortest_path_config;
+wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_shortest_path_config* cfg,
+                               wfst_fst** out);
+/* single-source (min,+) distances from the start state (what single_shortest_path computes into
+ * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
+wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
+
+/* ---- fused batch: for each acceptor i: shortest_path(compose(acceptors[i], t)) — the loop a
+ * caller writes around the two reference entry points; here one device-resident pipeline.
+ * outs[i] are small host-resident FSTs. composed_arcs (may be NULL) receives the total number of
+ * arcs emitted by the n compositions before trimming. ---- */
+wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
+                                             const wfst_fst* t, const wfst_compose_config* ccfg,
+                                             const wfst_shortest_path_config* scfg, wfst_fst** outs,
+                                             uint64_t* composed_arcs);
+
+/* ---- host-side mutable VectorFst<TropicalWeight> mirror.  What rustfst-ffi exposes as vec_fst_* /
+ * fst_* (rustfst-ffi/src/fst/vector_fst.rs:13-354, src/fst/mod.rs:128-216, src/algorithms/tr_sort.rs:15)
+ * for callers that have no Rust VectorFst of their own (the Python mirror, C/C++ programs).  Semantics
+ * incl. the property bookkeeping follow rustfst/src/fst_impls/vector_fst/mutable_fst.rs:25-281 and
+ * rustfst/src/fst_properties/mutate_properties.rs.  A Rust shim does NOT need these: it flattens its own
+ * VectorFst through the trait surface and calls wfst_fst_upload. ---- */
+typedef struct wfst_vec_fst wfst_vec_fst;
+wfst_status wfst_vec_fst_new(wfst_vec_fst** out);                                   /* vec_fst_new :13 */
+wfst_status wfst_vec_fst_destroy(wfst_vec_fst* f);                                  /* fst_destroy mod.rs:376 */
+wfst_status wfst_vec_fst_copy(const wfst_vec_fst* f, wfst_vec_fst** out);           /* vec_fst_copy :285 */
+wfst_status wfst_vec_fst_add_state(wfst_vec_fst* f, uint32_t* state);               /* vec_fst_add_state :56 */
+wfst_status wfst_vec_fst_add_tr(wfst_vec_fst* f, uint32_t state, const wfst_tr* tr); /* vec_fst_add_tr :83 */
+wfst_status wfst_vec_fst_set_start(wfst_vec_fst* f, uint32_t state);                /* vec_fst_set_start :26 */
+wfst_status wfst_vec_fst_set_final(wfst_vec_fst* f, uint32_t state, float weight);  /* vec_fst_set_final :39 */
+wfst_status wfst_vec_fst_del_final_weight(wfst_vec_fst* f, uint32_t state);         /* vec_fst_del_final_weight :101 */
+wfst_status wfst_vec_fst_num_states(const wfst_vec_fst* f, uint32_t* n);            /* vec_fst_num_states :248 */
+wfst_status wfst_vec_fst_start(const wfst_vec_fst* f, int64_t* start);              /* fst_start mod.rs:128; -1 = None */
+/* fst_final_weight mod.rs:143: *is_some = 0 for None */
+wfst_status wfst_vec_fst_final_weight(const wfst_vec_fst* f, uint32_t state, float* weight, int* is_some);
+wfst_status wfst_vec_fst_num_trs(const wfst_vec_fst* f, uint32_t state, uint64_t* n); /* fst_num_trs mod.rs:162 */
+/* fst_get_trs mod.rs:179: copies the state's arcs into out[cap]; *n receives the count */
+wfst_status wfst_vec_fst_get_trs(const wfst_vec_fst* f, uint32_t state, wfst_tr* out, uint64_t cap, uint64_t* n);
+wfst_status wfst_vec_fst_properties(const wfst_vec_fst* f, uint64_t* props);
+wfst_status wfst_vec_fst_tr_sort(wfst_vec_fst* f, int ilabel_cmp);                  /* fst_tr_sort tr_sort.rs:15 */
+wfst_status wfst_vec_fst_equals(const wfst_vec_fst* a, const wfst_vec_fst* b, int* equal); /* vec_fst_equals :265 */
+/* flatten through the trait surface + upload == the shim's input step */
+wfst_status wfst_vec_fst_to_device(wfst_ctx* ctx, const wfst_vec_fst* f, wfst_fst** out);
+/* download + rebuild (add_states / set_start / set_trs_unchecked / set_final / set_properties) == the shim's output step */
+wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
+
+/* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
+typedef struct {
+  /* relaxation kernel (sssp_relax_*): launches, total device time from HIP events on ctx's stream,
+   * and the algorithmic units they processed */
+  uint64_t relax_launches;
+  double relax_ms;
+  uint64_t relax_arcs;    /* arcs relaxed (sum over launches) */
+  uint64_t relax_states;  /* frontier states expanded (sum over launches) */
+  uint64_t sweeps;        /* relaxation sweeps of the last solve */
+  /* compose */
+  uint64_t compose_states; /* composed states created (pre-trim), last call */
+  uint64_t compose_arcs;   /* composed arcs emitted (pre-trim), last call */
+  uint64_t compose_retries; /* arena-overflow retries, cumulative */
+  double compose_ms;       /* device time of the last compose / fused-batch kernel */
+} wfst_stats;
+/* profiling on: relaxation launches are bracketed by HIP events (adds sync; never on in timed runs) */
+wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on);
+wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out);
+wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFST_AMD_H */

@@ -1,0 +1,309 @@
+// api.cpp — the extern "C" surface declared in include/wfst.h (conventions: rustfst-ffi/src/lib.rs:29-97).
+#include <cstdlib>
+
+#include "common.h"
+#include "fst_props.h"
+
+namespace wfst {
+
+static thread_local std::string t_last_error;  // LAST_ERROR, rustfst-ffi/src/lib.rs:39-41
+static thread_local bool t_has_error = false;
+void set_last_error(const std::string& msg) {
+  t_last_error = msg;
+  t_has_error = true;
+  if (std::getenv("WFST_FFI_ERROR_STDERR")) std::fprintf(stderr, "%s\n", msg.c_str());  // cf. lib.rs:48-50
+}
+
+// ---------------------------------------------------------------- DevicePool
+size_t DevicePool::bucket(size_t bytes) {
+  if (bytes < 256) return 256;
+  // round up to a multiple of 1/8 of the enclosing power of two: <= 12.5 % slack, few distinct sizes
+  size_t p = 256;
+  while (p < bytes) p <<= 1;
+  size_t step = p >> 3;
+  return (bytes + step - 1) / step * step;
+}
+void* DevicePool::alloc(size_t bytes) {
+  size_t b = bucket(bytes);
+  auto it = free_.find(b);
+  if (it != free_.end()) {
+    void* p = it->second;
+    free_.erase(it);
+    live_[p] = b;
+    return p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, b);
+  if (e != hipSuccess) {
+    trim();
+    HIP_CHECK(hipMalloc(&p, b));
+  }
+  live_[p] = b;
+  return p;
+}
+void DevicePool::free(void* p) {
+  if (!p) return;
+  auto it = live_.find(p);
+  if (it == live_.end()) return;
+  free_.emplace(it->second, p);
+  live_.erase(it);
+}
+void DevicePool::trim() {
+  for (auto& kv : free_) (void)hipFree(kv.second);
+  free_.clear();
+}
+DevicePool::~DevicePool() {
+  trim();
+  for (auto& kv : live_) (void)hipFree(kv.first);
+}
+
+void* PinnedBuf::get(size_t bytes) {
+  if (bytes > cap) {
+    if (p) (void)hipHostFree(p);
+    size_t ncap = std::max<size_t>(bytes, cap * 2);
+    ncap = std::max<size_t>(ncap, 4096);
+    HIP_CHECK(hipHostMalloc(&p, ncap, hipHostMallocDefault));
+    cap = ncap;
+  }
+  return p;
+}
+PinnedBuf::~PinnedBuf() {
+  if (p) (void)hipHostFree(p);
+}
+
+}  // namespace wfst
+
+DeviceArena::~DeviceArena() {
+  if (base && ctx && ctx->pool) ctx->pool->free(base);
+}
+
+using namespace wfst;
+
+static wfst_ctx* ctx_create(int device, void* stream, bool own) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    throw Error("libwfst_amd: no HIP device available (this engine has no CPU fallback)");
+  if (device < 0 || device >= count) throw Error("libwfst_amd: device index out of range");
+  HIP_CHECK(hipSetDevice(device));
+  auto ctx = std::make_unique<wfst_ctx>();
+  ctx->device = device;
+  if (own) {
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->owns_stream = true;
+  } else {
+    ctx->stream = (hipStream_t)stream;
+  }
+  ctx->pool = std::make_unique<DevicePool>(device);
+  HIP_CHECK(hipEventCreate(&ctx->ev0));
+  HIP_CHECK(hipEventCreate(&ctx->ev1));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return ctx.release();
+}
+
+extern "C" {
+
+uint32_t wfst_abi_version(void) { return WFST_ABI_VERSION; }
+
+wfst_status wfst_last_error(char** msg) {
+  return wrap([&] {
+    if (!msg) throw Error("null out pointer");
+    std::string s = t_has_error ? t_last_error : std::string("No error message");
+    t_has_error = false;
+    char* out = (char*)std::malloc(s.size() + 1);
+    if (!out) throw Error("out of memory");
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    *msg = out;
+  });
+}
+wfst_status wfst_string_destroy(char* msg) {
+  std::free(msg);
+  return WFST_OK;
+}
+wfst_status wfst_bytes_destroy(uint8_t* data) {
+  std::free(data);
+  return WFST_OK;
+}
+
+wfst_status wfst_ctx_create(int device, wfst_ctx** out) {
+  return wrap([&] {
+    if (!out) throw Error("null out pointer");
+    *out = ctx_create(device, nullptr, true);
+  });
+}
+wfst_status wfst_ctx_create_on_stream(int device, void* hip_stream, wfst_ctx** out) {
+  return wrap([&] {
+    if (!out) throw Error("null out pointer");
+    *out = ctx_create(device, hip_stream, false);
+  });
+}
+wfst_status wfst_ctx_destroy(wfst_ctx* ctx) {
+  return wrap([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    ctx->pool.reset();
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+wfst_status wfst_ctx_synchronize(wfst_ctx* ctx) {
+  return wrap([&] {
+    if (!ctx) throw Error("null ctx");
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+wfst_status wfst_ctx_stream(wfst_ctx* ctx, void** hip_stream) {
+  return wrap([&] {
+    if (!ctx || !hip_stream) throw Error("null pointer");
+    *hip_stream = (void*)ctx->stream;
+  });
+}
+
+wfst_status wfst_fst_upload(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets,
+                            const wfst_tr* arcs, const float* finals, uint64_t props, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !out) throw Error("null pointer");
+    if (n_states && (!offsets || !finals)) throw Error("null array");
+    *out = upload_from_host(ctx, n_states, start, offsets, arcs, finals, props);
+  });
+}
+wfst_status wfst_fst_upload_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* d_offsets,
+                                   const wfst_tr* d_arcs, const float* d_finals, uint64_t props, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !out) throw Error("null pointer");
+    *out = upload_from_device(ctx, n_states, start, d_offsets, d_arcs, d_finals, props);
+  });
+}
+wfst_status wfst_fst_upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts,
+                                 const uint32_t* offsets_cat, const wfst_tr* arcs_cat, const float* finals_cat,
+                                 const uint64_t* props, wfst_fst** outs) {
+  return wrap([&] {
+    if (!ctx || !outs) throw Error("null pointer");
+    upload_many(ctx, n, n_states, starts, offsets_cat, arcs_cat, finals_cat, props, outs);
+  });
+}
+wfst_status wfst_fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !out || !data) throw Error("null pointer");
+    *out = fst_from_openfst_bytes(ctx, data, len);
+  });
+}
+wfst_status wfst_fst_to_openfst_bytes(const wfst_fst* fst, uint8_t** data, size_t* len) {
+  return wrap([&] {
+    if (!fst || !data || !len) throw Error("null pointer");
+    std::vector<uint8_t> buf;
+    fst_to_openfst_bytes(fst, buf);
+    uint8_t* p = (uint8_t*)std::malloc(buf.size() ? buf.size() : 1);
+    if (!p) throw Error("out of memory");
+    std::memcpy(p, buf.data(), buf.size());
+    *data = p;
+    *len = buf.size();
+  });
+}
+wfst_status wfst_fst_info(const wfst_fst* fst, uint32_t* n_states, uint64_t* n_arcs, int64_t* start, uint64_t* props) {
+  return wrap([&] {
+    if (!fst) throw Error("null fst");
+    if (n_states) *n_states = fst->n_states;
+    if (n_arcs) *n_arcs = fst->n_arcs;
+    if (start) *start = fst->start;
+    if (props) *props = fst->props;
+  });
+}
+wfst_status wfst_fst_download(const wfst_fst* fst, uint32_t* offsets, wfst_tr* arcs, float* finals) {
+  return wrap([&] {
+    if (!fst) throw Error("null fst");
+    ensure_host(fst);
+    const HostCsr& h = fst->host;
+    if (offsets) std::memcpy(offsets, h.offsets.data(), h.offsets.size() * sizeof(uint32_t));
+    if (arcs && !h.arcs.empty()) std::memcpy(arcs, h.arcs.data(), h.arcs.size() * sizeof(wfst_tr));
+    if (finals && !h.finals.empty()) std::memcpy(finals, h.finals.data(), h.finals.size() * sizeof(float));
+  });
+}
+wfst_status wfst_fst_destroy(wfst_fst* fst) {
+  return wrap([&] {
+    if (!fst) return;
+    if (fst->ctx) (void)hipSetDevice(fst->ctx->device);
+    delete fst;
+  });
+}
+
+wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fst2, const wfst_compose_config* cfg,
+                         wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !fst1 || !fst2 || !out) throw Error("null pointer");
+    wfst_compose_config c = cfg ? *cfg : wfst_compose_config{0, 1};  // ComposeConfig::default(), compose_static.rs:56-65
+    if (c.compose_filter != 0 && c.compose_filter != 3)
+      throw Error("unsupported: compose_filter " + std::to_string(c.compose_filter) +
+                  " is not implemented on the GPU path (Auto=0 and Sequence=3 are); use the CPU path");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = compose(ctx, fst1, fst2, c.connect != 0);
+  });
+}
+
+wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_shortest_path_config* cfg,
+                               wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !fst || !out) throw Error("null pointer");
+    wfst_shortest_path_config c = cfg ? *cfg : wfst_shortest_path_config{1e-6f, 1, 0};  // shortest_path.rs:31-39
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (c.nshortest == 0) {  // shortest_path.rs:118-120: FO::new()
+      HostCsr h;
+      h.offsets.push_back(0);
+      *out = make_host_fst(ctx, 0, -1, props::NULL_PROPS, std::move(h));
+      return;
+    }
+    // nshortest == 1 returns before `unique` is looked at (shortest_path.rs:122-133)
+    if (c.nshortest != 1)
+      throw Error("unsupported: nshortest > 1 is not implemented on the GPU path; use the CPU path");
+    *out = shortest_path_n1(ctx, fst);
+  });
+}
+
+wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops) {
+  return wrap([&] {
+    if (!ctx || !fst || !distance) throw Error("null pointer");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    shortest_distance(ctx, fst, distance, hops);
+  });
+}
+
+wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
+                                             const wfst_fst* t, const wfst_compose_config* ccfg,
+                                             const wfst_shortest_path_config* scfg, wfst_fst** outs,
+                                             uint64_t* composed_arcs) {
+  return wrap([&] {
+    if (!ctx || !t || !outs || (n && !acceptors)) throw Error("null pointer");
+    wfst_compose_config c = ccfg ? *ccfg : wfst_compose_config{0, 1};
+    wfst_shortest_path_config s = scfg ? *scfg : wfst_shortest_path_config{1e-6f, 1, 0};
+    if (c.compose_filter != 0 && c.compose_filter != 3) throw Error("unsupported: compose_filter");
+    if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    compose_shortest_path_batch(ctx, acceptors, n, t, c.connect != 0, outs, composed_arcs);
+  });
+}
+
+wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on) {
+  return wrap([&] {
+    if (!ctx) throw Error("null ctx");
+    ctx->profiling = on != 0;
+  });
+}
+wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out) {
+  return wrap([&] {
+    if (!ctx || !out) throw Error("null pointer");
+    *out = ctx->stats;
+  });
+}
+wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx) {
+  return wrap([&] {
+    if (!ctx) throw Error("null ctx");
+    ctx->stats = wfst_stats{};
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// common.h — shared host-side definitions of libwfst_amd (context, FST handle, device pool, errors).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/wfst.h"
+
+namespace wfst {
+
+constexpr float INF = __builtin_huge_valf();
+
+// ---------------------------------------------------------------- errors
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+void set_last_error(const std::string& msg);
+
+#define HIP_CHECK(expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess)                                                                                \
+      throw ::wfst::Error(std::string("HIP error ") + hipGetErrorString(_e) + " at " __FILE__ ":" +     \
+                          std::to_string(__LINE__) + " in " #expr);                                      \
+  } while (0)
+
+template <class F>
+wfst_status wrap(F&& f) noexcept {  // rustfst-ffi/src/lib.rs:43-56 `wrap`
+  try {
+    f();
+    return WFST_OK;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return WFST_KO;
+  } catch (...) {
+    set_last_error("unknown error");
+    return WFST_KO;
+  }
+}
+
+// ---------------------------------------------------------------- device memory pool
+// Size-bucketed caching allocator: hot paths never call hipMalloc/hipFree after warm-up.
+class DevicePool {
+ public:
+  explicit DevicePool(int device) { (void)device; }
+  ~DevicePool();
+  void* alloc(size_t bytes);
+  void free(void* p);
+  void trim();
+
+ private:
+  static size_t bucket(size_t bytes);
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> live_;
+};
+
+// RAII device buffer from the pool
+template <class T>
+struct DBuf {
+  DevicePool* pool = nullptr;
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(DevicePool& pl, size_t count) : pool(&pl), p((T*)pl.alloc(std::max<size_t>(count, 1) * sizeof(T))), n(count) {}
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : pool(o.pool), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    reset();
+    pool = o.pool;
+    p = o.p;
+    n = o.n;
+    o.p = nullptr;
+    return *this;
+  }
+  void reset() {
+    if (p) pool->free(p);
+    p = nullptr;
+  }
+  ~DBuf() { reset(); }
+};
+
+// pinned host staging buffer (grow-only)
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void* get(size_t bytes);
+  ~PinnedBuf();
+};
+
+}  // namespace wfst
+
+// ---------------------------------------------------------------- handles
+struct wfst_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  std::unique_ptr<wfst::DevicePool> pool;
+  wfst::PinnedBuf pinned;      // small D2H/H2D staging
+  wfst::PinnedBuf pinned_big;  // batch descriptors / results
+  bool profiling = false;
+  wfst_stats stats{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_cus = 256;
+};
+
+// Device-resident CSR. All arrays live in one arena allocation that may be
+// shared between several FSTs (wfst_fst_upload_many).
+struct DeviceArena {
+  wfst_ctx* ctx = nullptr;
+  void* base = nullptr;
+  size_t bytes = 0;
+  ~DeviceArena();
+};
+
+struct DeviceCsr {
+  std::shared_ptr<DeviceArena> arena;
+  const uint32_t* offsets = nullptr;  // [n+1]
+  const wfst_tr* arcs = nullptr;      // [E] AoS 16 B == CTr == on-disk arc
+  const float* finals = nullptr;      // [n], +inf = non-final
+  const uint32_t* noeps = nullptr;    // [n] number of output-epsilon arcs (VectorFstState.noepsilons)
+  const uint2* wn = nullptr;          // [E] packed {weight bits, nextstate}: the 8 B the relaxation needs
+};
+
+struct HostCsr {
+  std::vector<uint32_t> offsets;
+  std::vector<wfst_tr> arcs;
+  std::vector<float> finals;
+};
+
+struct wfst_fst {
+  wfst_ctx* ctx = nullptr;
+  uint32_t n_states = 0;
+  uint64_t n_arcs = 0;
+  int64_t start = -1;
+  uint64_t props = 0;
+  bool has_host = false, has_dev = false;
+  HostCsr host;
+  DeviceCsr dev;
+};
+
+namespace wfst {
+// fst_store.hip
+void ensure_device(wfst_fst* f);             // upload host copy if needed (mutates cache only)
+void ensure_host(const wfst_fst* f);         // download if needed
+wfst_fst* make_host_fst(wfst_ctx* ctx, uint32_t n_states, int64_t start, uint64_t props, HostCsr&& csr);
+wfst_fst* upload_from_host(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets,
+                           const wfst_tr* arcs, const float* finals, uint64_t props);
+wfst_fst* upload_from_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* d_offsets,
+                             const wfst_tr* d_arcs, const float* d_finals, uint64_t props);
+void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts, const uint32_t* offsets_cat,
+                 const wfst_tr* arcs_cat, const float* finals_cat, const uint64_t* props, wfst_fst** outs);
+// adopt freshly produced device arrays (compose output) as a new FST; arrays are copied into one arena
+wfst_fst* adopt_device(wfst_ctx* ctx, uint32_t n_states, uint64_t n_arcs, int64_t start, uint64_t props,
+                       const uint32_t* d_offsets, const wfst_tr* d_arcs, const float* d_finals);
+// openfst_io.cpp
+wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len);
+void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
+// sssp.hip
+wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
+void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
+// compose.hip
+wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect);
+void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,
+                                 wfst_fst** outs, uint64_t* composed_arcs);
+}  // namespace wfst

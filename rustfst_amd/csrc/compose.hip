@@ -1,0 +1,950 @@
+// compose.hip — composition (+ trim, + fused n=1 shortest path) of HBM-resident CSR FSTs.
+//
+// Replaces, for SortedMatcher x2 + SequenceComposeFilter (the AutoFilter default):
+//   compose / compose_with_config      rustfst/src/algorithms/compose/compose_static.rs:166-306
+//   ComposeFstOp::{compute_start,compute_trs,compute_final_weight,match_input,ordered_expand,
+//                  match_tr,match_tr_selected,add_tr}   compose/compose_fst_op.rs:199-449
+//   SortedMatcher / IteratorSortedMatcher / eps_loop   compose/matchers/sorted_matcher.rs:44-184, matchers/mod.rs:98-105
+//   SequenceComposeFilter::{set_state,filter_tr}       compose/compose_filters/sequence_compose_filter.rs:134-171
+//   StateTable::find_id                                 lazy/state_table.rs:49-59,102-119
+//   LazyFst::compute (FIFO BFS = the state numbering)   lazy/lazy_fst.rs:226-269
+//   connect + del_states                                connect.rs:51-66, vector_fst/mutable_fst.rs:132-189
+//
+// Execution model ("one wavefront = one composition problem"): the reference is a sequential BFS whose
+// state ids are first-touch order.  A 64-lane wave walks that BFS level by level for ONE (fst1,fst2)
+// pair; a launch runs one wave per problem, so a batch of acceptors against a shared transducer fills
+// the chip with independent waves (8 XCDs x 32 CUs x up to 32 waves) and needs no inter-workgroup
+// synchronisation at all.  Inside a level the 64 lanes share the work of one composed state:
+//   - the searched side's arc block (<= 64 arcs) is read with ONE coalesced 16-B-per-lane load and kept
+//     in registers; label matching is a wave ballot, matched arcs are fetched with lane shuffles
+//     (no second trip to HBM); larger blocks fall back to a per-lane binary search;
+//   - emitted arcs get their slot by a wave prefix sum, destination tuples go through an
+//     open-addressing table (u64 key CAS) whose value word holds atomicMin(first emission index);
+//   - after the level, first occurrences are ranked with ballots: new ids = reference BFS ids.
+// Everything stays in HBM/L2 between phases: the fused pipeline (compose -> relax -> backtrace) never
+// returns to the host.
+#include "common.h"
+#include "fst_props.h"
+
+namespace wfst {
+
+namespace {
+
+constexpr uint32_t NO_LABEL = WFST_NO_LABEL;
+constexpr uint32_t REJECT = 0xFFFFFFFFu;  // FilterState::new_no_state()
+constexpr uint64_t HT_EMPTY = ~0ull;
+constexpr uint32_t HV_INIT = 0xFFFFFFFFu;
+constexpr uint32_t HV_PEND = 0x80000000u;
+constexpr uint64_t KEY_INF = ~0ull;
+
+enum : uint32_t { MODE_BOTH = 0, MODE_INPUT = 1, MODE_OUTPUT = 2 };  // MatchType after match_type()
+enum : uint32_t { ST_OK = 0, ST_OVERFLOW_STATES = 1, ST_OVERFLOW_ARCS = 2, ST_OVERFLOW_HASH = 3, ST_OVERFLOW_PATH = 4 };
+enum : uint32_t { FLAG_TRIM = 1, FLAG_SP = 2 };
+
+struct FstView {
+  const uint32_t* offsets;
+  const wfst_tr* arcs;
+  const float* finals;
+  const uint32_t* noeps;
+  uint32_t n_states;
+  int32_t start;  // -1 = None
+};
+
+struct ProblemDesc {
+  FstView f1;
+  uint32_t mode;
+  uint32_t pad;
+};
+
+struct Caps {
+  uint32_t S;  // composed states
+  uint32_t A;  // composed arcs
+  uint32_t H;  // hash slots (power of two)
+};
+
+struct Result {
+  uint32_t status;
+  uint32_t n_states, n_arcs;  // pre-trim
+  uint32_t t_states, t_arcs;  // after trim (== pre-trim when not trimming)
+  int32_t t_start;
+  uint32_t has_path, hops;
+  float final_weight, total;
+  uint32_t path_off;  // offset of the path arcs in the packed path buffer
+  uint32_t n_levels;
+};
+
+struct Arena {
+  uint64_t* tuples;   // [S]   packed (fs<<63 | s1<<32 | s2)
+  uint64_t* hkeys;    // [H]
+  uint64_t* skey;     // [S]   shortest-path key (enc(d)<<32 | hops)
+  uint64_t* parent;   // [S]
+  wfst_tr* arcs;      // [A]   composed arcs (pre-trim), nextstate patched level by level
+  wfst_tr* t_arcs;    // [A]   trimmed arcs
+  uint32_t* hvals;    // [H]
+  uint32_t* off;      // [S+1]
+  uint32_t* t_off;    // [S+1]
+  float* fin;         // [S]
+  float* t_fin;       // [S]
+  uint32_t* aux;      // [S]   coaccessible flag / mark
+  uint32_t* aux2;     // [S]   new id / jump pointer
+  uint32_t* lvl;      // [S+1] first id of each BFS level
+};
+
+__host__ __device__ inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t arena_bytes(const Caps& c) {
+  size_t b = 0;
+  b += al16((size_t)c.S * 8);        // tuples
+  b += al16((size_t)c.H * 8);        // hkeys
+  b += al16((size_t)c.S * 8);        // skey
+  b += al16((size_t)c.S * 8);        // parent
+  b += al16((size_t)c.A * 16);       // arcs
+  b += al16((size_t)c.A * 16);       // t_arcs
+  b += al16((size_t)c.H * 4);        // hvals
+  b += al16((size_t)(c.S + 1) * 4);  // off
+  b += al16((size_t)(c.S + 1) * 4);  // t_off
+  b += al16((size_t)c.S * 4);        // fin
+  b += al16((size_t)c.S * 4);        // t_fin
+  b += al16((size_t)c.S * 4);        // aux
+  b += al16((size_t)c.S * 4);        // aux2
+  b += al16((size_t)(c.S + 1) * 4);  // lvl
+  return (b + 255) & ~(size_t)255;
+}
+__device__ inline Arena carve_arena(char* base, const Caps& c) {
+  Arena a;
+  char* p = base;
+  a.tuples = (uint64_t*)p; p += al16((size_t)c.S * 8);
+  a.hkeys = (uint64_t*)p; p += al16((size_t)c.H * 8);
+  a.skey = (uint64_t*)p; p += al16((size_t)c.S * 8);
+  a.parent = (uint64_t*)p; p += al16((size_t)c.S * 8);
+  a.arcs = (wfst_tr*)p; p += al16((size_t)c.A * 16);
+  a.t_arcs = (wfst_tr*)p; p += al16((size_t)c.A * 16);
+  a.hvals = (uint32_t*)p; p += al16((size_t)c.H * 4);
+  a.off = (uint32_t*)p; p += al16((size_t)(c.S + 1) * 4);
+  a.t_off = (uint32_t*)p; p += al16((size_t)(c.S + 1) * 4);
+  a.fin = (float*)p; p += al16((size_t)c.S * 4);
+  a.t_fin = (float*)p; p += al16((size_t)c.S * 4);
+  a.aux = (uint32_t*)p; p += al16((size_t)c.S * 4);
+  a.aux2 = (uint32_t*)p; p += al16((size_t)c.S * 4);
+  a.lvl = (uint32_t*)p;
+  return a;
+}
+
+// ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of mask bits below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  *total = __shfl(x, 63);
+  return x - v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    unsigned long long o = __shfl_xor(v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+// The wave is a whole workgroup (blockDim == 64): __syncthreads() is the wave-level fence that makes
+// the lanes' global-memory writes visible to each other between phases.
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+template <class T>
+__device__ __forceinline__ T ld_l2(const T* p) {  // L2-served load for words other lanes update atomically
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_l2(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) {
+  uint32_t b = (e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e;
+  return __uint_as_float(b);
+}
+// TropicalWeight::times_assign (semirings/tropical_weight.rs:60-70)
+__device__ __forceinline__ float wtimes(float a, float b) { return a == INF ? a : (b == INF ? b : a + b); }
+
+__device__ __forceinline__ uint32_t hash_u64(uint64_t h) {
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return (uint32_t)h;
+}
+__device__ __forceinline__ uint64_t pack_tuple(uint32_t fs, uint32_t s1, uint32_t s2) {
+  return ((uint64_t)fs << 63) | ((uint64_t)s1 << 32) | s2;
+}
+
+// StateTable::find_id (lazy/state_table.rs:49-59) as an open-addressing table.  The value word is
+// atomicMin(first emission index of this level) while the tuple is new, then its final id.
+__device__ __forceinline__ uint32_t ht_insert(uint64_t* hkeys, uint32_t* hvals, uint32_t hmask, uint64_t key,
+                                              uint32_t pend) {
+  uint32_t slot = hash_u64(key) & hmask;
+  for (uint32_t probes = 0; probes <= hmask; ++probes) {
+    const uint64_t k = hkeys[slot];  // may be a stale EMPTY: the CAS below is the arbiter
+    if (k == key) break;
+    if (k == HT_EMPTY) {
+      const uint64_t prev = atomicCAS((unsigned long long*)&hkeys[slot], (unsigned long long)HT_EMPTY,
+                                      (unsigned long long)key);
+      if (prev == HT_EMPTY || prev == key) break;
+    }
+    slot = (slot + 1) & hmask;
+  }
+  atomicMin(&hvals[slot], pend);
+  return slot;
+}
+
+struct ArcReg {
+  uint32_t il, ol;
+  float w;
+  uint32_t ns;
+};
+__device__ __forceinline__ ArcReg load_arc(const wfst_tr* p) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);  // one 16-B load
+  return ArcReg{v.x, v.y, __uint_as_float(v.z), v.w};
+}
+__device__ __forceinline__ void store_arc(wfst_tr* p, uint32_t il, uint32_t ol, float w, uint32_t ns) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(il, ol, __float_as_uint(w), ns);
+}
+__device__ __forceinline__ ArcReg shfl_arc(const ArcReg& a, uint32_t src) {
+  return ArcReg{(uint32_t)__shfl(a.il, src), (uint32_t)__shfl(a.ol, src), __shfl(a.w, src), (uint32_t)__shfl(a.ns, src)};
+}
+
+// lower / upper bound on the searched side's key column (superslice lower_bound_by,
+// matchers/sorted_matcher.rs:141-142), per lane, for arc blocks larger than one wave.
+__device__ inline void equal_range_global(const wfst_tr* arcs, uint32_t n, bool by_ilabel, uint32_t key, uint32_t* lo_out,
+                                          uint32_t* cnt_out) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    uint32_t k = by_ilabel ? arcs[mid].ilabel : arcs[mid].olabel;
+    if (k < key) lo = mid + 1; else hi = mid;
+  }
+  uint32_t first = lo;
+  hi = n;
+  while (lo < hi) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    uint32_t k = by_ilabel ? arcs[mid].ilabel : arcs[mid].olabel;
+    if (k <= key) lo = mid + 1; else hi = mid;
+  }
+  *lo_out = first;
+  *cnt_out = lo - first;
+}
+
+struct Level {
+  uint32_t arc_begin;  // first emitted arc of the level
+  uint32_t hi;         // number of ids assigned before this level's new states
+};
+
+// ComposeFstOp::compute_trs + compute_final_weight for composed state q (compose_fst_op.rs:406-449).
+// Appends q's arcs at arcs[*n_arcs ...]; destination = hash slot (patched to the id after ranking).
+// Returns false on arena overflow (status written to *status).
+__device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode, const Arena& ar, const Caps& caps,
+                             uint32_t q, const Level& lv, uint32_t* n_arcs_io, uint32_t* status) {
+  const uint32_t lane = lane_id();
+  const uint32_t hmask = caps.H - 1;
+  const uint64_t tk = ar.tuples[q];
+  const uint32_t fs = (uint32_t)(tk >> 63);
+  const uint32_t s1 = (uint32_t)(tk >> 32) & 0x7FFFFFFFu;
+  const uint32_t s2 = (uint32_t)tk;
+  const uint32_t b1 = f1.offsets[s1], e1 = f1.offsets[s1 + 1];
+  const uint32_t b2 = f2.offsets[s2], e2 = f2.offsets[s2 + 1];
+  const uint32_t n1 = e1 - b1, n2 = e2 - b2;
+  const float fin1 = f1.finals[s1], fin2 = f2.finals[s2];
+  const uint32_t ne1 = f1.noeps[s1];
+  // compute_final_weight :420-449 (final1 (x) final2; None when either is None / the product is zero)
+  if (lane == 0) ar.fin[q] = (fin1 != INF && fin2 != INF) ? wtimes(fin1, fin2) : INF;
+  // SequenceComposeFilter::set_state :134-148
+  const bool alleps1 = (n1 == ne1) && !(fin1 != INF);
+  const bool noeps1 = ne1 == 0;
+  // match_input :199-219 (SortedMatcher::priority = num_trs)
+  const bool mi = mode == MODE_BOTH ? (n1 <= n2) : (mode == MODE_INPUT);
+  const wfst_tr* it_arcs = mi ? f1.arcs + b1 : f2.arcs + b2;
+  const wfst_tr* se_arcs = mi ? f2.arcs + b2 : f1.arcs + b1;
+  const uint32_t n_it = mi ? n1 : n2;
+  const uint32_t n_se = mi ? n2 : n1;
+  const uint32_t sa = mi ? s2 : s1;
+  const uint32_t sb = mi ? s1 : s2;
+  // filter_tr outcomes :150-171, constant per composed state:
+  //   X: the fst1-side arc has olabel NO_LABEL (fst2 moves alone)    Y: the fst2-side arc has ilabel NO_LABEL
+  const uint32_t fsX = alleps1 ? REJECT : (noeps1 ? 0u : 1u);
+  const uint32_t fsY = fs != 0 ? REJECT : 0u;
+  const uint32_t fs_nolabel = mi ? fsX : fsY;  // iterated arc labelled NO_LABEL (the loop pseudo-arc)
+  const uint32_t fs_eps = mi ? fsY : fsX;      // iterated arc labelled 0 paired with the matcher's EpsLoop
+
+  const bool small = n_se <= 64;
+  ArcReg se{0, 0, 0.0f, 0};
+  uint32_t se_key = 0xFFFFFFFEu;
+  if (small && lane < n_se) {
+    se = load_arc(se_arcs + lane);
+    se_key = mi ? se.il : se.ol;
+  }
+
+  uint32_t n_arcs = *n_arcs_io;
+  const uint32_t n_items = n_it + 1;  // item 0 = the loop pseudo-arc (ordered_expand :229-233)
+  for (uint32_t base = 0; base < n_items; base += 64) {
+    const uint32_t j = base + lane;
+    const bool have = j < n_items;
+    ArcReg ab{0, 0, 0.0f, 0};
+    if (have) {
+      if (j == 0)
+        ab = mi ? ArcReg{0u, NO_LABEL, 0.0f, sb} : ArcReg{NO_LABEL, 0u, 0.0f, sb};
+      else
+        ab = load_arc(it_arcs + (j - 1));
+    }
+    const uint32_t label = mi ? ab.ol : ab.il;                    // match_tr :333
+    const uint32_t skey = label == NO_LABEL ? 0u : label;          // IteratorSortedMatcher::new :131-135
+    uint32_t lo = 0, cnt = 0;
+    if (small) {
+      const uint32_t in_chunk = min(64u, n_items - base);
+      for (uint32_t jj = 0; jj < in_chunk; ++jj) {
+        const uint32_t k = __shfl(skey, jj);
+        const uint64_t m = __ballot(lane < n_se && se_key == k);
+        if (lane == jj) {
+          cnt = (uint32_t)__popcll(m);
+          lo = m ? (uint32_t)__ffsll((unsigned long long)m) - 1u : 0u;
+        }
+      }
+    } else if (have) {
+      equal_range_global(se_arcs, n_se, mi, skey, &lo, &cnt);
+    }
+    uint32_t fsn;  // filter state of the emitted arcs of this item
+    bool eps_item = false;
+    if (!have) {
+      cnt = 0;
+      fsn = REJECT;
+    } else if (label == NO_LABEL) {
+      fsn = fs_nolabel;  // real arcs with key 0, no EpsLoop (sorted_matcher.rs:127-139)
+    } else if (label == 0u) {
+      fsn = fs_eps;  // EpsLoop first; the real epsilon arcs that follow are all rejected (:167-168)
+      eps_item = true;
+      cnt = 1;
+    } else {
+      fsn = 0u;
+    }
+    if (fsn == REJECT) cnt = 0;
+    uint32_t total;
+    const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+    if (total == 0) continue;
+    if (n_arcs + total > caps.A) {
+      *status = ST_OVERFLOW_ARCS;
+      return false;
+    }
+    if ((uint64_t)lv.hi + (n_arcs - lv.arc_begin) + total + 64 > (uint64_t)caps.H) {
+      *status = ST_OVERFLOW_HASH;
+      return false;
+    }
+    const uint32_t maxcnt = wave_max(cnt);
+    for (uint32_t m = 0; m < maxcnt; ++m) {
+      ArcReg aa;
+      if (small) {
+        aa = shfl_arc(se, (lo + m) & 63u);
+      } else {
+        aa = ArcReg{0, 0, 0.0f, 0};
+        if (m < cnt && !eps_item) aa = load_arc(se_arcs + lo + m);
+      }
+      if (m < cnt) {
+        if (eps_item) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, sa} : ArcReg{0u, NO_LABEL, 0.0f, sa};  // eps_loop, mod.rs:98-105
+        const ArcReg& a1 = mi ? ab : aa;  // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319)
+        const ArcReg& a2 = mi ? aa : ab;
+        const uint32_t e = n_arcs + pos + m;
+        const uint64_t key = pack_tuple(fsn, a1.ns, a2.ns);
+        const uint32_t slot = ht_insert(ar.hkeys, ar.hvals, hmask, key, HV_PEND | (e - lv.arc_begin));
+        store_arc(ar.arcs + e, a1.il, a2.ol, wtimes(a1.w, a2.w), slot);  // add_tr :267-285
+      }
+    }
+    n_arcs += total;
+  }
+  *n_arcs_io = n_arcs;
+  return true;
+}
+
+// One relaxation pass over states [lo, hi): lanes over states.  Returns (wave-uniform) whether any key improved.
+__device__ bool relax_states(const Arena& ar, uint32_t lo, uint32_t hi, uint32_t n_arcs_total) {
+  const uint32_t lane = lane_id();
+  bool changed = false;
+  for (uint32_t base = lo; base < hi; base += 64) {
+    const uint32_t q = base + lane;
+    if (q < hi) {
+      const uint64_t kq = ld_l2(&ar.skey[q]);
+      if (kq != KEY_INF) {
+        const float d = dec_f32((uint32_t)(kq >> 32));
+        const uint32_t h1 = (uint32_t)kq + 1u;
+        const uint32_t b = ar.off[q], e = ar.off[q + 1];
+        for (uint32_t i = b; i < e && i < n_arcs_total; ++i) {
+          const ArcReg a = load_arc(ar.arcs + i);
+          const float c = (d + a.w) + 0.0f;
+          if (!(c < INF)) continue;
+          const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
+          const uint64_t old = atomicMin((unsigned long long*)&ar.skey[a.ns], (unsigned long long)ck);
+          if (ck < old) changed = true;
+        }
+      }
+    }
+  }
+  return __any(changed);
+}
+
+template <uint32_t FLAGS>
+__global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __restrict__ descs, FstView f2, Caps caps,
+                                                          char* __restrict__ arena_base, size_t arena_stride,
+                                                          Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
+                                                          uint32_t path_cap, uint32_t* __restrict__ path_cursor) {
+  const uint32_t p = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const ProblemDesc desc = descs[p];
+  const FstView f1 = desc.f1;
+  const uint32_t mode = desc.mode;
+  const Arena ar = carve_arena(arena_base + (size_t)p * arena_stride, caps);
+  Result res;
+  res.status = ST_OK;
+  res.n_states = res.n_arcs = res.t_states = res.t_arcs = 0;
+  res.t_start = -1;
+  res.has_path = res.hops = 0;
+  res.final_weight = res.total = INF;
+  res.path_off = 0;
+  res.n_levels = 0;
+
+  uint32_t n_states = 0, n_arcs = 0, n_levels = 0;
+  bool ok = true;
+  bool needs_fixup = false;
+
+  // compute_start :389-404
+  if (f1.start >= 0 && f2.start >= 0) {
+    // clear this problem's table
+    for (uint32_t i = lane; i < caps.H; i += 64) {
+      ar.hkeys[i] = HT_EMPTY;
+      ar.hvals[i] = HV_INIT;
+    }
+    if (FLAGS & FLAG_SP)
+      for (uint32_t i = lane; i < caps.S; i += 64) ar.skey[i] = KEY_INF;
+    wave_sync();
+    if (lane == 0) {
+      const uint64_t key0 = pack_tuple(0u, (uint32_t)f1.start, (uint32_t)f2.start);
+      const uint32_t slot = ht_insert(ar.hkeys, ar.hvals, caps.H - 1, key0, 0u);
+      st_l2(&ar.hvals[slot], 0u);
+      ar.tuples[0] = key0;
+      if (FLAGS & FLAG_SP) ar.skey[0] = (uint64_t)enc_f32(0.0f) << 32;
+    }
+    wave_sync();
+    n_states = 1;
+    uint32_t lo = 0, hi = 1;
+    // LazyFst::compute :235-259 — FIFO BFS; level k = ids [lo, hi)
+    while (lo < hi && ok) {
+      if (lane == 0) ar.lvl[n_levels] = lo;
+      n_levels++;
+      Level lv{n_arcs, hi};
+      for (uint32_t q = lo; q < hi; ++q) {
+        if (lane == 0) ar.off[q] = n_arcs;
+        if (!expand_state(f1, f2, mode, ar, caps, q, lv, &n_arcs, &res.status)) {
+          ok = false;
+          break;
+        }
+      }
+      if (!ok) break;
+      if (lane == 0) ar.off[hi] = n_arcs;
+      wave_sync();
+      // rank first occurrences: new id = hi + (number of earlier first occurrences)  [state_table.rs:49-59]
+      uint32_t n_new = 0;
+      for (uint32_t base = lv.arc_begin; base < n_arcs; base += 64) {
+        const uint32_t e = base + lane;
+        bool first = false;
+        uint32_t slot = 0;
+        if (e < n_arcs) {
+          slot = ar.arcs[e].nextstate;
+          first = ld_l2(&ar.hvals[slot]) == (HV_PEND | (e - lv.arc_begin));
+        }
+        const uint64_t m = __ballot(first);
+        const uint32_t cntm = (uint32_t)__popcll(m);
+        if (hi + n_new + cntm > caps.S) {
+          res.status = ST_OVERFLOW_STATES;
+          ok = false;
+          break;
+        }
+        if (first) {
+          const uint32_t id = hi + n_new + lanes_below(m);
+          st_l2(&ar.hvals[slot], id);
+          ar.tuples[id] = ld_l2(&ar.hkeys[slot]);
+        }
+        n_new += cntm;
+      }
+      if (!ok) break;
+      wave_sync();
+      // patch destinations: slot -> id
+      for (uint32_t base = lv.arc_begin; base < n_arcs; base += 64) {
+        const uint32_t e = base + lane;
+        if (e < n_arcs) {
+          const uint32_t id = ld_l2(&ar.hvals[ar.arcs[e].nextstate]);
+          ar.arcs[e].nextstate = id;
+          if (id < hi) needs_fixup = true;  // arc into this or an earlier level: one forward pass is not enough
+        }
+      }
+      wave_sync();
+      if (FLAGS & FLAG_SP) {
+        // relax this level's arcs now: on a lattice every predecessor of these states is already final
+        relax_states(ar, lo, hi, n_arcs);
+        wave_sync();
+      }
+      lo = hi;
+      hi += n_new;
+      n_states = hi;
+    }
+    if (lane == 0) ar.lvl[n_levels] = n_states;
+  }
+  needs_fixup = __any(needs_fixup);
+  res.n_states = n_states;
+  res.n_arcs = n_arcs;
+  res.n_levels = n_levels;
+  res.t_states = n_states;
+  res.t_arcs = n_arcs;
+  res.t_start = n_states ? 0 : -1;
+
+  // ------------------------------------------------------------ trim: connect() + del_states (stable)
+  if ((FLAGS & FLAG_TRIM) && ok && n_states) {
+    // every BFS-discovered state is accessible; coaccess = can reach a final state (connect.rs:54-60)
+    for (uint32_t i = lane; i < n_states; i += 64) ar.aux[i] = ar.fin[i] != INF ? 1u : 0u;
+    wave_sync();
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (int32_t k = (int32_t)n_levels - 1; k >= 0; --k) {  // reverse level order: one pass on lattices
+        const uint32_t llo = ar.lvl[k], lhi = ar.lvl[k + 1];
+        for (uint32_t base = llo; base < lhi; base += 64) {
+          const uint32_t q = base + lane;
+          if (q < lhi && ld_l2(&ar.aux[q]) == 0u) {
+            const uint32_t b = ar.off[q], e = ar.off[q + 1];
+            for (uint32_t i = b; i < e; ++i) {
+              if (ld_l2(&ar.aux[ar.arcs[i].nextstate])) {
+                st_l2(&ar.aux[q], 1u);
+                changed = true;
+                break;
+              }
+            }
+          }
+        }
+        wave_sync();
+      }
+      changed = __any(changed);
+    }
+    // new ids = rank among survivors (mutable_fst.rs:139-149)
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < n_states; base += 64) {
+      const uint32_t q = base + lane;
+      const bool keep = q < n_states && ld_l2(&ar.aux[q]) != 0u;
+      const uint64_t m = __ballot(keep);
+      if (q < n_states) ar.aux2[q] = keep ? kept + lanes_below(m) : REJECT;
+      kept += (uint32_t)__popcll(m);
+    }
+    wave_sync();
+    // surviving arcs, order preserved, retargeted (mutable_fst.rs:153-176)
+    uint32_t t_arcs = 0;
+    for (uint32_t base = 0; base < n_states; base += 64) {
+      const uint32_t q = base + lane;
+      const bool keep = q < n_states && ar.aux2[q] != REJECT;
+      uint32_t b = 0, e = 0, cnt = 0;
+      if (keep) {
+        b = ar.off[q];
+        e = ar.off[q + 1];
+        for (uint32_t i = b; i < e; ++i) cnt += ar.aux2[ar.arcs[i].nextstate] != REJECT;
+      }
+      uint32_t total;
+      const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+      if (keep) {
+        const uint32_t nq = ar.aux2[q];
+        uint32_t w = t_arcs + pos;
+        ar.t_off[nq] = w;
+        ar.t_fin[nq] = ar.fin[q];
+        for (uint32_t i = b; i < e; ++i) {
+          const ArcReg a = load_arc(ar.arcs + i);
+          const uint32_t nn = ar.aux2[a.ns];
+          if (nn != REJECT) store_arc(ar.t_arcs + (w++), a.il, a.ol, a.w, nn);
+        }
+      }
+      t_arcs += total;
+    }
+    if (lane == 0) ar.t_off[kept] = t_arcs;
+    res.t_states = kept;
+    res.t_arcs = t_arcs;
+    res.t_start = (kept && ar.aux2[0] != REJECT) ? (int32_t)ar.aux2[0] : -1;
+    wave_sync();
+  }
+
+  // ------------------------------------------------------------ fused n=1 shortest path on the composed FST
+  // (run on the untrimmed composition: dead states cannot lie on a successful path, and the canonical tie
+  //  rule is invariant under the stable renumbering of trim, so the result equals shortest_path(connect(C)))
+  if ((FLAGS & FLAG_SP) && ok && n_states) {
+    if (needs_fixup) {  // cyclic / non-layered composition: iterate to the fixed point
+      for (uint32_t it = 0; it <= n_states; ++it) {
+        wave_sync();
+        if (!relax_states(ar, 0, n_states, n_arcs)) break;
+      }
+    }
+    wave_sync();
+    // f_parent = argmin (d (x) rho, id)      shortest_path.rs:214-220
+    unsigned long long best = KEY_INF;
+    for (uint32_t base = 0; base < n_states; base += 64) {
+      const uint32_t q = base + lane;
+      if (q < n_states) {
+        const uint64_t kq = ld_l2(&ar.skey[q]);
+        const float f = ar.fin[q];
+        if (kq != KEY_INF && f < INF) {
+          const float tot = (dec_f32((uint32_t)(kq >> 32)) + f) + 0.0f;
+          if (tot < INF) {
+            const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | q;
+            best = c < best ? c : best;
+          }
+        }
+      }
+    }
+    best = wave_min_u64(best);
+    if (best != KEY_INF) {
+      const uint32_t fp = (uint32_t)best;
+      const uint32_t hops = (uint32_t)ld_l2(&ar.skey[fp]);
+      res.has_path = 1;
+      res.hops = hops;
+      res.final_weight = ar.fin[fp];
+      res.total = dec_f32((uint32_t)(best >> 32));
+      // parent[t] = min (s,pos) among layered tight arcs
+      for (uint32_t i = lane; i < n_states; i += 64) ar.parent[i] = KEY_INF;
+      wave_sync();
+      for (uint32_t base = 0; base < n_states; base += 64) {
+        const uint32_t q = base + lane;
+        if (q < n_states) {
+          const uint64_t kq = ld_l2(&ar.skey[q]);
+          if (kq != KEY_INF) {
+            const float d = dec_f32((uint32_t)(kq >> 32));
+            const uint32_t h1 = (uint32_t)kq + 1u;
+            const uint32_t b = ar.off[q], e = ar.off[q + 1];
+            for (uint32_t i = b; i < e; ++i) {
+              const ArcReg a = load_arc(ar.arcs + i);
+              const float c = (d + a.w) + 0.0f;
+              if (!(c < INF)) continue;
+              const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
+              if (ck == ld_l2(&ar.skey[a.ns]))
+                atomicMin((unsigned long long*)&ar.parent[a.ns], ((unsigned long long)q << 32) | (i - b));
+            }
+          }
+        }
+      }
+      wave_sync();
+      // mark the ancestors of f_parent by pointer doubling: aux = mark, jump pointers ping-pong
+      // between aux2 and lvl (dead after trim)
+      uint32_t* ja = ar.aux2;
+      uint32_t* jb = ar.lvl;
+      for (uint32_t i = lane; i < n_states; i += 64) {
+        const uint64_t pr = ld_l2(&ar.parent[i]);
+        ja[i] = pr == KEY_INF ? i : (uint32_t)(pr >> 32);
+        ar.aux[i] = i == fp ? 1u : 0u;
+      }
+      wave_sync();
+      for (uint32_t span = 1; span <= hops; span <<= 1) {
+        // mark[jump[t]] |= mark[t]; jump'[t] = jump[jump[t]]
+        for (uint32_t i = lane; i < n_states; i += 64) {
+          const uint32_t j = ja[i];
+          if (ld_l2(&ar.aux[i])) st_l2(&ar.aux[j], 1u);
+          jb[i] = ja[j];
+        }
+        wave_sync();
+        uint32_t* tmp = ja;
+        ja = jb;
+        jb = tmp;
+      }
+      // reserve the slice of the packed path buffer and write the arcs (shortest_path.rs:257-272)
+      uint32_t poff = 0;
+      if (lane == 0) poff = atomicAdd(path_cursor, hops);
+      poff = __shfl(poff, 0);
+      if ((uint64_t)poff + hops > path_cap) {
+        res.status = ST_OVERFLOW_PATH;
+      } else {
+        res.path_off = poff;
+        for (uint32_t i = lane; i < n_states; i += 64) {
+          if (ld_l2(&ar.aux[i])) {
+            const uint64_t ki = ld_l2(&ar.skey[i]);
+            const uint32_t hi_ = (uint32_t)ki;
+            if (hi_ >= 1u) {
+              const uint64_t pr = ld_l2(&ar.parent[i]);
+              const uint32_t s = (uint32_t)(pr >> 32), pos = (uint32_t)pr;
+              const ArcReg a = load_arc(ar.arcs + ar.off[s] + pos);
+              const uint32_t k = hops - hi_;  // i is the k-th state created by the backtrace
+              store_arc(path_buf + poff + k, a.il, a.ol, a.w, k);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) results[p] = res;
+}
+
+// ---------------------------------------------------------------- host side
+// ComposeFstOp::match_type (compose_fst_op.rs:169-197) with SortedMatcher::match_type
+// (matchers/sorted_matcher.rs:56-85): decided from the property bits only.
+uint32_t decide_match_mode(uint64_t p1, uint64_t p2) {
+  using namespace props;
+  const bool o_sorted = p1 & O_LABEL_SORTED, o_known = p1 & (O_LABEL_SORTED | NOT_O_LABEL_SORTED);
+  const bool i_sorted = p2 & I_LABEL_SORTED, i_known = p2 & (I_LABEL_SORTED | NOT_I_LABEL_SORTED);
+  if (o_sorted && i_sorted) return MODE_BOTH;
+  if (o_sorted) return MODE_OUTPUT;
+  if (i_sorted) return MODE_INPUT;
+  // neither known-sorted: match_type(true) -> properties_check fails when the bit pair is unknown
+  if (!o_known) throw Error("ComposeFst: 1st argument: label-sortedness properties are not known (sort?)");
+  if (!i_known) throw Error("ComposeFst: 2nd argument: label-sortedness properties are not known (sort?)");
+  throw Error(
+      "ComposeFst: 1st argument cannot match on output labels and 2nd argument cannot match on input labels (sort?).");
+}
+
+FstView view_of(const wfst_fst* f) {
+  FstView v;
+  v.offsets = f->dev.offsets;
+  v.arcs = f->dev.arcs;
+  v.finals = f->dev.finals;
+  v.noeps = f->dev.noeps;
+  v.n_states = f->n_states;
+  v.start = (int32_t)f->start;
+  return v;
+}
+
+uint32_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  if (p > 0x80000000ull) throw Error("composition too large for the wave-per-problem path");
+  return (uint32_t)p;
+}
+
+Caps make_caps(uint64_t est_states, uint64_t est_arcs) {
+  Caps c;
+  uint64_t S = std::max<uint64_t>(est_states, 64);
+  uint64_t A = std::max<uint64_t>(est_arcs, 128);
+  if (S > 0x7FFFFFF0ull || A > 0x7FFFFFF0ull) throw Error("composition too large for the wave-per-problem path");
+  c.S = (uint32_t)S;
+  c.A = (uint32_t)A;
+  c.H = next_pow2(2 * S + 128);
+  return c;
+}
+
+struct BatchRun {
+  std::vector<Result> results;
+  DBuf<char> arena;
+  size_t stride = 0;
+  Caps caps{};
+  DBuf<wfst_tr> paths;
+  std::vector<wfst_tr> h_paths;
+};
+
+template <uint32_t FLAGS>
+void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
+            bool want_paths) {
+  const size_t n = descs.size();
+  DevicePool& pool = *ctx->pool;
+  hipStream_t st = ctx->stream;
+  run.caps = caps;
+  run.stride = arena_bytes(caps);
+  run.arena = DBuf<char>(pool, run.stride * n);
+  DBuf<ProblemDesc> d_desc(pool, n);
+  DBuf<Result> d_res(pool, n);
+  DBuf<uint32_t> d_cursor(pool, 1);
+  const uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
+  run.paths = DBuf<wfst_tr>(pool, path_cap);
+  ProblemDesc* h_desc = (ProblemDesc*)ctx->pinned_big.get(n * sizeof(ProblemDesc) + n * sizeof(Result) + 64);
+  std::memcpy(h_desc, descs.data(), n * sizeof(ProblemDesc));
+  HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, sizeof(uint32_t), st));
+  if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev0, st));
+  compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(d_desc.p, f2, caps, run.arena.p, run.stride, d_res.p, run.paths.p,
+                                                          path_cap, d_cursor.p);
+  HIP_CHECK(hipGetLastError());
+  if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
+  Result* h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
+  uint32_t* h_cursor = (uint32_t*)((char*)h_res + n * sizeof(Result));
+  HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, n * sizeof(Result), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (ctx->profiling) {
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->stats.compose_ms = ms;
+  }
+  run.results.assign(h_res, h_res + n);
+  if (want_paths) {
+    const uint32_t used = std::min<uint32_t>(*h_cursor, path_cap);
+    run.h_paths.resize(used);
+    if (used) {
+      HIP_CHECK(hipMemcpyAsync(run.h_paths.data(), run.paths.p, (size_t)used * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+  }
+}
+
+// builds the reference's linear shortest-path FST (see sssp.hip::build_path_fst)
+wfst_fst* path_to_fst(wfst_ctx* ctx, const Result& r, const wfst_tr* path_arcs) {
+  HostCsr h;
+  uint64_t p = props::NULL_PROPS;
+  uint32_t n_states = 0;
+  int64_t start = -1;
+  h.offsets.push_back(0);
+  if (r.has_path) {
+    n_states = r.hops + 1;
+    h.finals.assign(n_states, INF);
+    for (uint32_t k = 0; k <= r.hops; ++k) {
+      p = props::add_state(p);
+      if (k == 0) {
+        h.finals[0] = r.final_weight;
+        p = props::set_final(p, nullptr, &r.final_weight);
+      } else {
+        h.arcs.push_back(path_arcs[k - 1]);
+        p = props::add_tr(p, k, path_arcs[k - 1], nullptr);
+      }
+      h.offsets.push_back((uint32_t)h.arcs.size());
+    }
+    start = r.hops;
+    p = props::set_start(p);
+  }
+  p = props::shortest_path(p, true) & props::ALL;
+  return make_host_fst(ctx, n_states, start, p, std::move(h));
+}
+
+const char* status_name(uint32_t s) {
+  switch (s) {
+    case ST_OVERFLOW_STATES: return "states";
+    case ST_OVERFLOW_ARCS: return "arcs";
+    case ST_OVERFLOW_HASH: return "hash";
+    case ST_OVERFLOW_PATH: return "path";
+    default: return "ok";
+  }
+}
+
+}  // namespace
+
+wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect) {
+  const uint32_t mode = decide_match_mode(f1->props, f2->props);
+  ensure_device(const_cast<wfst_fst*>(f1));
+  ensure_device(const_cast<wfst_fst*>(f2));
+  const bool has_start = f1->start >= 0 && f2->start >= 0;
+  const uint64_t out_props = props::compose_result(f1->props, f2->props, connect, has_start);
+  if (!has_start) {  // compute_start -> None: empty FST (lazy_fst.rs:229-232)
+    HostCsr h;
+    h.offsets.push_back(0);
+    return make_host_fst(ctx, 0, -1, out_props, std::move(h));
+  }
+  std::vector<ProblemDesc> descs(1);
+  descs[0].f1 = view_of(f1);
+  descs[0].mode = mode;
+  descs[0].pad = 0;
+  const FstView v2 = view_of(f2);
+  uint64_t est_s = 4ull * std::max<uint64_t>(f1->n_states, 64) + 1024;
+  uint64_t est_a = 4ull * est_s;
+  for (int attempt = 0;; ++attempt) {
+    Caps caps = make_caps(est_s, est_a);
+    BatchRun run;
+    if (connect)
+      launch<FLAG_TRIM>(ctx, descs, v2, caps, run, false);
+    else
+      launch<0>(ctx, descs, v2, caps, run, false);
+    const Result& r = run.results[0];
+    ctx->stats.compose_states = r.n_states;
+    ctx->stats.compose_arcs = r.n_arcs;
+    if (r.status == ST_OK) {
+      // carve the finished arrays out of the problem arena (same carve as the kernel)
+      const Caps& c = run.caps;
+      char* p = run.arena.p;
+      p += al16((size_t)c.S * 8) + al16((size_t)c.H * 8) + al16((size_t)c.S * 8) + al16((size_t)c.S * 8);
+      const wfst_tr* arcs = (const wfst_tr*)p; p += al16((size_t)c.A * 16);
+      const wfst_tr* t_arcs = (const wfst_tr*)p; p += al16((size_t)c.A * 16);
+      p += al16((size_t)c.H * 4);
+      const uint32_t* off = (const uint32_t*)p; p += al16((size_t)(c.S + 1) * 4);
+      const uint32_t* t_off = (const uint32_t*)p; p += al16((size_t)(c.S + 1) * 4);
+      const float* fin = (const float*)p; p += al16((size_t)c.S * 4);
+      const float* t_fin = (const float*)p;
+      if (connect)
+        return adopt_device(ctx, r.t_states, r.t_arcs, r.t_start, out_props, t_off, t_arcs, t_fin);
+      return adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1, out_props, off, arcs, fin);
+    }
+    ctx->stats.compose_retries++;
+    if (attempt > 24) throw Error(std::string("compose: arena overflow (") + status_name(r.status) + ") after retries");
+    est_s *= 4;
+    est_a *= 4;
+  }
+}
+
+void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool /*connect*/,
+                                 wfst_fst** outs, uint64_t* composed_arcs) {
+  if (composed_arcs) *composed_arcs = 0;
+  if (n == 0) return;
+  ensure_device(const_cast<wfst_fst*>(t));
+  const FstView v2 = view_of(t);
+  std::vector<ProblemDesc> descs(n);
+  std::vector<size_t> todo(n);
+  uint64_t max_states = 64;
+  for (size_t i = 0; i < n; ++i) {
+    if (!accs[i]) throw Error("null acceptor in batch");
+    descs[i].mode = decide_match_mode(accs[i]->props, t->props);
+    ensure_device(const_cast<wfst_fst*>(accs[i]));
+    descs[i].f1 = view_of(accs[i]);
+    descs[i].pad = 0;
+    todo[i] = i;
+    max_states = std::max<uint64_t>(max_states, accs[i]->n_states);
+    outs[i] = nullptr;
+  }
+  uint64_t est_s = 4ull * max_states + 256;
+  uint64_t est_a = 2ull * est_s;
+  uint64_t tot_arcs = 0, tot_states = 0;
+  double ms = 0;
+  try {
+    for (int attempt = 0; !todo.empty(); ++attempt) {
+      Caps caps = make_caps(est_s, est_a);
+      std::vector<ProblemDesc> cur(todo.size());
+      for (size_t k = 0; k < todo.size(); ++k) cur[k] = descs[todo[k]];
+      BatchRun run;
+      launch<FLAG_SP>(ctx, cur, v2, caps, run, true);
+      ms += ctx->stats.compose_ms;
+      std::vector<size_t> again;
+      for (size_t k = 0; k < todo.size(); ++k) {
+        const Result& r = run.results[k];
+        if (r.status != ST_OK) {
+          again.push_back(todo[k]);
+          continue;
+        }
+        tot_arcs += r.n_arcs;
+        tot_states += r.n_states;
+        outs[todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? run.h_paths.data() + r.path_off : nullptr);
+      }
+      if (!again.empty()) {
+        ctx->stats.compose_retries++;
+        if (attempt > 24) throw Error("compose_shortest_path_batch: arena overflow after retries");
+        est_s *= 4;
+        est_a *= 4;
+      }
+      todo.swap(again);
+    }
+  } catch (...) {
+    for (size_t i = 0; i < n; ++i) {
+      delete outs[i];
+      outs[i] = nullptr;
+    }
+    throw;
+  }
+  ctx->stats.compose_states = tot_states;
+  ctx->stats.compose_arcs = tot_arcs;
+  ctx->stats.compose_ms = ms;
+  if (composed_arcs) *composed_arcs = tot_arcs;
+}
+
+}  // namespace wfst

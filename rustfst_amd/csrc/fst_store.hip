@@ -1,0 +1,280 @@
+// fst_store.hip — FST handles: HBM CSR arenas, derived arrays, upload / download.
+//
+// HBM layout of one FST, all in one arena allocation:
+//   offsets[n+1] u32 | arcs[E] {ilabel,olabel,weight,nextstate} 16 B (== CTr == on-disk arc,
+//   rustfst-ffi/src/tr.rs:8-21) | finals[n] f32 (+inf = non-final) | noeps[n] u32 (number of
+//   output-epsilon arcs: VectorFstState.noepsilons, vector_fst/data_structure.rs:28-34, needed by
+//   the sequence filter) | wn[E] {weight bits, nextstate} 8 B (the only bytes the relaxation reads).
+#include "common.h"
+#include "fst_props.h"
+
+namespace wfst {
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+// one thread per arc: pack {w,next}; validate nextstate
+__global__ void derive_wn_kernel(const wfst_tr* __restrict__ arcs, uint2* __restrict__ wn, uint64_t n_arcs,
+                                 uint32_t n_states_max, uint32_t* __restrict__ err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n_arcs; i += stride) {
+    const uint4 a = reinterpret_cast<const uint4*>(arcs)[i];  // one 16-B load per arc
+    wn[i] = make_uint2(a.z, a.w);
+    bad |= a.w >= n_states_max;
+  }
+  if (bad) atomicOr(err, 1u);
+}
+
+// one thread per state (of the concatenation): count olabel == 0 arcs; validate offsets.
+// seg_* describe the FSTs packed in the arena so that nextstate bounds are per FST.
+__global__ void derive_noeps_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
+                                    uint32_t* __restrict__ noeps, uint32_t n_states, uint32_t* __restrict__ err) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_states) return;
+  const uint32_t b = offsets[s], e = offsets[s + 1];
+  if (e < b) {
+    atomicOr(err, 2u);
+    noeps[s] = 0;
+    return;
+  }
+  uint32_t c = 0;
+  for (uint32_t i = b; i < e; ++i) c += arcs[i].olabel == WFST_EPS_LABEL;
+  noeps[s] = c;
+}
+
+struct Layout {
+  size_t off_offsets, off_arcs, off_finals, off_noeps, off_wn, total;
+};
+Layout make_layout(size_t n_offsets, size_t n_states, size_t n_arcs) {
+  Layout l;
+  size_t o = 0;
+  l.off_offsets = o;
+  o = align_up(o + n_offsets * sizeof(uint32_t));
+  l.off_arcs = o;
+  o = align_up(o + n_arcs * sizeof(wfst_tr));
+  l.off_finals = o;
+  o = align_up(o + n_states * sizeof(float));
+  l.off_noeps = o;
+  o = align_up(o + n_states * sizeof(uint32_t));
+  l.off_wn = o;
+  o = align_up(o + n_arcs * sizeof(uint2));
+  l.total = std::max<size_t>(o, ALIGN);
+  return l;
+}
+
+std::shared_ptr<DeviceArena> make_arena(wfst_ctx* ctx, size_t bytes) {
+  auto a = std::make_shared<DeviceArena>();
+  a->ctx = ctx;
+  a->base = ctx->pool->alloc(bytes);
+  a->bytes = bytes;
+  return a;
+}
+
+void check_header(uint32_t n_states, int64_t start) {
+  if (n_states >= 0x7FFFFFFFu) throw Error("FST too large: state ids must fit in 31 bits");
+  if (start < -1 || (start >= 0 && (uint64_t)start >= n_states)) throw Error("start state out of range");
+}
+
+// Runs the derive kernels for a single FST laid out at `l` in `arena` and validates it.
+void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_t n_arcs) {
+  DBuf<uint32_t> err(*ctx->pool, 1);
+  HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), ctx->stream));
+  if (n_arcs) {
+    int blocks = (int)std::min<uint64_t>((n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
+    derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(d.arcs, const_cast<uint2*>(d.wn), n_arcs, n_states, err.p);
+  }
+  if (n_states) {
+    derive_noeps_kernel<<<(n_states + 255) / 256, 256, 0, ctx->stream>>>(d.offsets, d.arcs, const_cast<uint32_t*>(d.noeps),
+                                                                        n_states, err.p);
+  }
+  HIP_CHECK(hipGetLastError());
+  uint32_t* h = (uint32_t*)ctx->pinned.get(sizeof(uint32_t));
+  HIP_CHECK(hipMemcpyAsync(h, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (*h & 1u) throw Error("invalid FST: an arc's nextstate is >= num_states");
+  if (*h & 2u) throw Error("invalid FST: offsets are not non-decreasing");
+}
+
+DeviceCsr carve(const std::shared_ptr<DeviceArena>& arena, const Layout& l) {
+  DeviceCsr d;
+  d.arena = arena;
+  char* b = (char*)arena->base;
+  d.offsets = (const uint32_t*)(b + l.off_offsets);
+  d.arcs = (const wfst_tr*)(b + l.off_arcs);
+  d.finals = (const float*)(b + l.off_finals);
+  d.noeps = (const uint32_t*)(b + l.off_noeps);
+  d.wn = (const uint2*)(b + l.off_wn);
+  return d;
+}
+
+}  // namespace
+
+wfst_fst* make_host_fst(wfst_ctx* ctx, uint32_t n_states, int64_t start, uint64_t props, HostCsr&& csr) {
+  auto f = std::make_unique<wfst_fst>();
+  f->ctx = ctx;
+  f->n_states = n_states;
+  f->n_arcs = csr.arcs.size();
+  f->start = start;
+  f->props = props & props::ALL;
+  f->host = std::move(csr);
+  f->has_host = true;
+  return f.release();
+}
+
+static wfst_fst* upload_generic(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets,
+                                const wfst_tr* arcs, const float* finals, uint64_t props, hipMemcpyKind kind,
+                                uint64_t n_arcs) {
+  check_header(n_states, start);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  Layout l = make_layout((size_t)n_states + 1, n_states, n_arcs);
+  auto arena = make_arena(ctx, l.total);
+  DeviceCsr d = carve(arena, l);
+  if (n_states) {
+    HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t*>(d.offsets), offsets, ((size_t)n_states + 1) * sizeof(uint32_t), kind,
+                             ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(const_cast<float*>(d.finals), finals, (size_t)n_states * sizeof(float), kind, ctx->stream));
+  } else {
+    HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(d.offsets), 0, sizeof(uint32_t), ctx->stream));
+  }
+  if (n_arcs) HIP_CHECK(hipMemcpyAsync(const_cast<wfst_tr*>(d.arcs), arcs, n_arcs * sizeof(wfst_tr), kind, ctx->stream));
+  derive_single(ctx, d, n_states, n_arcs);
+  auto f = std::make_unique<wfst_fst>();
+  f->ctx = ctx;
+  f->n_states = n_states;
+  f->n_arcs = n_arcs;
+  f->start = start;
+  f->props = props & props::ALL;  // FstProperties::from_bits_truncate (vector_fst/serializable_fst.rs:165)
+  f->dev = d;
+  f->has_dev = true;
+  return f.release();
+}
+
+wfst_fst* upload_from_host(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets, const wfst_tr* arcs,
+                           const float* finals, uint64_t props) {
+  uint64_t n_arcs = n_states ? offsets[n_states] : 0;
+  if (n_states && offsets[0] != 0) throw Error("invalid FST: offsets[0] must be 0");
+  if (n_arcs && !arcs) throw Error("null arcs array");
+  return upload_generic(ctx, n_states, start, offsets, arcs, finals, props, hipMemcpyHostToDevice, n_arcs);
+}
+
+wfst_fst* upload_from_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* d_offsets,
+                             const wfst_tr* d_arcs, const float* d_finals, uint64_t props) {
+  HIP_CHECK(hipSetDevice(ctx->device));
+  uint32_t last = 0;
+  if (n_states) {
+    HIP_CHECK(hipMemcpyAsync(&last, d_offsets + n_states, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  return upload_generic(ctx, n_states, start, d_offsets, d_arcs, d_finals, props, hipMemcpyDeviceToDevice, last);
+}
+
+wfst_fst* adopt_device(wfst_ctx* ctx, uint32_t n_states, uint64_t n_arcs, int64_t start, uint64_t props,
+                       const uint32_t* d_offsets, const wfst_tr* d_arcs, const float* d_finals) {
+  return upload_generic(ctx, n_states, start, d_offsets, d_arcs, d_finals, props, hipMemcpyDeviceToDevice, n_arcs);
+}
+
+void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts, const uint32_t* offsets_cat,
+                 const wfst_tr* arcs_cat, const float* finals_cat, const uint64_t* props, wfst_fst** outs) {
+  HIP_CHECK(hipSetDevice(ctx->device));
+  size_t tot_states = 0, tot_arcs = 0;
+  std::vector<size_t> state_base(n), arc_base(n);
+  for (size_t i = 0; i < n; ++i) {
+    check_header(n_states[i], starts[i]);
+    state_base[i] = tot_states;
+    arc_base[i] = tot_arcs;
+    const uint32_t* off = offsets_cat + tot_states + i;
+    if (off[0] != 0) throw Error("invalid FST in batch: offsets[0] must be 0");
+    tot_arcs += off[n_states[i]];
+    tot_states += n_states[i];
+  }
+  Layout l = make_layout(tot_states + n, tot_states, tot_arcs);
+  auto arena = make_arena(ctx, l.total);
+  DeviceCsr all = carve(arena, l);
+  HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t*>(all.offsets), offsets_cat, (tot_states + n) * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, ctx->stream));
+  if (tot_states)
+    HIP_CHECK(hipMemcpyAsync(const_cast<float*>(all.finals), finals_cat, tot_states * sizeof(float), hipMemcpyHostToDevice,
+                             ctx->stream));
+  if (tot_arcs)
+    HIP_CHECK(hipMemcpyAsync(const_cast<wfst_tr*>(all.arcs), arcs_cat, tot_arcs * sizeof(wfst_tr), hipMemcpyHostToDevice,
+                             ctx->stream));
+  // validation on the host (these are small FSTs: acceptors), derive arrays on the device
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t* off = offsets_cat + state_base[i] + i;
+    for (uint32_t s = 0; s < n_states[i]; ++s)
+      if (off[s + 1] < off[s]) throw Error("invalid FST in batch: offsets are not non-decreasing");
+    const wfst_tr* a = arcs_cat + arc_base[i];
+    for (uint32_t e = 0; e < off[n_states[i]]; ++e)
+      if (a[e].nextstate >= n_states[i]) throw Error("invalid FST in batch: an arc's nextstate is >= num_states");
+  }
+  {
+    DBuf<uint32_t> err(*ctx->pool, 1);
+    HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), ctx->stream));
+    if (tot_arcs) {
+      int blocks = (int)std::min<uint64_t>((tot_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
+      derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(all.arcs, const_cast<uint2*>(all.wn), tot_arcs, 0xFFFFFFFFu, err.p);
+    }
+    // noeps: per FST the offsets are relative, so run per FST on its slice (tiny launches; upload path only)
+    for (size_t i = 0; i < n; ++i) {
+      if (!n_states[i]) continue;
+      derive_noeps_kernel<<<(n_states[i] + 255) / 256, 256, 0, ctx->stream>>>(
+          all.offsets + state_base[i] + i, all.arcs + arc_base[i], const_cast<uint32_t*>(all.noeps) + state_base[i],
+          n_states[i], err.p);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  for (size_t i = 0; i < n; ++i) {
+    auto f = std::make_unique<wfst_fst>();
+    f->ctx = ctx;
+    f->n_states = n_states[i];
+    f->n_arcs = (offsets_cat + state_base[i] + i)[n_states[i]];
+    f->start = starts[i];
+    f->props = props[i] & props::ALL;
+    f->dev.arena = arena;
+    f->dev.offsets = all.offsets + state_base[i] + i;
+    f->dev.arcs = all.arcs + arc_base[i];
+    f->dev.finals = all.finals + state_base[i];
+    f->dev.noeps = all.noeps + state_base[i];
+    f->dev.wn = all.wn + arc_base[i];
+    f->has_dev = true;
+    outs[i] = f.release();
+  }
+}
+
+void ensure_device(wfst_fst* f) {
+  if (f->has_dev) return;
+  if (!f->has_host) throw Error("FST handle holds no data");
+  wfst_ctx* ctx = f->ctx;
+  std::unique_ptr<wfst_fst> tmp(upload_from_host(ctx, f->n_states, f->start, f->host.offsets.data(), f->host.arcs.data(),
+                                                 f->host.finals.data(), f->props));
+  f->dev = tmp->dev;
+  f->has_dev = true;
+}
+
+void ensure_host(const wfst_fst* cf) {
+  if (cf->has_host) return;
+  wfst_fst* f = const_cast<wfst_fst*>(cf);  // cache fill only
+  if (!f->has_dev) throw Error("FST handle holds no data");
+  wfst_ctx* ctx = f->ctx;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  f->host.offsets.resize((size_t)f->n_states + 1);
+  f->host.arcs.resize(f->n_arcs);
+  f->host.finals.resize(f->n_states);
+  HIP_CHECK(hipMemcpyAsync(f->host.offsets.data(), f->dev.offsets, f->host.offsets.size() * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+  if (f->n_arcs)
+    HIP_CHECK(hipMemcpyAsync(f->host.arcs.data(), f->dev.arcs, f->n_arcs * sizeof(wfst_tr), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  if (f->n_states)
+    HIP_CHECK(hipMemcpyAsync(f->host.finals.data(), f->dev.finals, (size_t)f->n_states * sizeof(float),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  f->has_host = true;
+}
+
+}  // namespace wfst

@@ -1,0 +1,316 @@
+// sssp.hip — n=1 shortest path on an HBM-resident CSR: frontier-synchronous tropical relaxation.
+//
+// Replaces rustfst::algorithms::shortest_path for nshortest == 1:
+//   single_shortest_path            rustfst/src/algorithms/shortest_path.rs:173-239
+//   single_shortest_path_backtrace  rustfst/src/algorithms/shortest_path.rs:241-282
+// The reference relaxes states one at a time in AutoQueue order (queues/auto_queue.rs:23-99: top order
+// on lattices, FIFO inside cyclic SCCs).  Here every frontier state of a sweep is relaxed at once:
+//   key[t] = (order-preserving f32 bits of d[t]) << 32 | hops[t]      one u64 per state
+//   relax arc (s,w,t):  cand = (enc(d[s] + w) << 32) | (hops[s] + 1);  atomicMin(&key[t], cand)
+// The least fixed point of that recurrence is unique (f32 + is monotone), so the result does not depend
+// on scheduling.  Ties are resolved canonically (DESIGN.md §Shortest path): fewest arcs, then the
+// smallest (source state, arc position) predecessor, then the smallest final state id.
+// No MFMA: this is sparse DP; the bound is HBM / L2-atomic traffic (20 B per arc relaxed by the
+// SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
+#include "common.h"
+#include "fst_props.h"
+
+namespace wfst {
+
+namespace {
+
+constexpr uint64_t KEY_INF = ~0ull;
+constexpr int GROUP = 16;  // lanes cooperating on one frontier state (average fan-out ~10)
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) {
+  uint32_t b = (e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e;
+  return __uint_as_float(b);
+}
+
+struct Ctl {
+  uint32_t count[2];         // frontier sizes, double-buffered by sweep parity
+  unsigned long long arcs;   // arcs relaxed (profiling only)
+  unsigned long long best;   // enc(total) << 32 | final state
+  // backtrace header
+  uint32_t f_parent, hops;
+  float final_weight, total;
+  uint32_t has_path, pad;
+};
+
+__global__ void sssp_init_kernel(uint64_t* key, uint32_t* q0, Ctl* ctl, uint32_t start) {
+  key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
+  q0[0] = start;
+  ctl->count[0] = 1;
+  ctl->count[1] = 0;
+  ctl->arcs = 0;
+  ctl->best = KEY_INF;
+  ctl->has_path = 0;
+}
+
+// One sweep: relax every arc leaving the current frontier.  GROUP lanes share one frontier state so a
+// state's arcs (contiguous 8-B {w,next} records) are read by consecutive lanes.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restrict__ offsets,
+                                                         const uint2* __restrict__ wn, uint64_t* __restrict__ key,
+                                                         uint32_t* __restrict__ stamp,
+                                                         const uint32_t* __restrict__ q_cur, uint32_t n_cur,
+                                                         uint32_t* __restrict__ q_next, Ctl* __restrict__ ctl,
+                                                         uint32_t sweep) {
+  const uint32_t parity = sweep & 1u;
+  uint32_t* next_count = &ctl->count[parity ^ 1u];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = tid % GROUP;
+  const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
+  for (uint32_t idx = tid / GROUP; idx < n_cur; idx += n_groups) {
+    const uint32_t s = q_cur[idx];
+    const uint64_t ks = key[s];
+    const float d = dec_f32((uint32_t)(ks >> 32));
+    const uint32_t h1 = (uint32_t)ks + 1u;
+    const uint32_t b = offsets[s], e = offsets[s + 1];
+    if (COUNT && lane == 0) atomicAdd(&ctl->arcs, (unsigned long long)(e - b));
+    for (uint32_t i = b + lane; i < e; i += GROUP) {
+      const uint2 a = wn[i];
+      const float c = (d + __uint_as_float(a.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+      if (!(c < INF)) continue;                           // +inf never improves (shortest_path.rs:226)
+      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
+      const uint32_t t = a.y;
+      if (ck < key[t]) {  // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
+        const uint64_t old = atomicMin((unsigned long long*)&key[t], (unsigned long long)ck);
+        if (ck < old) {
+          if (atomicExch(&stamp[t], sweep + 1u) != sweep + 1u) {  // stamp 0 = never queued
+            const uint32_t pos = atomicAdd(next_count, 1u);
+            q_next[pos] = t;
+          }
+        }
+      }
+    }
+  }
+}
+
+// f_parent = argmin over final states of (d[s] (x) rho(s), s)      (shortest_path.rs:214-220)
+__global__ void sssp_final_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key, uint32_t n,
+                                  Ctl* __restrict__ ctl) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const float f = finals[s];
+  const uint64_t k = key[s];
+  if (k == KEY_INF || !(f < INF)) return;
+  const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;
+  if (!(tot < INF)) return;
+  atomicMin(&ctl->best, ((unsigned long long)enc_f32(tot) << 32) | s);
+}
+
+// parent[t] = min (s,pos) over arcs with (d[s]+w, hops[s]+1) == (d[t], hops[t])
+__global__ void __launch_bounds__(256) sssp_parent_kernel(const uint32_t* __restrict__ offsets,
+                                                          const uint2* __restrict__ wn,
+                                                          const uint64_t* __restrict__ key,
+                                                          unsigned long long* __restrict__ parent, uint32_t n) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = tid % GROUP;
+  const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
+  for (uint32_t s = tid / GROUP; s < n; s += n_groups) {
+    const uint64_t ks = key[s];
+    if (ks == KEY_INF) continue;
+    const float d = dec_f32((uint32_t)(ks >> 32));
+    const uint32_t h1 = (uint32_t)ks + 1u;
+    const uint32_t b = offsets[s], e = offsets[s + 1];
+    for (uint32_t i = b + lane; i < e; i += GROUP) {
+      const uint2 a = wn[i];
+      const float c = (d + __uint_as_float(a.x)) + 0.0f;
+      if (!(c < INF)) continue;
+      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
+      if (ck == key[a.y]) atomicMin(&parent[a.y], ((unsigned long long)s << 32) | (i - b));
+    }
+  }
+}
+
+__global__ void sssp_header_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key, Ctl* ctl) {
+  const unsigned long long best = ctl->best;
+  if (best == KEY_INF) {
+    ctl->has_path = 0;
+    ctl->hops = 0;
+    return;
+  }
+  const uint32_t fp = (uint32_t)best;
+  ctl->has_path = 1;
+  ctl->f_parent = fp;
+  ctl->hops = (uint32_t)key[fp];
+  ctl->final_weight = finals[fp];
+  ctl->total = dec_f32((uint32_t)(best >> 32));
+}
+
+// single_shortest_path_backtrace (shortest_path.rs:241-282): walk parent[] from f_parent; the arc of the
+// k-th created state (k >= 1) is ifst.trs(parent state)[pos] re-targeted to state k-1.
+__global__ void sssp_backtrace_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
+                                      const unsigned long long* __restrict__ parent, const Ctl* __restrict__ ctl,
+                                      wfst_tr* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t cur = ctl->f_parent;
+  const uint32_t hops = ctl->hops;
+  for (uint32_t k = 0; k < hops; ++k) {
+    const unsigned long long p = parent[cur];
+    const uint32_t s = (uint32_t)(p >> 32), pos = (uint32_t)p;
+    wfst_tr tr = arcs[offsets[s] + pos];
+    tr.nextstate = k;
+    out[k] = tr;
+    cur = s;
+  }
+}
+
+__global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __restrict__ dist, uint32_t* __restrict__ hops,
+                                   uint32_t n) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint64_t k = key[s];
+  dist[s] = k == KEY_INF ? INF : dec_f32((uint32_t)(k >> 32));
+  if (hops) hops[s] = k == KEY_INF ? 0xFFFFFFFFu : (uint32_t)k;
+}
+
+struct Solve {
+  DBuf<uint64_t> key;
+  DBuf<uint32_t> stamp, q0, q1;
+  DBuf<Ctl> ctl;
+  uint32_t sweeps = 0;
+};
+
+// Runs the relaxation to its fixed point. f must have a device copy and a start state.
+void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
+  const uint32_t n = f->n_states;
+  DevicePool& pool = *ctx->pool;
+  sv.key = DBuf<uint64_t>(pool, n);
+  sv.stamp = DBuf<uint32_t>(pool, n);
+  sv.q0 = DBuf<uint32_t>(pool, n);
+  sv.q1 = DBuf<uint32_t>(pool, n);
+  sv.ctl = DBuf<Ctl>(pool, 1);
+  hipStream_t st = ctx->stream;
+  HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
+  HIP_CHECK(hipMemsetAsync(sv.stamp.p, 0, (size_t)n * sizeof(uint32_t), st));
+  sssp_init_kernel<<<1, 1, 0, st>>>(sv.key.p, sv.q0.p, sv.ctl.p, (uint32_t)f->start);
+  uint32_t* h_count = (uint32_t*)ctx->pinned.get(64);
+  uint32_t n_cur = 1;
+  uint32_t sweep = 0;
+  const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
+  ctx->stats.sweeps = 0;
+  while (n_cur > 0) {
+    if (sweep > n + 1) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+    uint32_t* qc = (sweep & 1u) ? sv.q1.p : sv.q0.p;
+    uint32_t* qn = (sweep & 1u) ? sv.q0.p : sv.q1.p;
+    const uint32_t blocks = std::min<uint32_t>(max_blocks, (uint32_t)(((uint64_t)n_cur * GROUP + 255) / 256));
+    if (ctx->profiling) {
+      HIP_CHECK(hipEventRecord(ctx->ev0, st));
+      sssp_relax_kernel<true><<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.stamp.p, qc, n_cur, qn,
+                                                      sv.ctl.p, sweep);
+      HIP_CHECK(hipEventRecord(ctx->ev1, st));
+    } else {
+      sssp_relax_kernel<false><<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.stamp.p, qc, n_cur, qn,
+                                                       sv.ctl.p, sweep);
+    }
+    // the kernel of sweep k appends to count[(k&1)^1]; count[k&1] is stale and must be zero before sweep k+1
+    HIP_CHECK(hipMemsetAsync(&sv.ctl.p->count[sweep & 1u], 0, sizeof(uint32_t), st));
+    HIP_CHECK(hipMemcpyAsync(h_count, &sv.ctl.p->count[(sweep & 1u) ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (ctx->profiling) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      ctx->stats.relax_ms += ms;
+      ctx->stats.relax_launches += 1;
+      ctx->stats.relax_states += n_cur;
+    }
+    n_cur = *h_count;
+    sweep++;
+  }
+  sv.sweeps = sweep;
+  ctx->stats.sweeps = sweep;
+  if (ctx->profiling) {
+    Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
+    HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    ctx->stats.relax_arcs += hc->arcs;
+  }
+}
+
+// Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
+// word (add_state / set_final / add_tr / set_start bookkeeping, then shortest_path_properties(.., true)).
+wfst_fst* build_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final_weight, const wfst_tr* path_arcs) {
+  HostCsr h;
+  uint64_t p = props::NULL_PROPS;
+  uint32_t n_states = 0;
+  int64_t start = -1;
+  h.offsets.push_back(0);
+  if (has_path) {
+    n_states = hops + 1;
+    h.finals.assign(n_states, INF);
+    for (uint32_t k = 0; k <= hops; ++k) {
+      p = props::add_state(p);
+      if (k == 0) {
+        h.finals[0] = final_weight;
+        p = props::set_final(p, nullptr, &final_weight);
+      } else {
+        h.arcs.push_back(path_arcs[k - 1]);
+        p = props::add_tr(p, k, path_arcs[k - 1], nullptr);
+      }
+      h.offsets.push_back((uint32_t)h.arcs.size());
+    }
+    start = hops;
+    p = props::set_start(p);
+  }
+  p = props::shortest_path(p, true) & props::ALL;
+  return make_host_fst(ctx, n_states, start, p, std::move(h));
+}
+
+}  // namespace
+
+void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops) {
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) {
+    for (uint32_t i = 0; i < n; ++i) {
+      distance[i] = INF;
+      if (hops) hops[i] = 0xFFFFFFFFu;
+    }
+    return;
+  }
+  ensure_device(const_cast<wfst_fst*>(f));
+  Solve sv;
+  run_relaxation(ctx, f, sv);
+  DBuf<float> d(*ctx->pool, n);
+  DBuf<uint32_t> hh(*ctx->pool, n);
+  sssp_export_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(sv.key.p, d.p, hops ? hh.p : nullptr, n);
+  HIP_CHECK(hipMemcpyAsync(distance, d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (hops) HIP_CHECK(hipMemcpyAsync(hops, hh.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) return build_path_fst(ctx, false, 0, INF, nullptr);  // shortest_path.rs:185-187
+  ensure_device(const_cast<wfst_fst*>(f));
+  hipStream_t st = ctx->stream;
+  Solve sv;
+  run_relaxation(ctx, f, sv);
+  sssp_final_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.finals, sv.key.p, n, sv.ctl.p);
+  sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
+  Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
+  HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
+  const uint32_t hops = hc->hops;
+  const float final_weight = hc->final_weight;
+  std::vector<wfst_tr> path(hops);
+  if (hops) {
+    DBuf<unsigned long long> parent(*ctx->pool, n);
+    HIP_CHECK(hipMemsetAsync(parent.p, 0xFF, (size_t)n * sizeof(unsigned long long), st));
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
+    sssp_parent_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, parent.p, n);
+    DBuf<wfst_tr> out(*ctx->pool, hops);
+    sssp_backtrace_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, parent.p, sv.ctl.p, out.p);
+    HIP_CHECK(hipMemcpyAsync(path.data(), out.p, (size_t)hops * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  return build_path_fst(ctx, true, hops, final_weight, path.data());
+}
+
+}  // namespace wfst

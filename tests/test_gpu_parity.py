@@ -1,0 +1,411 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every result of the HIP path, obtained through the
+C-ABI, is compared with the CPU oracle on the same seeded inputs.
+
+Bars: compose — bit-exact state ids, arc order, labels, weight bit patterns, finals, property word.
+Shortest path — bit-exact against the oracle's canonical-tie mode on ALL inputs; against the
+reference-order mode (KDELTA, AutoQueue) whenever the optimum is unique (the reference's own contract,
+tests_openfst/algorithms/shortest_path.rs:69-92); total weight within 1e-5 always.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustfst_amd
+from rustfst_amd import ComposeConfig, ComposeFilter, ShortestPathConfig, Tr, VectorFst, synth
+from helpers import assert_flat_identical, random_fst_flat, to_device, to_oracle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def vbuild(spec):
+    f = VectorFst()
+    for _ in range(spec["n_states"]):
+        f.add_state()
+    if spec.get("start") is not None:
+        f.set_start(spec["start"])
+    for s, il, ol, w, ns in spec["arcs"]:
+        f.add_tr(s, Tr(il, ol, w, ns))
+    for s, w in spec["finals"]:
+        f.set_final(s, w)
+    return f
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+# ------------------------------------------------------------------ the reference's own python tests, verbatim shape
+def test_compose_fst(gpu_ctx):
+    """rustfst-python/tests/algorithms/test_compose.py:13-81"""
+    fst1 = VectorFst()
+    s1 = fst1.add_state()
+    s2 = fst1.add_state()
+    s3 = fst1.add_state()
+    fst1.set_start(s1)
+    fst1.set_final(s2)
+    fst1.set_final(s3)
+    fst1.add_tr(s1, Tr(1, 2, 1.0, s2))
+    fst1.add_tr(s1, Tr(1, 4, 2.0, s3))
+    fst1.add_tr(s2, Tr(3, 5, 2.0, s2))
+
+    fst2 = VectorFst()
+    s1 = fst2.add_state()
+    s2 = fst2.add_state()
+    s3 = fst2.add_state()
+    fst2.set_start(s1)
+    fst2.set_final(s3)
+    fst2.add_tr(s1, Tr(2, 6, 1.0, s2))
+    fst2.add_tr(s2, Tr(5, 7, 2.5, s3))
+    fst2.add_tr(s3, Tr(5, 8, 1.5, s3))
+    fst2.add_tr(s1, Tr(4, 9, 3.0, s3))
+
+    expected_fst = VectorFst()
+    s1 = expected_fst.add_state()
+    s2 = expected_fst.add_state()
+    s3 = expected_fst.add_state()
+    s4 = expected_fst.add_state()
+    expected_fst.set_start(s1)
+    expected_fst.set_final(s3)
+    expected_fst.set_final(s4)
+    expected_fst.add_tr(s1, Tr(1, 6, 2.0, s2))
+    expected_fst.add_tr(s1, Tr(1, 9, 5.0, s3))
+    expected_fst.add_tr(s2, Tr(3, 7, 4.5, s4))
+    expected_fst.add_tr(s4, Tr(3, 8, 3.5, s4))
+
+    fst3 = fst1.compose(fst2)
+    assert fst3 == expected_fst
+    # explicit Sequence filter + connect (compose_with_config) gives the same machine
+    fst4 = fst1.compose(fst2, ComposeConfig(ComposeFilter.SEQUENCEFILTER, True))
+    assert fst4 == expected_fst
+
+
+def test_shortest_path(gpu_ctx):
+    """rustfst-python/tests/algorithms/test_shortest_path.py:5-51"""
+    fst1 = VectorFst()
+    s1 = fst1.add_state()
+    s2 = fst1.add_state()
+    s3 = fst1.add_state()
+    s4 = fst1.add_state()
+    fst1.set_start(s1)
+    fst1.set_final(s4, 2.0)
+    fst1.add_tr(s1, Tr(1, 1, 3.0, s2))
+    fst1.add_tr(s2, Tr(2, 2, 2.0, s2))
+    fst1.add_tr(s2, Tr(3, 3, 4.0, s4))
+    fst1.add_tr(s1, Tr(4, 4, 5.0, s3))
+    fst1.add_tr(s3, Tr(5, 5, 4.0, s4))
+
+    expected_fst = VectorFst()
+    s1 = expected_fst.add_state()
+    s2 = expected_fst.add_state()
+    s3 = expected_fst.add_state()
+    expected_fst.set_start(s3)
+    expected_fst.set_final(s1, 2.0)
+    expected_fst.add_tr(s3, Tr(1, 1, 3.0, s2))
+    expected_fst.add_tr(s2, Tr(3, 3, 4.0, s1))
+
+    config = ShortestPathConfig(1, True)
+    shortes_path = fst1.shortest_path(config)
+    assert shortes_path == expected_fst
+    assert fst1.shortest_path() == expected_fst
+
+
+def test_b3_vectors(gpu_ctx, oracle):
+    g = golden("b3_fst_003_004.json")
+    c3 = vbuild(g["fst_003"]).compose(vbuild(g["fst_003_compose"]))
+    assert c3 == vbuild(g["fst_003_expected_compose"])
+    assert c3.shortest_path() == vbuild(g["fst_003_expected_shortest_path"])
+    c4 = vbuild(g["fst_004"]).compose(vbuild(g["fst_004_compose"]))  # MatchOutput-only branch
+    assert c4 == vbuild(g["fst_004_expected_compose"])
+    assert c4.shortest_path() == vbuild(g["fst_004_expected_shortest_path"])
+    empty = vbuild(g["fst_003"]).compose(vbuild(g["fst_004"]))  # literal BASELINE config 1: empty FST
+    assert empty.num_states() == 0 and empty.start() is None
+    sp = empty.shortest_path()
+    assert sp.num_states() == 0 and sp.start() is None
+
+
+def test_error_behaviour(gpu_ctx):
+    a = VectorFst()
+    a.add_state()
+    a.add_state()
+    a.set_start(0)
+    a.add_tr(0, Tr(1, 5, 0.0, 1))
+    a.add_tr(0, Tr(1, 3, 0.0, 1))
+    b = VectorFst()
+    b.add_state()
+    b.add_state()
+    b.set_start(0)
+    b.add_tr(0, Tr(7, 1, 0.0, 1))
+    b.add_tr(0, Tr(2, 1, 0.0, 1))
+    with pytest.raises(rustfst_amd.WfstError, match=r"sort\?"):  # compose_fst_op.rs:194
+        a.compose(b)
+    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
+        rustfst_amd.acceptor([1]).compose(rustfst_amd.acceptor([1]), ComposeConfig(ComposeFilter.MATCHFILTER))
+    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
+        rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=3))
+    assert rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=0)).num_states() == 0
+    # invalid CSR is rejected at the boundary, not on the device
+    with pytest.raises(rustfst_amd.WfstError, match="nextstate"):
+        bad = synth.linear_acceptor_flat([1, 2])
+        bad["arcs"]["nextstate"][1] = 99
+        to_device(bad)
+
+
+# ------------------------------------------------------------------ compose: bit-exact vs oracle
+CASES = [
+    # (n1, fan1, n2, fan2, sigma, p_eps_o(fst1), p_eps_i(fst2), sort1, sort2)
+    (6, 3, 8, 4, 4, 0.0, 0.0, "olabel", "ilabel"),
+    (10, 3, 12, 3, 3, 0.3, 0.3, "olabel", "ilabel"),     # epsilons on both sides: sequence filter states 0/1
+    (12, 4, 9, 5, 5, 0.5, 0.1, "olabel", "ilabel"),
+    (8, 2, 15, 6, 6, 0.2, 0.4, "olabel", "none"),        # only fst1 sorted -> MatchOutput
+    (8, 5, 15, 3, 6, 0.2, 0.4, "none", "ilabel"),        # only fst2 sorted -> MatchInput
+    (40, 3, 60, 8, 12, 0.1, 0.1, "olabel", "ilabel"),
+    (5, 70, 7, 90, 40, 0.05, 0.05, "olabel", "ilabel"),  # fan-out > 64: binary-search path + multi-chunk items
+    (30, 2, 30, 2, 2, 0.0, 0.0, "olabel", "ilabel"),     # dense label collisions, cyclic
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("connect", [True, False])
+def test_compose_bit_exact_vs_oracle(gpu_ctx, oracle, case, connect):
+    n1, f1, n2, f2, sigma, pe1, pe2, sort1, sort2 = CASES[case]
+    for seed in range(4):
+        rng = np.random.default_rng(1000 * case + seed)
+        a = random_fst_flat(rng, n1, f1, sigma, p_eps_o=pe1, p_eps_i=0.1 if pe1 else 0.0, sort=sort1)
+        b = random_fst_flat(rng, n2, f2, sigma, p_eps_i=pe2, p_eps_o=0.1 if pe2 else 0.0, sort=sort2)
+        if sort1 == "none" and (a["props"] & synth.O_LABEL_SORTED):
+            continue
+        exp = to_oracle(oracle, a).compose(to_oracle(oracle, b), connect=connect).to_flat()
+        got = to_device(a).compose(to_device(b), ComposeConfig(ComposeFilter.AUTOFILTER, connect)).to_flat()
+        assert_flat_identical(got, exp, f"case {case} seed {seed} connect {connect}")
+
+
+def test_compose_acceptor_with_synthetic_transducer(gpu_ctx, oracle):
+    t = synth.make_transducer(3000, 6, 16, 0.05, seed=21)
+    accs = synth.make_acceptors(t, 4, 40, seed0=500)
+    dt, ot = to_device(t), to_oracle(oracle, t)
+    for a in accs:
+        for connect in (True, False):
+            exp = to_oracle(oracle, a).compose(ot, connect=connect).to_flat()
+            got = to_device(a).compose(dt, ComposeConfig(connect=connect)).to_flat()
+            assert_flat_identical(got, exp, f"A o T connect={connect}")
+            assert exp["n_states"] > 40
+
+
+def test_compose_wide_lattice_grows_arena(gpu_ctx, oracle):
+    """Sigma=4 makes the BFS frontier grow every level: exercises arena overflow + retry."""
+    t = synth.make_transducer(400, 8, 4, 0.0, seed=33)
+    a = synth.make_acceptors(t, 1, 10, seed0=9)[0]
+    exp = to_oracle(oracle, a).compose(to_oracle(oracle, t)).to_flat()
+    before = gpu_ctx.stats()["compose_retries"]
+    got = to_device(a).compose(to_device(t)).to_flat()
+    assert_flat_identical(got, exp, "wide lattice")
+    assert exp["n_states"] > 1500
+    assert gpu_ctx.stats()["compose_retries"] > before
+
+
+# ------------------------------------------------------------------ shortest path
+def check_shortest_path(oracle, flat, dev=None, what=""):
+    of = to_oracle(oracle, flat)
+    dev = dev or to_device(flat)
+    got = dev.shortest_path().to_flat()
+    can = of.shortest_path_canonical()
+    assert_flat_identical(got, can.to_flat(), f"{what}: vs canonical oracle")
+    ref = of.shortest_path()  # reference order + KDELTA
+    gw = path_weight(got)
+    if np.isinf(ref.total_weight):
+        assert got["n_states"] == 0
+    else:
+        assert abs(gw - ref.total_weight) <= 1e-5, f"{what}: weight {gw} vs reference-mode {ref.total_weight}"
+        ok, _ = of.contains_path(oracle.OracleFst.from_flat(**{k: got[k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props")}))
+        assert ok, f"{what}: path is not a path of the input"
+        if can.n_tied_choices == 0:
+            assert_flat_identical(got, ref.to_flat(), f"{what}: unique optimum must equal the reference-mode output")
+    return can
+
+
+def path_weight(flat):
+    return np.inf if flat["n_states"] == 0 else float(sum_left_fold(flat))
+
+
+def sum_left_fold(flat):
+    # path arcs are stored from the final end backwards; the reference accumulates from the start state
+    acc = np.float32(0.0)
+    for w in flat["arcs"]["weight"][::-1]:
+        acc = np.float32(acc + w)
+    return np.float32(acc + flat["finals"][0])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_shortest_path_small_random(gpu_ctx, oracle, seed):
+    rng = np.random.default_rng(300 + seed)
+    flat = random_fst_flat(rng, int(rng.integers(2, 80)), 4, 6, p_eps_i=0.1, p_final=0.15, min_fanout=0)
+    check_shortest_path(oracle, flat, what=f"seed {seed}")
+
+
+def test_shortest_path_ties_and_zero_weight_cycles(gpu_ctx, oracle):
+    """Unweighted cyclic FST: every arc is tight; the hop-layered parent rule must still give a simple path."""
+    rng = np.random.default_rng(4)
+    flat = random_fst_flat(rng, 50, 4, 3, p_final=0.1, max_w=1, min_fanout=1)  # all weights 0
+    can = check_shortest_path(oracle, flat, what="unweighted")
+    assert can.n_tied_choices > 0
+    flat2 = random_fst_flat(rng, 200, 5, 3, p_final=0.05, max_w=3, weight_grid=1, min_fanout=1)  # weights in {0,1,2}
+    check_shortest_path(oracle, flat2, what="small integer weights")
+
+
+def test_shortest_path_negative_weights_and_unreachable(gpu_ctx, oracle):
+    rng = np.random.default_rng(8)
+    flat = random_fst_flat(rng, 30, 3, 4, p_final=0.3, acyclic=True, min_fanout=1)
+    flat["arcs"]["weight"] -= np.float32(1.5)  # negative weights on a DAG (reference test weights go negative too)
+    check_shortest_path(oracle, flat, what="negative")
+    # no final reachable -> empty result
+    flat["finals"][:] = np.inf
+    assert to_device(flat).shortest_path().num_states == 0
+    # start None
+    flat["start"] = None
+    assert to_device(flat).shortest_path().num_states == 0
+
+
+def test_shortest_distance_matches_oracle(gpu_ctx, oracle):
+    t = synth.make_transducer(20000, 10, 256, 0.0, seed=3)
+    dist, hops = to_device(t).shortest_distance(want_hops=True)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+    np.testing.assert_array_equal(hops, can.hops)
+    ref = to_oracle(oracle, t).shortest_path(want_distance=True)  # reference order + KDELTA on grid weights
+    np.testing.assert_array_equal(dist.view(np.uint32), ref.distance.view(np.uint32))
+
+
+def test_shortest_path_on_transducer_100k(gpu_ctx, oracle):
+    """BASELINE config 2 sized T (100k states / 1M arcs): direct shortest_path(T)."""
+    t = synth.make_transducer(100_000, 10, 256, 0.0, seed=2)
+    check_shortest_path(oracle, t, what="T 100k")
+
+
+# ------------------------------------------------------------------ compose -> shortest path, single and batched
+def test_config2_compose_then_shortest_path(gpu_ctx, oracle):
+    """BASELINE config 2: T = 100k states / 1M arcs, one 1000-arc acceptor (random walk), seed 2."""
+    t = synth.make_transducer(100_000, 10, 256, 0.0, seed=2)
+    a = synth.make_acceptors(t, 1, 1000, seed0=2)[0]
+    dt, da = to_device(t), to_device(a)
+    ot, oa = to_oracle(oracle, t), to_oracle(oracle, a)
+    oc = oa.compose(ot)
+    dc = da.compose(dt)
+    assert_flat_identical(dc.to_flat(), oc.to_flat(), "config2 compose")
+    got = dc.shortest_path().to_flat()
+    can = oc.shortest_path_canonical()
+    assert_flat_identical(got, can.to_flat(), "config2 shortest path")
+    ref = oc.shortest_path()
+    assert abs(float(sum_left_fold(got)) - ref.total_weight) <= 1e-5
+    if can.n_tied_choices == 0:
+        assert_flat_identical(got, ref.to_flat(), "config2 vs reference mode")
+    # fused single-problem batch gives the same path
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch([da], dt)
+    assert_flat_identical(outs[0].to_flat(), got, "fused == compose then shortest_path")
+    assert n_arcs == oa.compose(ot, connect=False).num_arcs
+
+
+@pytest.mark.parametrize("p_eps", [0.0, 0.05])
+def test_batch_fused_vs_oracle(gpu_ctx, oracle, p_eps):
+    t = synth.make_transducer(5000, 8, 32, p_eps, seed=41)
+    accs = synth.make_acceptors(t, 24, 30, seed0=1000)
+    accs.append(synth.linear_acceptor_flat([1, 2, 3]))         # almost surely no successful path
+    accs.append(synth.linear_acceptor_flat([]))                # empty string acceptor
+    dt = to_device(t)
+    daccs = rustfst_amd.DeviceFst.upload_many(accs)
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt)
+    ot = to_oracle(oracle, t)
+    tot = 0
+    for i, a in enumerate(accs):
+        oc_raw = to_oracle(oracle, a).compose(ot, connect=False)
+        tot += oc_raw.num_arcs
+        oc = to_oracle(oracle, a).compose(ot, connect=True)
+        can = oc.shortest_path_canonical()
+        assert_flat_identical(outs[i].to_flat(), can.to_flat(), f"batch item {i}")
+        ref = oc.shortest_path()
+        if can.n_tied_choices == 0:
+            assert_flat_identical(outs[i].to_flat(), ref.to_flat(), f"batch item {i} vs reference mode")
+    assert n_arcs == tot
+    # oracle batch driver (used as the CPU baseline) agrees with the per-item oracle calls
+    o_outs, o_arcs, _ = oracle.compose_shortest_path_batch([to_oracle(oracle, a) for a in accs], ot, n_threads=2)
+    assert o_arcs == tot
+    for i in range(len(accs)):
+        assert abs(path_weight_or_inf(o_outs[i].to_flat()) - path_weight_or_inf(outs[i].to_flat())) <= 1e-5
+
+
+def path_weight_or_inf(flat):
+    return np.inf if flat["n_states"] == 0 else float(sum_left_fold(flat))
+
+
+def test_batch_cyclic_composition_needs_fixup(gpu_ctx, oracle):
+    """fst1 with cycles: the composition is not layered, the in-kernel relaxation must iterate."""
+    rng = np.random.default_rng(12)
+    a = random_fst_flat(rng, 12, 3, 4, p_eps_o=0.2, p_final=0.3, sort="olabel", min_fanout=1)
+    t = random_fst_flat(rng, 40, 5, 4, p_eps_i=0.2, p_final=0.2, sort="ilabel", min_fanout=1)
+    outs, _ = rustfst_amd.compose_shortest_path_batch([to_device(a)], to_device(t))
+    oc = to_oracle(oracle, a).compose(to_oracle(oracle, t))
+    assert_flat_identical(outs[0].to_flat(), oc.shortest_path_canonical().to_flat(), "cyclic fused")
+
+
+# ------------------------------------------------------------------ I/O and round trips
+@pytest.mark.parametrize("name", ["sigma_matcher_2_left.fst", "sigma_matcher_2_right.fst"])
+def test_openfst_binary_round_trip(gpu_ctx, oracle, name):
+    data = open(os.path.join(GOLDEN, name), "rb").read()
+    d = rustfst_amd.DeviceFst.from_bytes(data)
+    o = oracle.OracleFst.load(data)
+    assert_flat_identical(d.to_flat(), o.to_flat(), name)
+    assert d.to_bytes() == o.store()
+    v = VectorFst.from_bytes(data)
+    assert VectorFst.from_bytes(v.to_bytes()) == v
+
+
+def test_upload_device_pointers(gpu_ctx, oracle):
+    torch = pytest.importorskip("torch")
+    t = synth.make_transducer(1000, 5, 16, 0.0, seed=5)
+    off = torch.from_numpy(t["offsets"].astype(np.int64)).to(torch.int32).cuda()
+    arcs = torch.from_numpy(t["arcs"].view(np.uint8).reshape(-1, 16)).cuda()
+    fin = torch.from_numpy(t["finals"]).cuda()
+    torch.cuda.synchronize()
+    d = rustfst_amd.DeviceFst.from_device_arrays(t["n_states"], 0, off.data_ptr(), arcs.data_ptr(), fin.data_ptr(),
+                                                 t["props"])
+    assert_flat_identical(d.to_flat(), t, "device upload")
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE size
+def test_config3_properties_1m_states(gpu_ctx, oracle):
+    """BASELINE config 3 (1M states / 10M arcs): properties that do not need the oracle at full size."""
+    t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
+    accs = synth.make_acceptors(t, 8, 200, seed0=1000)
+    dt = to_device(t)
+    dist, hops = dt.shortest_distance(want_hops=True)
+    arcs, off = t["arcs"], t["offsets"]
+    src = np.repeat(np.arange(t["n_states"], dtype=np.int64), np.diff(off.astype(np.int64)))
+    cand = (dist[src] + arcs["weight"]).astype(np.float32)
+    # fixed point: no arc can still improve its head; every reached non-start state has a tight incoming arc
+    assert np.all(cand >= dist[arcs["nextstate"]])
+    tight = cand == dist[arcs["nextstate"]]
+    has_tight = np.zeros(t["n_states"], dtype=bool)
+    has_tight[arcs["nextstate"][tight]] = True
+    reached = np.isfinite(dist)
+    assert reached.all() and has_tight[1:].all() and dist[0] == 0.0
+    # idempotence + path checks
+    sp = dt.shortest_path()
+    spf = sp.to_flat()
+    assert spf["n_states"] >= 2
+    fin_states = np.flatnonzero(np.isfinite(t["finals"]))
+    best = np.min((dist[fin_states] + t["finals"][fin_states]).astype(np.float32))
+    assert float(sum_left_fold(spf)) == float(best)
+    assert_flat_identical(sp.shortest_path().to_flat(), spf, "shortest_path is idempotent on its own output", check_props=False)
+    # batch: each result reads exactly its acceptor's label string, and the oracle agrees on a sample
+    outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs), dt)
+    ot = to_oracle(oracle, t)
+    for i, (a, o) in enumerate(zip(accs, outs)):
+        f = o.to_flat()
+        assert f["n_states"] == 201
+        np.testing.assert_array_equal(f["arcs"]["ilabel"][::-1], a["arcs"]["ilabel"])
+        if i < 2:
+            can = to_oracle(oracle, a).compose(ot).shortest_path_canonical()
+            assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")

@@ -1,0 +1,148 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/wfst.h declares, the host VectorFst mirror does the reference's property bookkeeping (checked
+against the oracle's restatement), the workload generator is deterministic, and the engine refuses to
+run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rustfst_amd
+from rustfst_amd import Tr, VectorFst, _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wfst.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wfst_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(wfst_lib):
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(wfst_lib, n), f"libwfst_amd.so does not export {n}"
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert set(names) == bound, f"ctypes binding out of sync with wfst.h: {set(names) ^ bound}"
+    assert wfst_lib.wfst_abi_version() == 1
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "wfst.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert "hipStream_t" not in text
+
+
+def test_last_error_protocol(wfst_lib):
+    import ctypes as C
+    assert wfst_lib.wfst_vec_fst_set_start(None, 0) == 1  # KO
+    msg = C.c_char_p()
+    assert wfst_lib.wfst_last_error(C.byref(msg)) == 0
+    assert b"null" in msg.value
+    wfst_lib.wfst_string_destroy(msg)
+    assert wfst_lib.wfst_last_error(C.byref(msg)) == 0
+    assert msg.value == b"No error message"  # taken once, like rustfst_ffi_get_last_error (lib.rs:64-67)
+    wfst_lib.wfst_string_destroy(msg)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_engine_fails_loudly_without_gpu(wfst_lib):
+    with pytest.raises(rustfst_amd.WfstError, match="no HIP device|no CPU fallback|HIP error"):
+        rustfst_amd.Context(0)
+
+
+def test_vector_fst_mirror_matches_oracle_bookkeeping(oracle, wfst_lib):
+    rng = np.random.default_rng(7)
+    for trial in range(30):
+        n = int(rng.integers(1, 8))
+        v, o = VectorFst(), oracle.OracleFst()
+        for _ in range(n):
+            assert v.add_state() == o.add_state()
+        for _ in range(int(rng.integers(0, 15))):
+            s, ns = int(rng.integers(0, n)), int(rng.integers(0, n))
+            il, ol = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            w = float(rng.integers(0, 4)) / 2048.0 if rng.random() < 0.5 else float(rng.integers(0, 20)) / 4
+            v.add_tr(s, Tr(il, ol, w, ns))
+            o.add_tr(s, il, ol, w, ns)
+            assert v.properties() == o.properties
+        if rng.random() < 0.8:
+            s = int(rng.integers(0, n))
+            v.set_start(s)
+            o.set_start(s)
+        for _ in range(int(rng.integers(0, 3))):
+            s, w = int(rng.integers(0, n)), float(rng.integers(0, 8)) / 4
+            v.set_final(s, w)
+            o.set_final(s, w)
+        assert v.properties() == o.properties
+        assert v.num_states() == o.num_states and v.start() == o.start
+        by_ol = bool(rng.integers(0, 2))
+        v.tr_sort(ilabel_cmp=not by_ol)
+        o.tr_sort(by_olabel=by_ol)
+        assert v.properties() == o.properties
+        fo = o.to_flat()
+        got = []
+        for s in range(n):
+            got.extend((t.ilabel, t.olabel, np.float32(t.weight), t.next_state) for t in v.trs(s))
+        exp = [(int(a["ilabel"]), int(a["olabel"]), a["weight"], int(a["nextstate"])) for a in fo["arcs"]]
+        assert got == exp
+
+
+def test_vector_fst_errors_mirror_reference(wfst_lib):
+    f = VectorFst()
+    with pytest.raises(rustfst_amd.WfstError, match="doesn't exist"):
+        f.set_start(3)  # mutable_fst.rs:36-40
+    with pytest.raises(rustfst_amd.WfstError, match="doesn't exist"):
+        f.add_tr(0, Tr(1, 1, 0.0, 0))
+    a, b = rustfst_amd.acceptor([1, 2, 3]), rustfst_amd.acceptor([1, 2, 3])
+    assert a == b and a.copy() == a
+    b.set_final(3, 0.5)
+    assert a != b
+    b.set_final(3, 0.0005)  # within KDELTA: TropicalWeight == is approximate (semiring.rs:159-168)
+    assert a == b
+
+
+def test_synth_generator_is_deterministic_and_well_formed(wfst_lib):
+    t1 = synth.make_transducer(2000, 10, 256, 0.0, seed=3)
+    t2 = synth.make_transducer(2000, 10, 256, 0.0, seed=3)
+    for k in ("offsets", "finals"):
+        np.testing.assert_array_equal(t1[k], t2[k])
+    np.testing.assert_array_equal(t1["arcs"], t2["arcs"])
+    arcs, off = t1["arcs"], t1["offsets"]
+    il = arcs["ilabel"].reshape(2000, 10).astype(np.int64)
+    assert np.all(np.diff(il, axis=1) >= 0)  # ilabel-sorted
+    assert np.all(arcs["nextstate"] < 2000)
+    w512 = arcs["weight"].astype(np.float64) * 512
+    assert np.all(w512 == np.round(w512)) and w512.max() < 5120  # the 1/512 grid
+    # ring backbone: every state has an arc to s+1
+    ns = arcs["nextstate"].reshape(2000, 10)
+    assert all(((s + 1) % 2000) in ns[s] for s in range(0, 2000, 97))
+    # epsilons appear with p_eps, stay first in each state
+    te = synth.make_transducer(2000, 10, 256, 0.05, seed=5)
+    frac = np.mean(te["arcs"]["ilabel"] == 0)
+    assert 0.02 < frac < 0.08
+    accs = synth.make_acceptors(t1, 3, 20, seed0=1000)
+    assert accs[0]["n_states"] == 21 and accs[0]["props"] == synth.acceptor_props(20)
+    assert not np.array_equal(accs[0]["arcs"]["ilabel"], accs[1]["arcs"]["ilabel"])
+
+
+def test_acceptor_matches_reference_utils(oracle, wfst_lib):
+    """utils::acceptor (labels_to_fst.rs:111-132) built through the mirror, the oracle, and the flat helper agree."""
+    labels = [5, 9, 2, 2]
+    v = rustfst_amd.acceptor(labels)
+    o = oracle.OracleFst()
+    cur = o.add_state()
+    o.set_start(cur)
+    for l in labels:
+        nxt = o.add_state()
+        o.add_tr(cur, l, l, 0.0, nxt)
+        cur = nxt
+    o.set_final(cur, 0.0)
+    flat = synth.linear_acceptor_flat(labels)
+    assert v.properties() == o.properties == flat["props"]
+    fo = o.to_flat()
+    np.testing.assert_array_equal(fo["offsets"], flat["offsets"])
+    np.testing.assert_array_equal(fo["arcs"], flat["arcs"])
+    np.testing.assert_array_equal(fo["finals"], flat["finals"])

@@ -1,0 +1,220 @@
+"""CPU tests of the oracle (oracle/oracle.cpp) against everything the reference holds in-repo for this
+path: K1/K2/K3 known-answer tests, K4 loader fixtures, the hand-derived App. B vectors, plus
+invariants (brute force, path membership, REF == canonical when the optimum is unique)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import random_fst_flat, to_oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(oracle, spec):
+    f = oracle.OracleFst()
+    for _ in range(spec["n_states"]):
+        f.add_state()
+    if spec.get("start") is not None:
+        f.set_start(spec["start"])
+    for s, il, ol, w, ns in spec["arcs"]:
+        f.add_tr(s, il, ol, w, ns)
+    for s, w in spec["finals"]:
+        f.set_final(s, w)
+    return f
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def flat_matches_spec(flat, spec):
+    assert flat["n_states"] == spec["n_states"]
+    assert flat["start"] == spec.get("start")
+    got = []
+    for s in range(flat["n_states"]):
+        for a in flat["arcs"][flat["offsets"][s]:flat["offsets"][s + 1]]:
+            got.append([s, int(a["ilabel"]), int(a["olabel"]), float(a["weight"]), int(a["nextstate"])])
+    exp = spec["arcs"]
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g[:3] == e[:3] and g[4] == e[4], (g, e)
+        assert abs(g[3] - e[3]) <= 1.0 / 1024.0, (g, e)
+    fin = {s: w for s, w in spec["finals"]}
+    for s in range(flat["n_states"]):
+        if s in fin:
+            assert abs(float(flat["finals"][s]) - fin[s]) <= 1.0 / 1024.0
+        else:
+            assert np.isinf(flat["finals"][s])
+
+
+# ---------------------------------------------------------------- K1: test_compose.py:13-81
+def test_k1_compose_known_answer(oracle):
+    g = load_golden("k1_compose.json")
+    res = build(oracle, g["fst1"]).compose(build(oracle, g["fst2"]))
+    flat_matches_spec(res.to_flat(), g["expected"])
+
+
+# ---------------------------------------------------------------- K2: test_shortest_path.py:5-51
+def test_k2_shortest_path_known_answer(oracle):
+    g = load_golden("k2_shortest_path.json")
+    f = build(oracle, g["fst"])
+    sp = f.shortest_path()
+    flat_matches_spec(sp.to_flat(), g["expected"])
+    assert sp.queue_kind == "scc"  # self-loop at s1 -> SccQueue with a FIFO (auto_queue.rs:81-95)
+    spc = f.shortest_path_canonical()
+    flat_matches_spec(spc.to_flat(), g["expected"])
+    assert spc.n_tied_choices == 0
+
+
+# ---------------------------------------------------------------- K3: doctest compose_static.rs:282-289
+def test_k3_linear_compose(oracle):
+    a = oracle.OracleFst()
+    for _ in range(3):
+        a.add_state()
+    a.set_start(0)
+    a.add_tr(0, 1, 2, 0.0, 1)
+    a.add_tr(1, 2, 3, 0.0, 2)
+    a.set_final(2, 0.0)
+    b = oracle.OracleFst()
+    for _ in range(3):
+        b.add_state()
+    b.set_start(0)
+    b.add_tr(0, 2, 3, 0.0, 1)
+    b.add_tr(1, 3, 4, 0.0, 2)
+    b.set_final(2, 0.0)
+    r = a.compose(b).to_flat()
+    assert r["n_states"] == 3 and r["start"] == 0
+    assert [(int(x["ilabel"]), int(x["olabel"]), int(x["nextstate"])) for x in r["arcs"]] == [(1, 3, 1), (2, 4, 2)]
+
+
+# ---------------------------------------------------------------- App. B.3 (hand-derived from the reference sources)
+def test_b3_fst_003(oracle):
+    g = load_golden("b3_fst_003_004.json")
+    c = build(oracle, g["fst_003"]).compose(build(oracle, g["fst_003_compose"]))
+    flat_matches_spec(c.to_flat(), g["fst_003_expected_compose"])
+    sp = c.shortest_path()
+    flat_matches_spec(sp.to_flat(), g["fst_003_expected_shortest_path"])
+    assert abs(sp.total_weight - 7.0) < 1e-5
+
+
+def test_b3_fst_004_one_side_sorted(oracle):
+    g = load_golden("b3_fst_003_004.json")
+    f2 = build(oracle, g["fst_004_compose"])
+    assert f2.properties & 0x2000_0000  # NOT_I_LABEL_SORTED: ilabels [25,26,5] in insertion order
+    c = build(oracle, g["fst_004"]).compose(f2)
+    flat_matches_spec(c.to_flat(), g["fst_004_expected_compose"])
+    sp = c.shortest_path()
+    flat_matches_spec(sp.to_flat(), g["fst_004_expected_shortest_path"])
+    assert abs(sp.total_weight - 3.9) < 1e-5
+
+
+def test_b3_literal_003_o_004_is_empty(oracle):
+    g = load_golden("b3_fst_003_004.json")
+    c = build(oracle, g["fst_003"]).compose(build(oracle, g["fst_004"]))
+    assert c.num_states == 0 and c.start is None
+    sp = c.shortest_path()
+    assert sp.num_states == 0 and sp.start is None
+
+
+def test_compose_unsorted_is_an_error(oracle):
+    a = oracle.OracleFst()
+    a.add_state()
+    a.add_state()
+    a.set_start(0)
+    a.add_tr(0, 1, 5, 0.0, 1)
+    a.add_tr(0, 1, 3, 0.0, 1)  # olabels [5,3]: NOT_O_LABEL_SORTED
+    b = oracle.OracleFst()
+    b.add_state()
+    b.add_state()
+    b.set_start(0)
+    b.add_tr(0, 7, 1, 0.0, 1)
+    b.add_tr(0, 2, 1, 0.0, 1)  # ilabels [7,2]: NOT_I_LABEL_SORTED
+    with pytest.raises(oracle.OracleError, match="sort"):
+        a.compose(b)
+
+
+# ---------------------------------------------------------------- K4: binary loader fixtures
+@pytest.mark.parametrize("name,n_states,n_arcs", [("sigma_matcher_2_left.fst", 8, 10), ("sigma_matcher_2_right.fst", 12, 14)])
+def test_k4_loader_fixtures(oracle, name, n_states, n_arcs):
+    data = open(os.path.join(GOLDEN, name), "rb").read()
+    f = oracle.OracleFst.load(data)
+    assert (f.num_states, f.num_arcs) == (n_states, n_arcs)
+    again = oracle.OracleFst.load(f.store())
+    assert again == f and again.properties == f.properties
+
+
+# ---------------------------------------------------------------- invariants on random small FSTs
+@pytest.mark.parametrize("seed", range(12))
+def test_shortest_path_weight_is_bruteforce_min(oracle, seed):
+    rng = np.random.default_rng(seed)
+    flat = random_fst_flat(rng, n_states=int(rng.integers(2, 8)), max_fanout=3, sigma=4, p_final=0.4, acyclic=True)
+    f = to_oracle(oracle, flat)
+    sp = f.shortest_path()
+    brute = f.bruteforce_min_weight(10)
+    if np.isinf(brute):
+        assert sp.num_states == 0
+    else:
+        assert sp.total_weight == pytest.approx(brute, abs=1e-6)
+        ok, w = f.contains_path(sp)
+        assert ok and w == pytest.approx(brute, abs=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_ref_equals_canonical_when_optimum_unique(oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    flat = random_fst_flat(rng, n_states=int(rng.integers(5, 60)), max_fanout=4, sigma=6, p_final=0.2, min_fanout=1)
+    f = to_oracle(oracle, flat)
+    ref = f.shortest_path()
+    can = f.shortest_path_canonical()
+    exact = f.shortest_path(eq_mode=oracle.EQ_EXACT)
+    assert ref.total_weight == can.total_weight == exact.total_weight or \
+        (np.isinf(ref.total_weight) and np.isinf(can.total_weight))
+    if can.n_tied_choices == 0:
+        assert ref == can and exact == can
+        assert ref.properties == can.properties
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_compose_paths_are_paths_of_both(oracle, seed):
+    """every successful path of A o T reads a string accepted by A with weight w_A (x) w_T: checked
+    through shortest path weights: sp(A o T) == brute-force min over the composition."""
+    rng = np.random.default_rng(200 + seed)
+    a = random_fst_flat(rng, n_states=5, max_fanout=2, sigma=3, p_eps_o=0.2, p_final=0.5, sort="olabel", acyclic=True)
+    t = random_fst_flat(rng, n_states=6, max_fanout=3, sigma=3, p_eps_i=0.2, p_final=0.5, sort="ilabel", acyclic=True)
+    fa, ft = to_oracle(oracle, a), to_oracle(oracle, t)
+    c_trim = fa.compose(ft, connect=True)
+    c_raw = fa.compose(ft, connect=False)
+    assert c_trim.num_states <= c_raw.num_states
+    # trim must not change the best path weight
+    w1 = c_trim.shortest_path().total_weight
+    w2 = c_raw.shortest_path().total_weight
+    assert (np.isinf(w1) and np.isinf(w2)) or w1 == pytest.approx(w2, abs=1e-6)
+    assert w2 == pytest.approx(c_raw.bruteforce_min_weight(14), abs=1e-6) or np.isinf(w2)
+    # connect() is idempotent and keeps ids stable
+    again = oracle.OracleFst.from_flat(**{k: c_trim.to_flat()[k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props")})
+    again.connect()
+    assert again == c_trim
+
+
+def test_queue_disciplines(oracle):
+    # linear acceptor: TOP_SORTED bit -> StateOrderQueue (auto_queue.rs:32-33)
+    a = oracle.OracleFst()
+    for _ in range(3):
+        a.add_state()
+    a.set_start(0)
+    a.add_tr(0, 1, 1, 1.5, 1)
+    a.add_tr(1, 2, 2, 2.5, 2)
+    a.set_final(2, 0.0)
+    assert a.shortest_path().queue_kind == "state_order"
+    # composed lattice: props carry neither TOP_SORTED nor ACYCLIC knowledge once T is cyclic -> SCC DFS
+    rng = np.random.default_rng(5)
+    from rustfst_amd import synth
+    t = synth.make_transducer(200, 4, 8, 0.0, seed=11)
+    accs = synth.make_acceptors(t, 1, 12, seed0=77)
+    c = to_oracle(oracle, accs[0]).compose(to_oracle(oracle, t))
+    sp = c.shortest_path()
+    assert sp.queue_kind in ("top_order_scc", "scc")
+    assert sp.num_states == 13
