@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the compose -> shortest_path hot path on MI355X.
+
+Workload (BASELINE.json configs[2] + configs[3]): one shared synthetic transducer
+T(1M states, 10M arcs, fan-out 10, |Sigma| = 256, weights on the 1/512 grid, seed 3), HBM-resident.
+One "step" on every rank =
+  (S1) shortest_path(T)                      — the 10M-arc frontier relaxation (the roofline kernel)
+  (S2) for each of this rank's B linear acceptors (random walks of length 200 in T):
+       shortest_path(compose(A_i, T))        — the fused wave-per-problem pipeline
+  (N > 1 only) all-gather of the B result paths over RCCL.
+Acceptor i of the global batch (B x N acceptors) lives on rank i mod N (weak scaling: per-GPU work is
+fixed); T is replicated; no collective during compute.
+value = arcs/s over the whole job, arcs per rank-step = E(T) [each arc of T relaxed at least once]
+        + E_composed (arcs emitted by compose before trim) + E_relaxed on the composed FSTs (== E_composed).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--states", type=int, default=1_000_000)
+    ap.add_argument("--fanout", type=int, default=10)
+    ap.add_argument("--sigma", type=int, default=256)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--acc-len", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import rustfst_amd
+    from rustfst_amd import dist as wdist
+    from rustfst_amd import synth
+
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        if int(os.environ.get("WORLD_SIZE", "1")) != world:
+            raise SystemExit("--gpus N must match WORLD_SIZE (launch with torch.distributed.run)")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    stream = torch.cuda.Stream(device=device)
+    ctx = rustfst_amd.Context(local_rank, stream=stream.cuda_stream)
+    rustfst_amd.set_default_context(ctx)
+
+    # ------------------------------------------------------------------ synthetic workload (identical on all ranks)
+    t0 = time.time()
+    t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
+    n_total = args.batch_per_gpu * world
+    accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
+    mine = wdist.shard_indices(n_total, rank, world)
+    dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+    daccs = rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx)
+    e_t = int(t["offsets"][-1])
+    gen_s = time.time() - t0
+
+    last = {}
+
+    def step():
+        sp = dt.shortest_path()
+        outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt)
+        last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
+        if world > 1:
+            packed = wdist.pack_paths([o.to_flat() for o in outs], args.acc_len + 8)
+            last["gathered"] = wdist.gather_paths(packed, world, device)
+        return e_t + 2 * n_arcs
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t_start = time.perf_counter()
+        arcs = 0
+        for _ in range(args.steps):
+            arcs += step()
+        barrier()
+        elapsed = time.perf_counter() - t_start
+
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            ta = torch.tensor([arcs], dtype=torch.int64, device=device)
+            dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+            arcs = int(ta.item())
+
+        # ------------------------------------------------------------------ per-part times (untimed extra pass)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record(stream)
+        sp = dt.shortest_path()
+        ev[1].record(stream)
+        outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt)
+        ev[2].record(stream)
+        torch.cuda.synchronize(device)
+        ms_sp_t = ev[0].elapsed_time(ev[1])
+        ms_batch = ev[1].elapsed_time(ev[2])
+        sweeps = ctx.stats()["sweeps"]
+
+        # ------------------------------------------------------------------ roofline of the relaxation kernel
+        # HIP events bracket every sssp_relax_kernel launch on ctx's stream (wfst_ctx_set_profiling);
+        # achieved = algorithmic bytes (20 B per arc relaxed + 12 B per frontier state) / kernel time.
+        roofline = None
+        if rank == 0:
+            ctx.reset_stats()
+            ctx.set_profiling(True)
+            dt.shortest_path()
+            ctx.set_profiling(False)
+            st = ctx.stats()
+            if st["relax_ms"] > 0:
+                algo_bytes = 20.0 * st["relax_arcs"] + 12.0 * st["relax_states"]
+                achieved = algo_bytes / (st["relax_ms"] * 1e-3) / 1e9
+                roofline = {
+                    "kernel": "sssp_relax_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches": int(st["relax_launches"]),
+                    "avg_launch_us": round(1e3 * st["relax_ms"] / max(1, st["relax_launches"]), 2),
+                    "algorithmic_bytes_per_launch": round(algo_bytes / max(1, st["relax_launches"]), 1),
+                    "arcs_relaxed": int(st["relax_arcs"]), "frontier_states": int(st["relax_states"]),
+                    "relax_arcs_per_s": round(st["relax_arcs"] / (st["relax_ms"] * 1e-3), 1),
+                }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py
+        ot = oracle_py.OracleFst.from_flat(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"])
+        oaccs = [oracle_py.OracleFst.from_flat(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"])
+                 for a in (accs_all[i] for i in mine)]
+        c0 = time.perf_counter()
+        osp = ot.shortest_path()
+        c1 = time.perf_counter()
+        o_outs, o_arcs, o_sec = oracle_py.compose_shortest_path_batch(oaccs, ot, n_threads=args.cpu_threads)
+        cpu_s = (c1 - c0) + o_sec
+        cpu_arcs = e_t + 2 * o_arcs
+        # parity spot-check of what was just timed (cheap): total weights agree
+        gw = last["sp"].to_flat()
+        gpu_total = float(np.float32(np.add.reduce(gw["arcs"]["weight"][::-1].astype(np.float32), dtype=np.float32) + gw["finals"][0])) if gw["n_states"] else float("inf")
+        cpu_baseline = {
+            "value": round(cpu_arcs / cpu_s, 1), "unit": "arcs/s", "cores": args.cpu_threads, "kind": "port",
+            "sample": f"1 full step: shortest_path(T {args.states} states/{e_t} arcs) once + compose->shortest_path of "
+                      f"{len(oaccs)} acceptors (len {args.acc_len}); C++ restatement of rustfst 1.3.1 (oracle/), not rustfst binaries",
+            "seconds": round(cpu_s, 3), "ms_shortest_path_T": round(1e3 * (c1 - c0), 2),
+            "ms_batch": round(1e3 * o_sec, 2), "queue_kind": osp.queue_kind,
+            "shortest_path_T_weight_cpu": osp.total_weight, "shortest_path_T_weight_gpu": gpu_total,
+            "composed_arcs_match": bool(o_arcs == last["n_arcs"]),
+        }
+
+    if rank == 0:
+        value = arcs / elapsed
+        out = {
+            "metric": "arcs relaxed/sec (compose -> shortest_path, 1M-state / 10M-arc FST)",
+            "value": round(value, 1), "unit": "arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"configs[2]+[3]: shortest_path(T) + fused compose->shortest_path of {args.batch_per_gpu} "
+                            f"linear acceptors (len {args.acc_len}) per GPU against one shared T",
+                "transducer": {"states": args.states, "arcs": e_t, "fanout": args.fanout, "sigma": args.sigma, "seed": 3},
+                "batch_per_gpu": args.batch_per_gpu, "global_batch": n_total, "acceptor_len": args.acc_len,
+                "parallelism": f"acceptor-sharded x{world}, T replicated, RCCL all-gather of results only",
+            },
+            "ms_shortest_path_T": round(ms_sp_t, 4), "ms_compose_shortest_path_batch": round(ms_batch, 4),
+            "ms_per_compose_shortest_path": round(ms_batch / max(1, len(mine)), 5),
+            "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(last["n_arcs"]),
+            "setup_seconds": round(gen_s, 2),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

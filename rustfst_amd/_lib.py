@@ -89,6 +89,15 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m rustfst_amd.build` "
                 "(hipcc --offload-arch=gfx950). rustfst_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME
+        # libamdhip64.so.7, requested by file name).  If the system copy were loaded first, torch would load
+        # a second runtime and then see no GPU; loaded in this order the dynamic linker resolves our
+        # NEEDED libamdhip64.so.7 to the copy torch already mapped.
+        if os.environ.get("WFST_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)

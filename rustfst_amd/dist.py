@@ -1,0 +1,77 @@
+"""Multi-GPU plumbing for the batch path: the unit of work is one
+(acceptor, T) problem; units are independent, so acceptor i goes to rank i mod G, T is replicated
+in every GPU's HBM, there is NO collective during compute, and the only exchange is a gather of
+the finished paths (a few KB) — an all-gather over RCCL/xGMI on GPUs, gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+from ._lib import TR_DTYPE
+
+
+def shard_indices(n_total: int, rank: int, world: int) -> List[int]:
+    """Global problem indices owned by `rank` (round robin: i mod world == rank)."""
+    return list(range(rank, n_total, world))
+
+
+def pack_paths(paths: Sequence[dict], max_arcs: int) -> np.ndarray:
+    """Fixed-size records so that one all-gather moves every rank's results:
+    per path: [n_arcs u32, final_weight f32 bits, pad, pad] + max_arcs x 16-byte arcs, as uint32 words.
+    `paths` are flat FST dicts of shortest-path outputs (n_states = n_arcs + 1, or 0 when empty)."""
+    rec = 4 + 4 * max_arcs
+    out = np.zeros((len(paths), rec), dtype=np.uint32)
+    for i, p in enumerate(paths):
+        n_arcs = max(int(p["n_states"]) - 1, 0)
+        if n_arcs > max_arcs:
+            raise ValueError(f"path with {n_arcs} arcs exceeds the gather record ({max_arcs})")
+        out[i, 0] = n_arcs
+        out[i, 1] = np.float32(p["finals"][0]).view(np.uint32) if p["n_states"] else np.float32(np.inf).view(np.uint32)
+        out[i, 2] = 1 if p["n_states"] else 0
+        if n_arcs:
+            out[i, 4:4 + 4 * n_arcs] = np.ascontiguousarray(p["arcs"]).view(np.uint32)
+    return out
+
+
+def unpack_paths(packed: np.ndarray) -> List[dict]:
+    """Inverse of pack_paths (property words are not transported; they are a function of the path)."""
+    res = []
+    for row in packed:
+        n_arcs = int(row[0])
+        if not row[2]:
+            res.append(dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=np.zeros(0, TR_DTYPE),
+                            finals=np.zeros(0, np.float32)))
+            continue
+        arcs = row[4:4 + 4 * n_arcs].copy().view(TR_DTYPE)
+        finals = np.full(n_arcs + 1, np.inf, dtype=np.float32)
+        finals[0] = row[1:2].view(np.float32)[0]
+        offsets = np.concatenate([[0], np.arange(0, n_arcs + 1)]).astype(np.uint32)
+        res.append(dict(n_states=n_arcs + 1, start=n_arcs, offsets=offsets, arcs=arcs, finals=finals))
+    return res
+
+
+def gather_paths(local_packed: np.ndarray, world: int, device=None):
+    """All-gather equally shaped per-rank result blocks. Returns [world, n_local, rec] uint32 (numpy).
+    Uses torch.distributed's default group: backend "nccl" (= RCCL over xGMI) when `device` is a GPU,
+    gloo on CPU."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(local_packed.view(np.int32))
+    if device is not None:
+        t = t.to(device, non_blocking=True)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().view(np.uint32)
+
+
+def interleave(gathered: np.ndarray, n_total: int) -> np.ndarray:
+    """[world, n_local, rec] (rank r holds problems r, r+world, ...) -> [n_total, rec] in problem order."""
+    world, n_local, rec = gathered.shape
+    out = np.zeros((n_total, rec), dtype=gathered.dtype)
+    for r in range(world):
+        idx = shard_indices(n_total, r, world)
+        out[idx] = gathered[r, :len(idx)]
+    return out
