@@ -20,7 +20,7 @@ namespace wfst {
 namespace {
 
 constexpr uint64_t KEY_INF = ~0ull;
-constexpr int GROUP = 16;  // lanes cooperating on one frontier state (average fan-out ~10)
+constexpr uint32_t GROUP = 16;  // lanes cooperating on one frontier state (average fan-out ~10)
 
 __device__ __forceinline__ uint32_t enc_f32(float f) {
   uint32_t b = __float_as_uint(f);
@@ -32,62 +32,93 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
 }
 
 struct Ctl {
-  uint32_t count[2];         // frontier sizes, double-buffered by sweep parity
-  unsigned long long arcs;   // arcs relaxed (profiling only)
-  unsigned long long best;   // enc(total) << 32 | final state
+  unsigned long long arcs;    // arcs leaving the current frontier (profiling only)
+  unsigned long long states;  // frontier states (profiling only)
+  unsigned long long best;    // enc(total) << 32 | final state
   // backtrace header
   uint32_t f_parent, hops;
   float final_weight, total;
   uint32_t has_path, pad;
 };
 
-__global__ void sssp_init_kernel(uint64_t* key, uint32_t* q0, Ctl* ctl, uint32_t start) {
+__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start) {
   key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
-  q0[0] = start;
-  ctl->count[0] = 1;
-  ctl->count[1] = 0;
+  flags0[start] = 1;
   ctl->arcs = 0;
+  ctl->states = 0;
   ctl->best = KEY_INF;
   ctl->has_path = 0;
 }
 
-// One sweep: relax every arc leaving the current frontier.  GROUP lanes share one frontier state so a
-// state's arcs (contiguous 8-B {w,next} records) are read by consecutive lanes.
-template <bool COUNT>
+// One sweep: relax every arc leaving the current frontier.
+// The frontier is a byte flag per state (idempotent plain stores: no queue, no dedupe atomics); a wave
+// scans 64 flags with one coalesced load + ballot, then GROUP lanes share each active state so its arcs
+// (contiguous 8-B {w,next} records) are read by consecutive lanes.  The only atomic is the atomicMin of
+// relaxations that pass the plain pre-check.
 __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restrict__ offsets,
                                                          const uint2* __restrict__ wn, uint64_t* __restrict__ key,
-                                                         uint32_t* __restrict__ stamp,
-                                                         const uint32_t* __restrict__ q_cur, uint32_t n_cur,
-                                                         uint32_t* __restrict__ q_next, Ctl* __restrict__ ctl,
-                                                         uint32_t sweep) {
-  const uint32_t parity = sweep & 1u;
-  uint32_t* next_count = &ctl->count[parity ^ 1u];
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = tid % GROUP;
-  const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
-  for (uint32_t idx = tid / GROUP; idx < n_cur; idx += n_groups) {
-    const uint32_t s = q_cur[idx];
-    const uint64_t ks = key[s];
-    const float d = dec_f32((uint32_t)(ks >> 32));
-    const uint32_t h1 = (uint32_t)ks + 1u;
-    const uint32_t b = offsets[s], e = offsets[s + 1];
-    if (COUNT && lane == 0) atomicAdd(&ctl->arcs, (unsigned long long)(e - b));
-    for (uint32_t i = b + lane; i < e; i += GROUP) {
-      const uint2 a = wn[i];
-      const float c = (d + __uint_as_float(a.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-      if (!(c < INF)) continue;                           // +inf never improves (shortest_path.rs:226)
-      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
-      const uint32_t t = a.y;
-      if (ck < key[t]) {  // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
-        const uint64_t old = atomicMin((unsigned long long*)&key[t], (unsigned long long)ck);
-        if (ck < old) {
-          if (atomicExch(&stamp[t], sweep + 1u) != sweep + 1u) {  // stamp 0 = never queued
-            const uint32_t pos = atomicAdd(next_count, 1u);
-            q_next[pos] = t;
+                                                         uint8_t* __restrict__ flags_cur,
+                                                         uint8_t* __restrict__ flags_next, uint32_t n,
+                                                         uint32_t* __restrict__ improved) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = lane % GROUP;         // lane inside its group
+  const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  bool any = false;
+  for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
+    const uint32_t sc = base + lane;
+    const bool act = sc < n && flags_cur[sc] != 0;
+    uint64_t mask = __ballot(act);
+    if (mask == 0) continue;
+    if (act) flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
+    while (mask) {
+      // the wave's 4 groups take the 4 lowest set bits
+      const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+      const uint64_t mine = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
+      mask = m3 & (m3 - 1);
+      if (mine == 0) continue;
+      const uint32_t s = base + (uint32_t)__ffsll((unsigned long long)mine) - 1u;
+      const uint64_t ks = key[s];
+      const float d = dec_f32((uint32_t)(ks >> 32));
+      const uint32_t h1 = (uint32_t)ks + 1u;
+      const uint32_t b = offsets[s], e = offsets[s + 1];
+      for (uint32_t i = b + sub; i < e; i += GROUP) {
+        const uint2 a = wn[i];
+        const float c = (d + __uint_as_float(a.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+        if (!(c < INF)) continue;                           // +inf never improves (shortest_path.rs:226)
+        const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
+        const uint32_t t = a.y;
+        if (ck < key[t]) {  // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
+          const uint64_t old = atomicMin((unsigned long long*)&key[t], (unsigned long long)ck);
+          if (ck < old) {
+            flags_next[t] = 1;
+            any = true;
           }
         }
       }
     }
+  }
+  if (any) *improved = 1u;
+}
+
+// profiling helper (runs outside the timed events): size of the current frontier and of its arc set
+__global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags, uint32_t n,
+                                  Ctl* __restrict__ ctl) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long arcs = 0, states = 0;
+  for (; s < n; s += gridDim.x * blockDim.x)
+    if (flags[s]) {
+      arcs += offsets[s + 1] - offsets[s];
+      states += 1;
+    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    arcs += __shfl_xor(arcs, d);
+    states += __shfl_xor(states, d);
+  }
+  if ((threadIdx.x & 63) == 0 && states) {
+    atomicAdd(&ctl->arcs, arcs);
+    atomicAdd(&ctl->states, states);
   }
 }
 
@@ -172,64 +203,73 @@ __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __re
 
 struct Solve {
   DBuf<uint64_t> key;
-  DBuf<uint32_t> stamp, q0, q1;
+  DBuf<uint8_t> flags;  // two frontiers of n bytes
+  DBuf<uint32_t> improved;
   DBuf<Ctl> ctl;
   uint32_t sweeps = 0;
 };
 
+constexpr uint32_t MAX_BATCH = 64;
+
 // Runs the relaxation to its fixed point. f must have a device copy and a start state.
+// Sweeps are launched in batches without returning to the host; a sweep that improves nothing leaves an
+// empty frontier, so the rest of its batch are no-ops and the host stops at the first zero flag.
 void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   const uint32_t n = f->n_states;
   DevicePool& pool = *ctx->pool;
   sv.key = DBuf<uint64_t>(pool, n);
-  sv.stamp = DBuf<uint32_t>(pool, n);
-  sv.q0 = DBuf<uint32_t>(pool, n);
-  sv.q1 = DBuf<uint32_t>(pool, n);
+  sv.flags = DBuf<uint8_t>(pool, 2 * (size_t)n);
+  sv.improved = DBuf<uint32_t>(pool, MAX_BATCH);
   sv.ctl = DBuf<Ctl>(pool, 1);
   hipStream_t st = ctx->stream;
   HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
-  HIP_CHECK(hipMemsetAsync(sv.stamp.p, 0, (size_t)n * sizeof(uint32_t), st));
-  sssp_init_kernel<<<1, 1, 0, st>>>(sv.key.p, sv.q0.p, sv.ctl.p, (uint32_t)f->start);
-  uint32_t* h_count = (uint32_t*)ctx->pinned.get(64);
-  uint32_t n_cur = 1;
+  HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * (size_t)n, st));
+  uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n};
+  sssp_init_kernel<<<1, 1, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
+  uint32_t* h_imp = (uint32_t*)ctx->pinned.get(MAX_BATCH * sizeof(uint32_t) + sizeof(Ctl));
+  Ctl* h_ctl = (Ctl*)(h_imp + MAX_BATCH);
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   uint32_t sweep = 0;
-  const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
+  uint32_t batch = ctx->profiling ? 1 : 4;
+  bool done = false;
   ctx->stats.sweeps = 0;
-  while (n_cur > 0) {
+  while (!done) {
     if (sweep > n + 1) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
-    uint32_t* qc = (sweep & 1u) ? sv.q1.p : sv.q0.p;
-    uint32_t* qn = (sweep & 1u) ? sv.q0.p : sv.q1.p;
-    const uint32_t blocks = std::min<uint32_t>(max_blocks, (uint32_t)(((uint64_t)n_cur * GROUP + 255) / 256));
-    if (ctx->profiling) {
-      HIP_CHECK(hipEventRecord(ctx->ev0, st));
-      sssp_relax_kernel<true><<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.stamp.p, qc, n_cur, qn,
-                                                      sv.ctl.p, sweep);
-      HIP_CHECK(hipEventRecord(ctx->ev1, st));
-    } else {
-      sssp_relax_kernel<false><<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.stamp.p, qc, n_cur, qn,
-                                                       sv.ctl.p, sweep);
+    HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, batch * sizeof(uint32_t), st));
+    for (uint32_t k = 0; k < batch; ++k) {
+      uint8_t* fc = fl[(sweep + k) & 1u];
+      uint8_t* fn = fl[((sweep + k) & 1u) ^ 1u];
+      if (ctx->profiling) {
+        sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fc, n, sv.ctl.p);
+        HIP_CHECK(hipEventRecord(ctx->ev0, st));
+      }
+      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fc, fn, n, sv.improved.p + k);
+      if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     }
-    // the kernel of sweep k appends to count[(k&1)^1]; count[k&1] is stale and must be zero before sweep k+1
-    HIP_CHECK(hipMemsetAsync(&sv.ctl.p->count[sweep & 1u], 0, sizeof(uint32_t), st));
-    HIP_CHECK(hipMemcpyAsync(h_count, &sv.ctl.p->count[(sweep & 1u) ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (ctx->profiling) {
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
       ctx->stats.relax_ms += ms;
       ctx->stats.relax_launches += 1;
-      ctx->stats.relax_states += n_cur;
     }
-    n_cur = *h_count;
-    sweep++;
+    for (uint32_t k = 0; k < batch; ++k) {
+      sweep++;
+      if (!h_imp[k]) {
+        done = true;
+        break;
+      }
+    }
+    batch = ctx->profiling ? 1 : std::min<uint32_t>(MAX_BATCH, batch * 2);
   }
   sv.sweeps = sweep;
   ctx->stats.sweeps = sweep;
   if (ctx->profiling) {
-    Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
-    HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    ctx->stats.relax_arcs += hc->arcs;
+    ctx->stats.relax_arcs += h_ctl->arcs;
+    ctx->stats.relax_states += h_ctl->states;
   }
 }
 
