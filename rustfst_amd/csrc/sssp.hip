@@ -125,14 +125,21 @@ __global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const ui
 // f_parent = argmin over final states of (d[s] (x) rho(s), s)      (shortest_path.rs:214-220)
 __global__ void sssp_final_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key, uint32_t n,
                                   Ctl* __restrict__ ctl) {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const float f = finals[s];
-  const uint64_t k = key[s];
-  if (k == KEY_INF || !(f < INF)) return;
-  const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;
-  if (!(tot < INF)) return;
-  atomicMin(&ctl->best, ((unsigned long long)enc_f32(tot) << 32) | s);
+  unsigned long long best = KEY_INF;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const float f = finals[s];
+    const uint64_t k = key[s];
+    if (k == KEY_INF || !(f < INF)) continue;
+    const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;
+    if (!(tot < INF)) continue;
+    const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | s;
+    best = c < best ? c : best;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {  // one atomic per wave instead of one per final state
+    const unsigned long long o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != KEY_INF) atomicMin(&ctl->best, best);
 }
 
 // parent[t] = min (s,pos) over arcs with (d[s]+w, hops[s]+1) == (d[t], hops[t])
@@ -230,7 +237,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   Ctl* h_ctl = (Ctl*)(h_imp + MAX_BATCH);
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   uint32_t sweep = 0;
-  uint32_t batch = ctx->profiling ? 1 : 4;
+  uint32_t batch = ctx->profiling ? 1 : 8;
   bool done = false;
   ctx->stats.sweeps = 0;
   while (!done) {
@@ -261,7 +268,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
         break;
       }
     }
-    batch = ctx->profiling ? 1 : std::min<uint32_t>(MAX_BATCH, batch * 2);
+    // constant small batches while the solve is shallow (few wasted no-op launches), larger ones for deep lattices
+    batch = ctx->profiling ? 1 : (sweep >= 64 ? MAX_BATCH : 8);
   }
   sv.sweeps = sweep;
   ctx->stats.sweeps = sweep;
@@ -331,7 +339,8 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   hipStream_t st = ctx->stream;
   Solve sv;
   run_relaxation(ctx, f, sv);
-  sssp_final_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.finals, sv.key.p, n, sv.ctl.p);
+  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p, n,
+                                                                                                      sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
   Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
   HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));

@@ -62,9 +62,10 @@ def gather_paths(local_packed: np.ndarray, world: int, device=None):
     t = torch.from_numpy(local_packed.view(np.int32))
     if device is not None:
         t = t.to(device, non_blocking=True)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    # concatenation layout along dim 0 (accepted by both the gloo and the nccl/RCCL backends)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy().view(np.uint32)
+    return out.cpu().numpy().view(np.uint32).reshape((world,) + tuple(t.shape))
 
 
 def interleave(gathered: np.ndarray, n_total: int) -> np.ndarray:

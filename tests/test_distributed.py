@@ -1,0 +1,102 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: acceptor sharding + result gather (rustfst_amd/dist.py).
+The compute on each rank is done by the oracle here (no GPU in this container); on the GPU box the same
+plumbing carries the HIP results (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from oracle import oracle_py
+    from rustfst_amd import dist as wdist
+    from rustfst_amd import synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = synth.make_transducer(500, 6, 16, 0.05, seed=13)
+        accs = synth.make_acceptors(t, n_total, 12, seed0=1000)  # identical on every rank (T gets the same finals)
+        ot = oracle_py.OracleFst.from_flat(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"])
+        mine = wdist.shard_indices(n_total, rank, world)
+        local = []
+        for i in mine:
+            a = accs[i]
+            oa = oracle_py.OracleFst.from_flat(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"])
+            local.append(oa.compose(ot).shortest_path_canonical().to_flat())
+        n_local = (n_total + world - 1) // world
+        packed = wdist.pack_paths(local, 12 + 8)
+        if packed.shape[0] < n_local:  # ragged tail: pad so that every rank contributes the same shape
+            packed = np.concatenate([packed, np.zeros((n_local - packed.shape[0], packed.shape[1]), np.uint32)])
+        gathered = wdist.gather_paths(packed, world, None)
+        allp = wdist.interleave(gathered, n_total)
+        if rank == 0:
+            # reference: all problems computed in one process
+            ok = True
+            for i, a in enumerate(accs):
+                oa = oracle_py.OracleFst.from_flat(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"])
+                exp = oa.compose(ot).shortest_path_canonical().to_flat()
+                got = wdist.unpack_paths(allp[i:i + 1])[0]
+                ok &= got["n_states"] == exp["n_states"] and got["start"] == exp["start"]
+                ok &= np.array_equal(got["arcs"], exp["arcs"]) and np.array_equal(got["finals"], exp["finals"])
+                ok &= np.array_equal(got["offsets"], exp["offsets"])
+            q.put(("ok" if ok else "mismatch", int(sum(int(r[0]) for r in allp))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_sharded_batch_gather_gloo_world2(n_total):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    status, total_arcs = q.get(timeout=10)
+    assert status == "ok"
+    assert total_arcs > 0
+
+
+def test_shard_indices_cover_everything():
+    from rustfst_amd import dist as wdist
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 7, 512):
+            seen = sorted(i for r in range(world) for i in wdist.shard_indices(n, r, world))
+            assert seen == list(range(n))
+
+
+def test_pack_unpack_roundtrip():
+    from rustfst_amd import dist as wdist
+    from rustfst_amd._lib import TR_DTYPE
+    arcs = np.array([(1, 2, 0.5, 0), (3, 4, 1.25, 1)], dtype=TR_DTYPE)
+    p = dict(n_states=3, start=2, offsets=np.array([0, 0, 1, 2], np.uint32), arcs=arcs,
+             finals=np.array([2.0, np.inf, np.inf], np.float32))
+    empty = dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=np.zeros(0, TR_DTYPE),
+                 finals=np.zeros(0, np.float32))
+    packed = wdist.pack_paths([p, empty], 5)
+    back = wdist.unpack_paths(packed)
+    assert back[0]["n_states"] == 3 and back[0]["start"] == 2
+    assert np.array_equal(back[0]["arcs"], arcs) and np.array_equal(back[0]["finals"], p["finals"])
+    assert np.array_equal(back[0]["offsets"], p["offsets"])
+    assert back[1]["n_states"] == 0
