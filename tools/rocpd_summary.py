@@ -1,31 +1,73 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into the per-kernel table that
-`rocprofv3 --stats` prints: name, calls, total/avg/min/max duration (us), share of GPU time.
-usage: python tools/rocpd_summary.py gpurun_out/prof/r01_results.db > profiles/<name>.md"""
+"""Summarise rocprofv3 rocpd sqlite databases.
+  kernel trace :  python tools/rocpd_summary.py trace  <trace_results.db>
+  PMC passes   :  python tools/rocpd_summary.py pmc    <pmc_fetch_results.db> <pmc_write_results.db>
+Prints markdown tables (what `rocprofv3 --stats` reports per kernel: calls, total/avg/min/max, share)."""
 import sqlite3
 import sys
 
 
-def main(path):
+def short(name, n=96):
+    name = name.replace("wfst::(anonymous namespace)::", "")
+    return name if len(name) < n else name[:n - 3] + "..."
+
+
+def trace(path):
     c = sqlite3.connect(path)
-    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
-    name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
-    rows = c.execute(f"select {name_col}, start, end from kernels").fetchall()
+    rows = c.execute("select name, start, end from kernels").fetchall()
     agg = {}
     for name, s, e in rows:
-        a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        a = agg.setdefault(name, [0, 0, 1 << 62, 0, 0])
         d = e - s
         a[0] += 1
         a[1] += d
         a[2] = min(a[2], d)
         a[3] = max(a[3], d)
+        a[4] += 1 if d >= 3000 else 0
     tot = sum(a[1] for a in agg.values()) or 1
-    print("| kernel | calls | total_us | avg_us | min_us | max_us | % |")
+    print("| kernel | calls | total_us | avg_us | min_us | max_us | % of GPU time |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        short = name if len(name) < 110 else name[:107] + "..."
-        print(f"| `{short}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
+        print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | "
+              f"{a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
+    rel = [(e - s) for name, s, e in rows if "sssp_relax_kernel" in name]
+    if rel:
+        n_solves = sum(1 for name, _, _ in rows if "sssp_final_kernel" in name) or 1
+        work = [d for d in rel if d >= 3000]  # launches after convergence inside a batch are ~1.5-3 us no-ops
+        print()
+        print(f"sssp_relax_kernel: {len(rel)} launches in {n_solves} solves ({len(rel) / n_solves:.1f} per solve); "
+              f"avg over all launches {sum(rel) / len(rel) / 1e3:.2f} us; "
+              f"{len(work)} launches >= 3 us avg {sum(work) / max(1, len(work)) / 1e3:.2f} us; "
+              f"kernel time per solve {sum(rel) / n_solves / 1e3:.1f} us")
+
+
+def pmc(fetch_db, write_db):
+    def load(path):
+        c = sqlite3.connect(path)
+        out = {}
+        for name, cname, n, tot in c.execute(
+                "select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
+            out[name] = (cname, n, tot)
+        nsolves = c.execute("select count(*) from pmc_events where name like '%sssp_final_kernel%'").fetchone()[0]
+        return out, max(1, nsolves)
+    f, nf = load(fetch_db)
+    w, nw = load(write_db)
+    print("| kernel | launches | FETCH_SIZE raw (MB) | 2x FETCH_SIZE (MB) | WRITE_SIZE (MB) | per solve: 2xFETCH+WRITE (MB) |")
+    print("|---|---:|---:|---:|---:|---:|")
+    for name in sorted(f, key=lambda k: -f[k][2]):
+        fr = f[name][2] / 1024.0
+        wr = w.get(name, ("", 0, 0.0))[2] / 1024.0
+        if fr + wr < 1.0:
+            continue
+        print(f"| `{short(name)}` | {f[name][1]} | {fr:.1f} | {2 * fr:.1f} | {wr:.1f} | {(2 * fr / nf + wr / nw):.1f} |")
+    print()
+    print(f"solves in the fetch pass: {nf}, in the write pass: {nw}. FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE is doubled "
+          "as MI355X_MICROARCH.md §HBM prescribes for gfx950 (calibrated there on wide coalesced reads; "
+          "the 8-B gathers of this kernel are uncalibrated, so read the column as an upper bound and the raw column as a lower bound).")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3])
