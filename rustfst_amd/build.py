@@ -40,6 +40,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(LIB_DIR, s.replace(".", "_") + ".o")
         cmd = [_hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
                "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, s), "-o", obj]
+        if os.environ.get("WFST_PHASE_TIMING") == "1":
+            cmd.insert(-4, "-DWFST_PHASE_TIMING")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

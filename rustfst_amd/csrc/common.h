@@ -127,6 +127,7 @@ struct DeviceCsr {
   const float* finals = nullptr;      // [n], +inf = non-final
   const uint32_t* noeps = nullptr;    // [n] number of output-epsilon arcs (VectorFstState.noepsilons)
   const uint2* wn = nullptr;          // [E] packed {weight bits, nextstate}: the 8 B the relaxation needs
+  const uint4* srec = nullptr;        // [n] {arc begin, arc count, final bits, noeps}: one 16-B load per state in compose
 };
 
 struct HostCsr {

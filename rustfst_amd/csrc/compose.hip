@@ -46,6 +46,7 @@ struct FstView {
   const wfst_tr* arcs;
   const float* finals;
   const uint32_t* noeps;
+  const uint4* srec;  // {arc begin, arc count, final bits, noeps}
   uint32_t n_states;
   int32_t start;  // -1 = None
 };
@@ -71,6 +72,9 @@ struct Result {
   float final_weight, total;
   uint32_t path_off;  // offset of the path arcs in the packed path buffer
   uint32_t n_levels;
+#ifdef WFST_PHASE_TIMING
+  unsigned long long dbg[8];
+#endif
 };
 
 struct Arena {
@@ -157,6 +161,19 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
+// broadcast from a wave-uniform lane: v_readlane (scalar path) instead of a ds_bpermute round trip
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t src) {
+  return ((uint64_t)rl((uint32_t)(v >> 32), src) << 32) | rl((uint32_t)v, src);
+}
+__device__ __forceinline__ uint4 rl128(uint4 v, uint32_t src) {
+  return make_uint4(rl(v.x, src), rl(v.y, src), rl(v.z, src), rl(v.w, src));
+}
+// LDS traffic of one wave is processed in issue order, so lanes of the (single-wave) workgroup only need
+// the compiler not to reorder around the hand-off and the LDS counter drained: no vmcnt wait, no s_barrier.
+__device__ __forceinline__ void lds_handoff() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // The wave is a whole workgroup (blockDim == 64): __syncthreads() is the wave-level fence that makes
 // the lanes' global-memory writes visible to each other between phases.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -249,27 +266,63 @@ __device__ inline void equal_range_global(const wfst_tr* arcs, uint32_t n, bool 
   *cnt_out = lo - first;
 }
 
+// Optional per-phase cycle accounting (build with -DWFST_PHASE_TIMING; results land in Result::dbg).
+#ifdef WFST_PHASE_TIMING
+#define PT_DECL unsigned long long pt_t = clock64(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT_MARK(k)                              \
+  {                                             \
+    const unsigned long long pt_n = clock64();  \
+    pt_acc[k] += pt_n - pt_t;                   \
+    pt_t = pt_n;                                \
+  }
+#define PT_STORE(res) \
+  for (int pt_i = 0; pt_i < 8; ++pt_i) (res).dbg[pt_i] = pt_acc[pt_i];
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#define PT_STORE(res)
+#endif
+
 struct Level {
   uint32_t arc_begin;  // first emitted arc of the level
   uint32_t hi;         // number of ids assigned before this level's new states
 };
 
-// ComposeFstOp::compute_trs + compute_final_weight for composed state q (compose_fst_op.rs:406-449).
-// Appends q's arcs at arcs[*n_arcs ...]; destination = hash slot (patched to the id after ranking).
-// Returns false on arena overflow (status written to *status).
-__device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode, const Arena& ar, const Caps& caps,
-                             uint32_t q, const Level& lv, uint32_t* n_arcs_io, uint32_t* status) {
+// LDS staging of ONE BFS level when it emits <= 64 arcs (the common case for acceptor o transducer
+// lattices): the level's arcs, destination tuples and shortest-path candidates stay on-chip, duplicates
+// are resolved with lane shuffles, and only first occurrences touch the hash table.
+struct FastStage {
+  uint32_t il[64], ol[64];
+  float w[64];
+  uint64_t key[64];   // destination tuple
+  uint64_t cand[64];  // shortest-path candidate key of the destination through this arc
+  uint64_t nkey[64];  // compacted new states (next frontier): tuple
+  uint64_t nsk[64];   //                                        shortest-path key
+  uint4 nr1[64];      //                                        state record in fst1 (prefetched)
+  uint4 nr2[64];      //                                        state record in fst2 (prefetched)
+};
+
+enum : int { EXP_OK = 0, EXP_ARENA_OVERFLOW = 1, EXP_FAST_OVERFLOW = 2 };
+
+// ComposeFstOp::compute_trs + compute_final_weight for composed state q = tuple `tk`
+// (compose_fst_op.rs:406-449).
+//  FAST = false: appends q's arcs at arcs[*n_arcs ...]; destination = hash slot (patched to the id after
+//                the level is ranked).
+//  FAST = true : stages the arcs in LDS at stg[*level_cnt ...]; nothing touches the hash table here.
+template <bool FAST>
+__device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode, const Arena& ar, const Caps& caps,
+                            uint32_t q, uint64_t tk, uint4 r1, uint4 r2, uint64_t src_sk, const Level& lv,
+                            uint32_t* n_arcs_io, FastStage* stg, uint32_t* level_cnt_io, uint32_t* status) {
   const uint32_t lane = lane_id();
   const uint32_t hmask = caps.H - 1;
-  const uint64_t tk = ar.tuples[q];
   const uint32_t fs = (uint32_t)(tk >> 63);
   const uint32_t s1 = (uint32_t)(tk >> 32) & 0x7FFFFFFFu;
   const uint32_t s2 = (uint32_t)tk;
-  const uint32_t b1 = f1.offsets[s1], e1 = f1.offsets[s1 + 1];
-  const uint32_t b2 = f2.offsets[s2], e2 = f2.offsets[s2 + 1];
-  const uint32_t n1 = e1 - b1, n2 = e2 - b2;
-  const float fin1 = f1.finals[s1], fin2 = f2.finals[s2];
-  const uint32_t ne1 = f1.noeps[s1];
+  // r1 / r2 = the 16-byte state records {arc begin, arc count, final bits, noeps} of s1 in fst1 / s2 in fst2
+  const uint32_t b1 = r1.x, b2 = r2.x;
+  const uint32_t n1 = r1.y, n2 = r2.y;
+  const float fin1 = __uint_as_float(r1.z), fin2 = __uint_as_float(r2.z);
+  const uint32_t ne1 = r1.w;
   // compute_final_weight :420-449 (final1 (x) final2; None when either is None / the product is zero)
   if (lane == 0) ar.fin[q] = (fin1 != INF && fin2 != INF) ? wtimes(fin1, fin2) : INF;
   // SequenceComposeFilter::set_state :134-148
@@ -297,8 +350,11 @@ __device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode
     se = load_arc(se_arcs + lane);
     se_key = mi ? se.il : se.ol;
   }
+  const float src_d = dec_f32((uint32_t)(src_sk >> 32));
+  const uint32_t src_h1 = (uint32_t)src_sk + 1u;
 
   uint32_t n_arcs = *n_arcs_io;
+  uint32_t level_cnt = FAST ? *level_cnt_io : 0u;
   const uint32_t n_items = n_it + 1;  // item 0 = the loop pseudo-arc (ordered_expand :229-233)
   for (uint32_t base = 0; base < n_items; base += 64) {
     const uint32_t j = base + lane;
@@ -316,7 +372,7 @@ __device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode
     if (small) {
       const uint32_t in_chunk = min(64u, n_items - base);
       for (uint32_t jj = 0; jj < in_chunk; ++jj) {
-        const uint32_t k = __shfl(skey, jj);
+        const uint32_t k = rl(skey, jj);
         const uint64_t m = __ballot(lane < n_se && se_key == k);
         if (lane == jj) {
           cnt = (uint32_t)__popcll(m);
@@ -341,18 +397,26 @@ __device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode
       fsn = 0u;
     }
     if (fsn == REJECT) cnt = 0;
-    uint32_t total;
-    const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+    uint32_t total, pos, maxcnt;
+    if (__ballot(cnt > 1u) == 0) {  // every item emits 0 or 1 arc (the usual case): two ballots replace the scans
+      const uint64_t em = __ballot(cnt == 1u);
+      pos = lanes_below(em);
+      total = (uint32_t)__popcll(em);
+      maxcnt = total ? 1u : 0u;
+    } else {
+      pos = wave_excl_scan(cnt, lane, &total);
+      maxcnt = wave_max(cnt);
+    }
     if (total == 0) continue;
-    if (n_arcs + total > caps.A) {
+    if (FAST && level_cnt + total > 64u) return EXP_FAST_OVERFLOW;
+    if ((FAST ? n_arcs + level_cnt : n_arcs) + total > caps.A) {
       *status = ST_OVERFLOW_ARCS;
-      return false;
+      return EXP_ARENA_OVERFLOW;
     }
-    if ((uint64_t)lv.hi + (n_arcs - lv.arc_begin) + total + 64 > (uint64_t)caps.H) {
+    if ((uint64_t)lv.hi + (FAST ? level_cnt : n_arcs - lv.arc_begin) + total + 64 > (uint64_t)caps.H) {
       *status = ST_OVERFLOW_HASH;
-      return false;
+      return EXP_ARENA_OVERFLOW;
     }
-    const uint32_t maxcnt = wave_max(cnt);
     for (uint32_t m = 0; m < maxcnt; ++m) {
       ArcReg aa;
       if (small) {
@@ -363,18 +427,62 @@ __device__ bool expand_state(const FstView& f1, const FstView& f2, uint32_t mode
       }
       if (m < cnt) {
         if (eps_item) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, sa} : ArcReg{0u, NO_LABEL, 0.0f, sa};  // eps_loop, mod.rs:98-105
-        const ArcReg& a1 = mi ? ab : aa;  // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319)
-        const ArcReg& a2 = mi ? aa : ab;
-        const uint32_t e = n_arcs + pos + m;
+        // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319); selected field by field so that the
+        // structs stay in registers (a reference select would push them to scratch)
+        const ArcReg a1{mi ? ab.il : aa.il, mi ? ab.ol : aa.ol, mi ? ab.w : aa.w, mi ? ab.ns : aa.ns};
+        const ArcReg a2{mi ? aa.il : ab.il, mi ? aa.ol : ab.ol, mi ? aa.w : ab.w, mi ? aa.ns : ab.ns};
         const uint64_t key = pack_tuple(fsn, a1.ns, a2.ns);
-        const uint32_t slot = ht_insert(ar.hkeys, ar.hvals, hmask, key, HV_PEND | (e - lv.arc_begin));
-        store_arc(ar.arcs + e, a1.il, a2.ol, wtimes(a1.w, a2.w), slot);  // add_tr :267-285
+        const float wsum = wtimes(a1.w, a2.w);  // add_tr :267-285
+        if (FAST) {
+          const uint32_t e = level_cnt + pos + m;
+          stg->il[e] = a1.il;
+          stg->ol[e] = a2.ol;
+          stg->w[e] = wsum;
+          stg->key[e] = key;
+          uint64_t cand = KEY_INF;
+          if (src_sk != KEY_INF) {
+            const float c = (src_d + wsum) + 0.0f;
+            if (c < INF) cand = ((uint64_t)enc_f32(c) << 32) | src_h1;
+          }
+          stg->cand[e] = cand;
+        } else {
+          const uint32_t e = n_arcs + pos + m;
+          const uint32_t slot = ht_insert(ar.hkeys, ar.hvals, hmask, key, HV_PEND | (e - lv.arc_begin));
+          store_arc(ar.arcs + e, a1.il, a2.ol, wsum, slot);
+        }
       }
     }
-    n_arcs += total;
+    if (FAST)
+      level_cnt += total;
+    else
+      n_arcs += total;
   }
-  *n_arcs_io = n_arcs;
-  return true;
+  if (FAST)
+    *level_cnt_io = level_cnt;
+  else
+    *n_arcs_io = n_arcs;
+  return EXP_OK;
+}
+
+// StateTable::find_id for a tuple seen for the first time in this level (fast path): CAS first, so a
+// new tuple costs one L2 round trip.  Returns the slot; *existed tells whether an earlier level owns it.
+__device__ __forceinline__ uint32_t ht_find_or_insert(uint64_t* hkeys, uint32_t hmask, uint64_t key, bool* existed) {
+  uint32_t slot = hash_u64(key) & hmask;
+  for (uint32_t probes = 0; probes <= hmask; ++probes) {
+    const uint64_t prev = atomicCAS((unsigned long long*)&hkeys[slot], (unsigned long long)HT_EMPTY,
+                                    (unsigned long long)key);
+    if (prev == HT_EMPTY) {
+      *existed = false;
+      return slot;
+    }
+    if (prev == key) {
+      *existed = true;
+      return slot;
+    }
+    slot = (slot + 1) & hmask;
+  }
+  *existed = false;
+  return slot;
 }
 
 // One relaxation pass over states [lo, hi): lanes over states.  Returns (wave-uniform) whether any key improved.
@@ -423,6 +531,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
   res.path_off = 0;
   res.n_levels = 0;
 
+  __shared__ FastStage stg;
+  PT_DECL
   uint32_t n_states = 0, n_arcs = 0, n_levels = 0;
   bool ok = true;
   bool needs_fixup = false;
@@ -447,14 +557,133 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
     wave_sync();
     n_states = 1;
     uint32_t lo = 0, hi = 1;
+    PT_MARK(0)  // table clear + start tuple
+    // frontier in registers while it is <= 64 states wide: lane i holds state lo + i
+    bool fast = true;
+    uint64_t f_key = lane == 0 ? pack_tuple(0u, (uint32_t)f1.start, (uint32_t)f2.start) : 0ull;
+    uint64_t f_sk = lane == 0 ? ((uint64_t)enc_f32(0.0f) << 32) : KEY_INF;
+    uint4 f_r1 = make_uint4(0, 0, 0, 0), f_r2 = make_uint4(0, 0, 0, 0);
+    if (lane == 0) {
+      f_r1 = f1.srec[f1.start];
+      f_r2 = f2.srec[f2.start];
+    }
     // LazyFst::compute :235-259 — FIFO BFS; level k = ids [lo, hi)
     while (lo < hi && ok) {
       if (lane == 0) ar.lvl[n_levels] = lo;
       n_levels++;
       Level lv{n_arcs, hi};
+      bool did_fast = false;
+      if (fast) {
+        // ---------------- small-level fast path: the whole level lives in LDS / registers
+        uint32_t level_cnt = 0;
+        int rc = EXP_OK;
+        for (uint32_t q = lo; q < hi; ++q) {
+          const uint64_t tk = rl64(f_key, q - lo);
+          const uint64_t ssk = rl64(f_sk, q - lo);
+          if (lane == 0) ar.off[q] = n_arcs + level_cnt;
+          rc = expand_state<true>(f1, f2, mode, ar, caps, q, tk, rl128(f_r1, q - lo), rl128(f_r2, q - lo), ssk, lv,
+                                  &n_arcs, &stg, &level_cnt, &res.status);
+          if (rc != EXP_OK) break;
+        }
+        if (rc == EXP_ARENA_OVERFLOW) {
+          ok = false;
+          break;
+        }
+        PT_MARK(1)  // fast: expansions (state records -> arc blocks -> matches -> LDS stage)
+        if (rc == EXP_OK) {
+          did_fast = true;
+          lds_handoff();
+          const bool have = lane < level_cnt;
+          uint32_t il = 0, ol = 0;
+          float w = 0.0f;
+          uint64_t key = HT_EMPTY, cand = KEY_INF;
+          if (have) {
+            il = stg.il[lane];
+            ol = stg.ol[lane];
+            w = stg.w[lane];
+            key = stg.key[lane];
+            cand = stg.cand[lane];
+          }
+          // speculative fetch of the destination's state records: overlaps the hash-table round trip below and
+          // removes one dependent trip to HBM from the next level
+          uint4 pr1 = make_uint4(0, 0, 0, 0), pr2 = make_uint4(0, 0, 0, 0);
+          if (have) {
+            pr1 = f1.srec[(uint32_t)(key >> 32) & 0x7FFFFFFFu];
+            pr2 = f2.srec[(uint32_t)key];
+          }
+          // first occurrence of each destination tuple inside the level + min candidate of its group
+          uint64_t mymin = cand;
+          uint32_t first = 64;
+          for (uint32_t i = 0; i < level_cnt; ++i) {
+            const uint64_t ki = rl64(key, i);
+            const uint64_t ci = rl64(cand, i);
+            if (have && ki == key) {
+              mymin = ci < mymin ? ci : mymin;
+              if (first == 64) first = i;
+            }
+          }
+          const bool is_first = have && first == lane;
+          PT_MARK(2)  // fast: stage read + record prefetch issue + in-register dedupe
+          uint32_t slot = 0, id = 0;
+          bool existed = false;
+          if (is_first) {
+            slot = ht_find_or_insert(ar.hkeys, caps.H - 1, key, &existed);
+            if (existed) id = ld_l2(&ar.hvals[slot]);
+          }
+          const bool newf = is_first && !existed;
+          const uint64_t nm = __ballot(newf);
+          const uint32_t n_new = (uint32_t)__popcll(nm);
+          if (hi + n_new > caps.S) {
+            res.status = ST_OVERFLOW_STATES;
+            ok = false;
+            break;
+          }
+          if (newf) {  // new id = hi + (number of earlier first occurrences)  [state_table.rs:49-59]
+            const uint32_t rank = lanes_below(nm);
+            id = hi + rank;
+            ar.hvals[slot] = id;  // plain store: later readers are this wave (same CU / L2); an sc1 store's ack is slow
+            ar.tuples[id] = key;
+            if (FLAGS & FLAG_SP) ar.skey[id] = mymin;
+            stg.nkey[rank] = key;
+            stg.nsk[rank] = mymin;
+            stg.nr1[rank] = pr1;
+            stg.nr2[rank] = pr2;
+          } else if ((FLAGS & FLAG_SP) && is_first && mymin != KEY_INF) {
+            atomicMin((unsigned long long*)&ar.skey[id], (unsigned long long)mymin);  // older state: fix-up will iterate
+          }
+          PT_MARK(3)  // fast: hash CAS + id assignment + stores issue
+          const uint32_t id_all = __shfl(id, first & 63u);
+          if (have) {
+            store_arc(ar.arcs + n_arcs + lane, il, ol, w, id_all);
+            if (id_all < hi) needs_fixup = true;  // arc into this or an earlier level
+          }
+          n_arcs += level_cnt;
+          if (lane == 0) ar.off[hi] = n_arcs;
+          lds_handoff();
+          if (lane < n_new) {
+            f_key = stg.nkey[lane];
+            f_sk = stg.nsk[lane];
+            f_r1 = stg.nr1[lane];
+            f_r2 = stg.nr2[lane];
+          } else {
+            f_key = 0ull;
+            f_sk = KEY_INF;
+          }
+          lds_handoff();
+          lo = hi;
+          hi += n_new;
+          n_states = hi;
+          PT_MARK(4)  // fast: arc stores + frontier compaction
+        }
+        // rc == EXP_FAST_OVERFLOW: more than 64 arcs in this level -> redo it on the general path
+      }
+      if (did_fast) continue;
+      // ---------------- general path: level staged through the arena in HBM/L2
       for (uint32_t q = lo; q < hi; ++q) {
         if (lane == 0) ar.off[q] = n_arcs;
-        if (!expand_state(f1, f2, mode, ar, caps, q, lv, &n_arcs, &res.status)) {
+        const uint64_t tk = ar.tuples[q];
+        if (expand_state<false>(f1, f2, mode, ar, caps, q, tk, f1.srec[(uint32_t)(tk >> 32) & 0x7FFFFFFFu],
+                                f2.srec[(uint32_t)tk], KEY_INF, lv, &n_arcs, nullptr, nullptr, &res.status) != EXP_OK) {
           ok = false;
           break;
         }
@@ -506,8 +735,18 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       lo = hi;
       hi += n_new;
       n_states = hi;
+      fast = n_new <= 64;
+      if (fast) {  // pull the new frontier back into registers
+        f_key = lane < n_new ? ar.tuples[lo + lane] : 0ull;
+        f_sk = ((FLAGS & FLAG_SP) && lane < n_new) ? ld_l2(&ar.skey[lo + lane]) : KEY_INF;
+        if (lane < n_new) {
+          f_r1 = f1.srec[(uint32_t)(f_key >> 32) & 0x7FFFFFFFu];
+          f_r2 = f2.srec[(uint32_t)f_key];
+        }
+      }
     }
     if (lane == 0) ar.lvl[n_levels] = n_states;
+    PT_MARK(5)  // general-path levels
   }
   needs_fixup = __any(needs_fixup);
   res.n_states = n_states;
@@ -691,6 +930,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       }
     }
   }
+  PT_MARK(6)  // trim / shortest-path epilogue
+  PT_STORE(res)
   if (lane == 0) results[p] = res;
 }
 
@@ -717,6 +958,7 @@ FstView view_of(const wfst_fst* f) {
   v.arcs = f->dev.arcs;
   v.finals = f->dev.finals;
   v.noeps = f->dev.noeps;
+  v.srec = f->dev.srec;
   v.n_states = f->n_states;
   v.start = (int32_t)f->start;
   return v;
@@ -783,6 +1025,15 @@ void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView&
     ctx->stats.compose_ms = ms;
   }
   run.results.assign(h_res, h_res + n);
+#ifdef WFST_PHASE_TIMING
+  {
+    unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+      for (int k = 0; k < 8; ++k) tot[k] += h_res[i].dbg[k];
+    std::fprintf(stderr, "[phase cycles/problem] clear %llu | expand %llu | dedupe %llu | hash %llu | store+compact %llu | general %llu | epilogue %llu  (n=%zu, levels of problem 0: %u)\n",
+                 tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot[4] / n, tot[5] / n, tot[6] / n, n, h_res[0].n_levels);
+  }
+#endif
   if (want_paths) {
     const uint32_t used = std::min<uint32_t>(*h_cursor, path_cap);
     run.h_paths.resize(used);

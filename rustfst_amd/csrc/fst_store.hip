@@ -4,7 +4,8 @@
 //   offsets[n+1] u32 | arcs[E] {ilabel,olabel,weight,nextstate} 16 B (== CTr == on-disk arc,
 //   rustfst-ffi/src/tr.rs:8-21) | finals[n] f32 (+inf = non-final) | noeps[n] u32 (number of
 //   output-epsilon arcs: VectorFstState.noepsilons, vector_fst/data_structure.rs:28-34, needed by
-//   the sequence filter) | wn[E] {weight bits, nextstate} 8 B (the only bytes the relaxation reads).
+//   the sequence filter) | wn[E] {weight bits, nextstate} 8 B (the only bytes the relaxation reads) |
+//   srec[n] {arc begin, arc count, final bits, noeps} 16 B (compose reads one record per state).
 #include "common.h"
 #include "fst_props.h"
 
@@ -32,22 +33,25 @@ __global__ void derive_wn_kernel(const wfst_tr* __restrict__ arcs, uint2* __rest
 // one thread per state (of the concatenation): count olabel == 0 arcs; validate offsets.
 // seg_* describe the FSTs packed in the arena so that nextstate bounds are per FST.
 __global__ void derive_noeps_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
-                                    uint32_t* __restrict__ noeps, uint32_t n_states, uint32_t* __restrict__ err) {
+                                    const float* __restrict__ finals, uint32_t* __restrict__ noeps,
+                                    uint4* __restrict__ srec, uint32_t n_states, uint32_t* __restrict__ err) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_states) return;
   const uint32_t b = offsets[s], e = offsets[s + 1];
   if (e < b) {
     atomicOr(err, 2u);
     noeps[s] = 0;
+    srec[s] = make_uint4(b, 0u, __float_as_uint(finals[s]), 0u);
     return;
   }
   uint32_t c = 0;
   for (uint32_t i = b; i < e; ++i) c += arcs[i].olabel == WFST_EPS_LABEL;
   noeps[s] = c;
+  srec[s] = make_uint4(b, e - b, __float_as_uint(finals[s]), c);
 }
 
 struct Layout {
-  size_t off_offsets, off_arcs, off_finals, off_noeps, off_wn, total;
+  size_t off_offsets, off_arcs, off_finals, off_noeps, off_wn, off_srec, total;
 };
 Layout make_layout(size_t n_offsets, size_t n_states, size_t n_arcs) {
   Layout l;
@@ -62,6 +66,8 @@ Layout make_layout(size_t n_offsets, size_t n_states, size_t n_arcs) {
   o = align_up(o + n_states * sizeof(uint32_t));
   l.off_wn = o;
   o = align_up(o + n_arcs * sizeof(uint2));
+  l.off_srec = o;
+  o = align_up(o + n_states * sizeof(uint4));
   l.total = std::max<size_t>(o, ALIGN);
   return l;
 }
@@ -88,8 +94,9 @@ void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_
     derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(d.arcs, const_cast<uint2*>(d.wn), n_arcs, n_states, err.p);
   }
   if (n_states) {
-    derive_noeps_kernel<<<(n_states + 255) / 256, 256, 0, ctx->stream>>>(d.offsets, d.arcs, const_cast<uint32_t*>(d.noeps),
-                                                                        n_states, err.p);
+    derive_noeps_kernel<<<(n_states + 255) / 256, 256, 0, ctx->stream>>>(d.offsets, d.arcs, d.finals,
+                                                                        const_cast<uint32_t*>(d.noeps),
+                                                                        const_cast<uint4*>(d.srec), n_states, err.p);
   }
   HIP_CHECK(hipGetLastError());
   uint32_t* h = (uint32_t*)ctx->pinned.get(sizeof(uint32_t));
@@ -108,6 +115,7 @@ DeviceCsr carve(const std::shared_ptr<DeviceArena>& arena, const Layout& l) {
   d.finals = (const float*)(b + l.off_finals);
   d.noeps = (const uint32_t*)(b + l.off_noeps);
   d.wn = (const uint2*)(b + l.off_wn);
+  d.srec = (const uint4*)(b + l.off_srec);
   return d;
 }
 
@@ -222,8 +230,9 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
     for (size_t i = 0; i < n; ++i) {
       if (!n_states[i]) continue;
       derive_noeps_kernel<<<(n_states[i] + 255) / 256, 256, 0, ctx->stream>>>(
-          all.offsets + state_base[i] + i, all.arcs + arc_base[i], const_cast<uint32_t*>(all.noeps) + state_base[i],
-          n_states[i], err.p);
+          all.offsets + state_base[i] + i, all.arcs + arc_base[i], all.finals + state_base[i],
+          const_cast<uint32_t*>(all.noeps) + state_base[i], const_cast<uint4*>(all.srec) + state_base[i], n_states[i],
+          err.p);
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -241,6 +250,7 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
     f->dev.finals = all.finals + state_base[i];
     f->dev.noeps = all.noeps + state_base[i];
     f->dev.wn = all.wn + arc_base[i];
+    f->dev.srec = all.srec + state_base[i];
     f->has_dev = true;
     outs[i] = f.release();
   }
