@@ -152,6 +152,13 @@ def main():
                     "algorithmic_bytes_per_launch": round(algo_bytes / max(1, st["relax_launches"]), 1),
                     "arcs_relaxed": int(st["relax_arcs"]), "frontier_states": int(st["relax_states"]),
                     "relax_arcs_per_s": round(st["relax_arcs"] / (st["relax_ms"] * 1e-3), 1),
+                    # SURVEY §8(d)/BASELINE.md per-SOLVE accounting: every arc of T counted once (20 E + 12 N bytes)
+                    # over the summed relaxation-kernel time of the solve; rewards relaxing FEWER arcs
+                    "solve_algorithmic_bytes": 20 * e_t + 12 * args.states,
+                    "solve_relax_kernel_ms": round(st["relax_ms"], 4),
+                    "solve_achieved": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9, 2),
+                    "solve_frac": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "re_relaxation_factor": round(st["relax_arcs"] / max(1, e_t), 3),
                 }
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle

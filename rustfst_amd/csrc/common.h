@@ -143,6 +143,9 @@ struct wfst_fst {
   int64_t start = -1;
   uint64_t props = 0;
   bool has_host = false, has_dev = false;
+  // arc-weight statistics gathered at upload (steer the near-far schedule of the relaxation)
+  float mean_weight = 0.0f;   // mean of the finite arc weights
+  bool has_negative = false;  // some arc weight < 0
   HostCsr host;
   DeviceCsr dev;
 };

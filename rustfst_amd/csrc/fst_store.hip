@@ -16,18 +16,44 @@ namespace {
 constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 
-// one thread per arc: pack {w,next}; validate nextstate
+struct WeightStats {
+  double sum;                // sum of the finite arc weights
+  unsigned long long count;  // number of finite arc weights
+  uint32_t negative;         // some weight < 0
+  uint32_t pad;
+};
+
+// one thread per arc: pack {w,next}; validate nextstate; accumulate weight statistics
 __global__ void derive_wn_kernel(const wfst_tr* __restrict__ arcs, uint2* __restrict__ wn, uint64_t n_arcs,
-                                 uint32_t n_states_max, uint32_t* __restrict__ err) {
+                                 uint32_t n_states_max, uint32_t* __restrict__ err, WeightStats* __restrict__ ws) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  bool bad = false;
+  bool bad = false, neg = false;
+  double sum = 0.0;
+  unsigned long long cnt = 0;
   for (; i < n_arcs; i += stride) {
     const uint4 a = reinterpret_cast<const uint4*>(arcs)[i];  // one 16-B load per arc
     wn[i] = make_uint2(a.z, a.w);
     bad |= a.w >= n_states_max;
+    const float w = __uint_as_float(a.z);
+    if (w < INF && w > -INF) {
+      sum += (double)w;
+      cnt++;
+      neg |= w < 0.0f;
+    }
   }
   if (bad) atomicOr(err, 1u);
+  if (ws) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      sum += __shfl_xor(sum, d);
+      cnt += __shfl_xor(cnt, d);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+      atomicAdd(&ws->sum, sum);
+      atomicAdd(&ws->count, cnt);
+    }
+    if (neg) ws->negative = 1u;
+  }
 }
 
 // one thread per state (of the concatenation): count olabel == 0 arcs; validate offsets.
@@ -86,12 +112,15 @@ void check_header(uint32_t n_states, int64_t start) {
 }
 
 // Runs the derive kernels for a single FST laid out at `l` in `arena` and validates it.
-void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_t n_arcs) {
+void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_t n_arcs, float* mean_weight,
+                   bool* has_negative) {
   DBuf<uint32_t> err(*ctx->pool, 1);
+  DBuf<WeightStats> ws(*ctx->pool, 1);
   HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), ctx->stream));
+  HIP_CHECK(hipMemsetAsync(ws.p, 0, sizeof(WeightStats), ctx->stream));
   if (n_arcs) {
     int blocks = (int)std::min<uint64_t>((n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
-    derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(d.arcs, const_cast<uint2*>(d.wn), n_arcs, n_states, err.p);
+    derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(d.arcs, const_cast<uint2*>(d.wn), n_arcs, n_states, err.p, ws.p);
   }
   if (n_states) {
     derive_noeps_kernel<<<(n_states + 255) / 256, 256, 0, ctx->stream>>>(d.offsets, d.arcs, d.finals,
@@ -99,11 +128,15 @@ void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_
                                                                         const_cast<uint4*>(d.srec), n_states, err.p);
   }
   HIP_CHECK(hipGetLastError());
-  uint32_t* h = (uint32_t*)ctx->pinned.get(sizeof(uint32_t));
+  uint32_t* h = (uint32_t*)ctx->pinned.get(64 + sizeof(WeightStats));
+  WeightStats* hws = (WeightStats*)((char*)h + 64);
   HIP_CHECK(hipMemcpyAsync(h, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(hws, ws.p, sizeof(WeightStats), hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (*h & 1u) throw Error("invalid FST: an arc's nextstate is >= num_states");
   if (*h & 2u) throw Error("invalid FST: offsets are not non-decreasing");
+  *mean_weight = hws->count ? (float)(hws->sum / (double)hws->count) : 0.0f;
+  *has_negative = hws->negative != 0;
 }
 
 DeviceCsr carve(const std::shared_ptr<DeviceArena>& arena, const Layout& l) {
@@ -149,8 +182,12 @@ static wfst_fst* upload_generic(wfst_ctx* ctx, uint32_t n_states, int64_t start,
     HIP_CHECK(hipMemsetAsync(const_cast<uint32_t*>(d.offsets), 0, sizeof(uint32_t), ctx->stream));
   }
   if (n_arcs) HIP_CHECK(hipMemcpyAsync(const_cast<wfst_tr*>(d.arcs), arcs, n_arcs * sizeof(wfst_tr), kind, ctx->stream));
-  derive_single(ctx, d, n_states, n_arcs);
+  float mean_w = 0.0f;
+  bool has_neg = false;
+  derive_single(ctx, d, n_states, n_arcs, &mean_w, &has_neg);
   auto f = std::make_unique<wfst_fst>();
+  f->mean_weight = mean_w;
+  f->has_negative = has_neg;
   f->ctx = ctx;
   f->n_states = n_states;
   f->n_arcs = n_arcs;
@@ -224,7 +261,8 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
     HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), ctx->stream));
     if (tot_arcs) {
       int blocks = (int)std::min<uint64_t>((tot_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
-      derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(all.arcs, const_cast<uint2*>(all.wn), tot_arcs, 0xFFFFFFFFu, err.p);
+      derive_wn_kernel<<<blocks, 256, 0, ctx->stream>>>(all.arcs, const_cast<uint2*>(all.wn), tot_arcs, 0xFFFFFFFFu, err.p,
+                                                        nullptr);
     }
     // noeps: per FST the offsets are relative, so run per FST on its slice (tiny launches; upload path only)
     for (size_t i = 0; i < n; ++i) {
@@ -263,6 +301,8 @@ void ensure_device(wfst_fst* f) {
   std::unique_ptr<wfst_fst> tmp(upload_from_host(ctx, f->n_states, f->start, f->host.offsets.data(), f->host.arcs.data(),
                                                  f->host.finals.data(), f->props));
   f->dev = tmp->dev;
+  f->mean_weight = tmp->mean_weight;
+  f->has_negative = tmp->has_negative;
   f->has_dev = true;
 }
 

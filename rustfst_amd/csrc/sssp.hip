@@ -12,6 +12,8 @@
 // smallest (source state, arc position) predecessor, then the smallest final state id.
 // No MFMA: this is sparse DP; the bound is HBM / L2-atomic traffic (20 B per arc relaxed by the
 // SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
+#include <cstdlib>
+
 #include "common.h"
 #include "fst_props.h"
 
@@ -31,7 +33,17 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
   return __uint_as_float(b);
 }
 
+// Near-far schedule (a Delta-stepping relative that needs no buckets): sweep k only relaxes active states
+// with d <= tau_k; the others stay in the frontier.  When a sweep activates nothing near, tau advances by
+// delta (doubling on consecutive empty sweeps so that gaps are crossed in log time).  All of it is decided on
+// the device from three words per sweep kept in a ring, so sweeps still launch back-to-back without a host
+// round trip, and without any same-address atomics (one conditional plain store per workgroup).
+constexpr uint32_t RING = 256;
+
 struct Ctl {
+  uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
+  uint32_t near[RING];    // sweep k activated at least one state with d <= tau_k
+  uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
   unsigned long long arcs;    // arcs leaving the current frontier (profiling only)
   unsigned long long states;  // frontier states (profiling only)
   unsigned long long best;    // enc(total) << 32 | final state
@@ -41,9 +53,27 @@ struct Ctl {
   uint32_t has_path, pad;
 };
 
+// threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
+__device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t* streak) {
+  *streak = 0;
+  if (sweep == 0) return delta;
+  const uint32_t p = (sweep - 1) % RING;
+  const float prev = __uint_as_float(ctl->tau[p]);
+  if (ctl->near[p]) return prev;
+  const uint32_t st = min(ctl->streak[p] + 1u, 30u);
+  *streak = st;
+  return prev + delta * (float)(1u << (st - 1u));
+}
+
 __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start) {
   key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
   flags0[start] = 1;
+  for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
+    ctl->tau[i] = 0;
+    ctl->near[i] = 0;
+    ctl->streak[i] = 0;
+  }
+  if (threadIdx.x) return;
   ctl->arcs = 0;
   ctl->states = 0;
   ctl->best = KEY_INF;
@@ -59,7 +89,20 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          const uint2* __restrict__ wn, uint64_t* __restrict__ key,
                                                          uint8_t* __restrict__ flags_cur,
                                                          uint8_t* __restrict__ flags_next, uint32_t n,
-                                                         uint32_t* __restrict__ improved) {
+                                                         uint32_t* __restrict__ improved, Ctl* __restrict__ ctl,
+                                                         uint32_t sweep, float delta) {
+  __shared__ uint32_t s_bits;  // bit 0: some activity (improvement or deferral), bit 1: a near activation
+  uint32_t streak;
+  const float tau = sweep_tau(ctl, sweep, delta, &streak);
+  const uint32_t slot = sweep % RING;
+  if (threadIdx.x == 0) s_bits = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->tau[slot] = __float_as_uint(tau);
+    ctl->streak[slot] = streak;
+    ctl->near[(sweep + 1) % RING] = 0;  // recycle the slot the next sweep will fill
+  }
+  __syncthreads();
+  bool near_any = false;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = lane % GROUP;         // lane inside its group
   const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
@@ -68,10 +111,18 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   bool any = false;
   for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
     const uint32_t sc = base + lane;
-    const bool act = sc < n && flags_cur[sc] != 0;
+    bool act = sc < n && flags_cur[sc] != 0;
+    if (__ballot(act) == 0) continue;
+    if (act) {
+      flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
+      const uint32_t ed = (uint32_t)(key[sc] >> 32);
+      if (dec_f32(ed) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
+        flags_next[sc] = 1;
+        any = true;
+        act = false;
+      }
+    }
     uint64_t mask = __ballot(act);
-    if (mask == 0) continue;
-    if (act) flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
     while (mask) {
       // the wave's 4 groups take the 4 lowest set bits
       const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
@@ -94,21 +145,34 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
           if (ck < old) {
             flags_next[t] = 1;
             any = true;
+            near_any |= c <= tau;
           }
         }
       }
     }
   }
-  if (any) *improved = 1u;
+  // one conditional plain store per workgroup (thousands of same-address stores/atomics per sweep would
+  // serialise at ~12 ns each)
+  const uint32_t bits = (__any(any) ? 1u : 0u) | (__any(near_any) ? 2u : 0u);
+  if (lane == 0 && bits) atomicOr(&s_bits, bits);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t b = s_bits;
+    if ((b & 1u) && *improved == 0u) *improved = 1u;
+    if ((b & 2u) && ctl->near[slot] == 0u) ctl->near[slot] = 1u;
+  }
 }
 
 // profiling helper (runs outside the timed events): size of the current frontier and of its arc set
-__global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags, uint32_t n,
-                                  Ctl* __restrict__ ctl) {
+__global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags,
+                                  const uint64_t* __restrict__ key, uint32_t n, Ctl* __restrict__ ctl, uint32_t sweep,
+                                  float delta) {
+  uint32_t streak_unused;
+  const float tau = sweep_tau(ctl, sweep, delta, &streak_unused);
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long arcs = 0, states = 0;
   for (; s < n; s += gridDim.x * blockDim.x)
-    if (flags[s]) {
+    if (flags[s] && dec_f32((uint32_t)(key[s] >> 32)) <= tau) {
       arcs += offsets[s + 1] - offsets[s];
       states += 1;
     }
@@ -232,25 +296,32 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
   HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * (size_t)n, st));
   uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n};
-  sssp_init_kernel<<<1, 1, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
+  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
   uint32_t* h_imp = (uint32_t*)ctx->pinned.get(MAX_BATCH * sizeof(uint32_t) + sizeof(Ctl));
   Ctl* h_ctl = (Ctl*)(h_imp + MAX_BATCH);
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
+  // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
+  // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
+  float delta = INF;
+  if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) delta = 1.5f * f->mean_weight;
+  if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
+  if (!(delta > 0.0f)) delta = INF;
   uint32_t sweep = 0;
   uint32_t batch = ctx->profiling ? 1 : 8;
   bool done = false;
   ctx->stats.sweeps = 0;
   while (!done) {
-    if (sweep > n + 1) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+    if (sweep > 4ull * n + 64) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
     HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, batch * sizeof(uint32_t), st));
     for (uint32_t k = 0; k < batch; ++k) {
       uint8_t* fc = fl[(sweep + k) & 1u];
       uint8_t* fn = fl[((sweep + k) & 1u) ^ 1u];
       if (ctx->profiling) {
-        sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fc, n, sv.ctl.p);
+        sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fc, sv.key.p, n, sv.ctl.p, sweep + k, delta);
         HIP_CHECK(hipEventRecord(ctx->ev0, st));
       }
-      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fc, fn, n, sv.improved.p + k);
+      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fc, fn, n, sv.improved.p + k,
+                                                sv.ctl.p, sweep + k, delta);
       if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
     }
     HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

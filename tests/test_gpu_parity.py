@@ -413,3 +413,22 @@ def test_config3_properties_1m_states(gpu_ctx, oracle):
         if i < 2:
             can = to_oracle(oracle, a).compose(ot).shortest_path_canonical()
             assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")
+
+
+@pytest.mark.parametrize("delta", ["0", "0.7", "3", "1000"])
+def test_near_far_schedule_does_not_change_results(oracle, delta):
+    """The near-far threshold schedule only reorders relaxations: distances, hops and the path are the
+    fixed point regardless of delta (0 = plain frontier sweeps)."""
+    os.environ["WFST_SSSP_DELTA"] = delta
+    try:
+        ctx = rustfst_amd.Context(0)
+        for n, fan, seed in ((20_000, 8, 1), (3_000, 20, 2)):
+            t = synth.make_transducer(n, fan, 64, 0.02, seed=seed)
+            d = to_device(t, ctx)
+            dist, hops = d.shortest_distance(want_hops=True)
+            can = to_oracle(oracle, t).shortest_path_canonical()
+            np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+            np.testing.assert_array_equal(hops, can.hops)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"delta={delta} n={n}")
+    finally:
+        del os.environ["WFST_SSSP_DELTA"]
