@@ -117,8 +117,11 @@ wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fs
  *      (rustfst-ffi/src/algorithms/shortest_path.rs:44-83) = rustfst::algorithms::shortest_path
  *      (rustfst/src/algorithms/shortest_path.rs:76-133).  cfg == NULL means
  *      ShortestPathConfig::default() = {delta 1e-6, nshortest 1, unique false} (:31-39).
- *      nshortest == 0 -> empty FST (:118-120); nshortest == 1 on the GPU; nshortest > 1 or unique
- *      -> KO "unsupported".  Output: linear FST numbered backwards, state 0 final (:241-282). ---- */
+ *      nshortest == 0 -> empty FST (:118-120).  nshortest == 1 (unique ignored, as in the reference):
+ *      relaxation + backtrace on the GPU; output = linear FST numbered backwards, state 0 final (:241-282).
+ *      nshortest > 1, unique = false (:135-170): shortest_distance and reverse() on the GPU, the sequential
+ *      n_shortest_path heap search (:409-518) + connect on the host; output = the reference's path tree.
+ *      nshortest > 1 with unique = true (needs determinize) -> KO "unsupported". ---- */
 typedef struct {
   float delta;
   uint64_t nshortest;

@@ -1109,6 +1109,228 @@ bool backtrace(const Fst& ifst, bool has_f_parent, uint32_t f_parent, const std:
   return true;
 }
 
+// ---------------------------------------------------------------- shortest_distance (B4)
+// ShortestDistanceState::shortest_distance with AutoQueue::new(fst, None, AnyTrFilter), first_path = false,
+// retain = false — shortest_distance.rs:153-237,313-335.  Convergence test is approx_equal(delta), not ==.
+inline bool approx_equal(float a, float b, float delta) { return std::fabs(a - b) <= delta; }  // utils_float.rs:1-3
+
+std::vector<float> shortest_distance_impl(const Fst& fst, float delta) {
+  std::vector<float> distance, adder, radder;
+  std::vector<bool> enqueued;
+  if (!fst.has_start) return distance;
+  std::unique_ptr<Queue> queue = auto_queue_new(fst);
+  queue->clear();
+  auto ensure = [&](size_t index) {
+    while (distance.size() <= index) {
+      distance.push_back(INF);
+      enqueued.push_back(false);
+      adder.push_back(INF);
+      radder.push_back(INF);
+    }
+  };
+  const size_t source = fst.start;
+  ensure(source);
+  distance[source] = 0.0f;
+  adder[source] = 0.0f;
+  radder[source] = 0.0f;
+  enqueued[source] = true;
+  queue->enqueue((uint32_t)source);
+  uint32_t st;
+  while (queue->dequeue(&st)) {
+    const size_t state = st;
+    enqueued[state] = false;
+    const float r = radder[state];
+    radder[state] = INF;
+    for (const Tr& tr : fst.states[state].trs) {
+      const size_t nextstate = tr.nextstate;
+      ensure(nextstate);
+      const float weight = wtimes(r, tr.weight);
+      if (!approx_equal(distance[nextstate], wplus(distance[nextstate], weight), delta)) {
+        adder[nextstate] = wplus(adder[nextstate], weight);
+        distance[nextstate] = adder[nextstate];
+        radder[nextstate] = wplus(radder[nextstate], weight);
+        if (!enqueued[state]) {  // (sic) the reference tests enqueued[state], shortest_distance.rs:224
+          queue->enqueue((uint32_t)nextstate);
+          enqueued[nextstate] = true;
+        } else {
+          queue->update((uint32_t)nextstate);
+        }
+      }
+    }
+  }
+  return distance;
+}
+
+// ---------------------------------------------------------------- reverse (B5) — reverse.rs:33-87
+// mutate_properties.rs:622-638
+inline uint64_t reverse_properties(uint64_t in, bool has_superinitial) {
+  uint64_t out = (P::ACCEPTOR | P::NOT_ACCEPTOR | P::EPSILONS | P::I_EPSILONS | P::O_EPSILONS | P::UNWEIGHTED | P::CYCLIC |
+                  P::ACYCLIC | P::WEIGHTED_CYCLES | P::UNWEIGHTED_CYCLES) & in;
+  if (has_superinitial) out |= P::WEIGHTED & in;
+  return out;
+}
+void reverse_impl(const Fst& ifst, Fst& ofst) {
+  ofst = Fst();
+  const uint32_t ostart = ofst.add_state();
+  ofst.add_states(ifst.num_states());
+  std::vector<std::vector<Tr>> states_trs(ifst.num_states() + 1);
+  for (size_t is = 0; is < ifst.num_states(); ++is) {
+    const uint32_t os = (uint32_t)is + 1;
+    if (ifst.has_start && ifst.start == is) ofst.set_final(os, 0.0f);
+    const State& st = ifst.states[is];
+    if (st.has_final) states_trs[0].push_back(Tr{EPS_LABEL, EPS_LABEL, st.final_w, os});
+    for (const Tr& itr : st.trs) states_trs[(size_t)itr.nextstate + 1].push_back(Tr{itr.ilabel, itr.olabel, itr.weight, os});
+  }
+  for (size_t s = 0; s < states_trs.size(); ++s) ofst.set_trs_unchecked((uint32_t)s, std::move(states_trs[s]));
+  ofst.set_start(ostart);
+  ofst.set_properties_with_mask(reverse_properties(ifst.properties, true) | ofst.properties, P::ALL);
+}
+
+// ---------------------------------------------------------------- n_shortest_path (B6) — shortest_path.rs:284-518
+inline bool natural_less(float w1, float w2) { return weq(wplus(w1, w2), w1) && !weq(w1, w2); }  // :284-286
+
+struct NPair {
+  bool some;  // Option<StateId>
+  uint32_t state;
+  float w;
+};
+struct NHeap {  // Heap :340-407 with ShortestPathCompare :288-338 as `less`
+  std::vector<uint32_t> data;
+  const std::vector<NPair>* pairs;
+  const std::vector<float>* distance;
+  float delta;
+  float pweight(const NPair& p) const {
+    if (!p.some) return 0.0f;
+    return p.state < distance->size() ? (*distance)[p.state] : INF;
+  }
+  bool less(uint32_t x, uint32_t y) const {
+    const NPair& px = (*pairs)[x];
+    const NPair& py = (*pairs)[y];
+    const float wx = wtimes(pweight(px), px.w);
+    const float wy = wtimes(pweight(py), py.w);
+    if (!px.some && py.some) return natural_less(wy, wx) || approx_equal(wx, wy, delta);
+    if (px.some && !py.some) return natural_less(wy, wx) && !approx_equal(wx, wy, delta);
+    return natural_less(wy, wx);
+  }
+  void sift_up(size_t idx) {
+    while (idx > 0) {
+      size_t parent = (idx - 1) / 2;
+      if (less(data[parent], data[idx])) {
+        std::swap(data[idx], data[parent]);
+        idx = parent;
+      } else {
+        break;
+      }
+    }
+  }
+  void push(uint32_t v) {
+    data.push_back(v);
+    sift_up(data.size() - 1);
+  }
+  void sift_down(size_t idx) {
+    for (;;) {
+      const uint32_t cur = data[idx];
+      const size_t c1 = 2 * idx + 1, c2 = 2 * idx + 2;
+      size_t big;
+      if (c1 >= data.size() && c2 >= data.size()) return;
+      if (c1 < data.size() && c2 >= data.size())
+        big = c1;
+      else if (less(data[c1], data[c2]))
+        big = c2;
+      else
+        big = c1;
+      if (!less(data[big], cur)) {
+        std::swap(data[idx], data[big]);
+        idx = big;
+      } else {
+        return;
+      }
+    }
+  }
+  uint32_t pop() {
+    const uint32_t top = data[0];
+    if (data.size() == 1) {
+      data.erase(data.begin());
+    } else {
+      data[0] = data.back();
+      data.pop_back();
+      sift_down(0);
+    }
+    return top;
+  }
+};
+
+// ifst = the reversed FST, distance indexed by its state ids.
+void n_shortest_path_impl(const Fst& ifst, const std::vector<float>& distance, size_t nshortest, float delta, Fst& ofst) {
+  ofst = Fst();
+  if (nshortest == 0) return;
+  if (!ifst.has_start || distance.size() <= ifst.start || wis_zero(distance[ifst.start])) return;
+  const uint32_t istart = ifst.start;
+  const uint32_t ostart = ofst.add_state();
+  ofst.set_start(ostart);
+  const uint32_t final_state = ofst.add_state();
+  ofst.set_final(final_state, 0.0f);
+  std::vector<NPair> pairs(final_state + 1, NPair{false, 0, INF});
+  pairs[final_state] = NPair{true, istart, 0.0f};
+  NHeap heap;
+  heap.pairs = &pairs;
+  heap.distance = &distance;
+  heap.delta = delta;
+  heap.push(final_state);
+  const float limit = wtimes(distance[istart], INF);  // weight_threshold = zero()
+  std::vector<size_t> r;
+  while (!heap.data.empty()) {
+    const uint32_t state = heap.pop();
+    const NPair p = pairs[state];
+    const int64_t p_first_real = (p.some ? (int64_t)p.state : -1) + 1;
+    const float d = p.some ? (p.state < distance.size() ? distance[p.state] : INF) : 0.0f;
+    if (natural_less(limit, wtimes(d, p.w))) continue;
+    while ((int64_t)r.size() <= p_first_real) r.push_back(0);
+    r[(size_t)p_first_real] += 1;
+    if (!p.some) ofst.add_tr(ofst.start, Tr{0, 0, 0.0f, state});
+    if (!p.some && r[(size_t)p_first_real] == nshortest) break;
+    if (r[(size_t)p_first_real] > nshortest) continue;
+    if (!p.some) continue;
+    for (const Tr& rarc : ifst.states[p.state].trs) {
+      Tr tr{rarc.ilabel, rarc.olabel, rarc.weight, rarc.nextstate};
+      const float weight = wtimes(p.w, tr.weight);
+      const uint32_t next = ofst.add_state();
+      pairs.push_back(NPair{true, tr.nextstate, weight});
+      tr.nextstate = state;
+      ofst.add_tr(next, tr);
+      heap.push(next);
+    }
+    const State& st = ifst.states[p.state];
+    if (st.has_final && !wis_zero(st.final_w)) {
+      const float weight = wtimes(p.w, st.final_w);
+      const uint32_t next = ofst.add_state();
+      pairs.push_back(NPair{false, 0, weight});
+      ofst.add_tr(next, Tr{0, 0, st.final_w, state});
+      heap.push(next);
+    }
+  }
+  connect_impl(ofst);
+  ofst.set_properties_with_mask(P::shortest_path_properties(ofst.properties, false), P::ALL);
+}
+
+// shortest_path_with_config, nshortest > 1, unique = false — shortest_path.rs:135-170
+bool shortest_path_n_impl(const Fst& ifst, size_t nshortest, float delta, Fst& out) {
+  std::vector<float> distance = shortest_distance_impl(ifst, delta);
+  Fst rfst;
+  reverse_impl(ifst, rfst);
+  float d = INF;
+  for (const Tr& rarc : rfst.states[0].trs) {
+    const uint32_t state = rarc.nextstate - 1;
+    if ((size_t)state < distance.size()) d = wplus(d, wtimes(rarc.weight, distance[state]));
+  }
+  std::vector<float> distance_2;
+  distance_2.reserve(distance.size() + 1);
+  distance_2.push_back(d);
+  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+  n_shortest_path_impl(rfst, distance_2, nshortest, delta, out);
+  return true;
+}
+
 // ---------------------------------------------------------------- canonical (deterministic-tie) shortest path
 struct Canon {
   std::vector<float> d;
@@ -1533,6 +1755,34 @@ int oracle_shortest_path_canonical(const oracle_fst* f, oracle_fst** out, float*
   if (hops) std::copy(c.h.begin(), c.h.end(), hops);
   if (total_weight) *total_weight = c.has_final ? c.total : INF;
   if (n_tied_choices) *n_tied_choices = canonical_count_ties(*f, c);
+  *out = res.release();
+  return 0;
+}
+
+int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out) {
+  DeltaGuard g(eq_mode);
+  auto res = std::make_unique<oracle_fst>();
+  if (nshortest == 0) {
+    *out = res.release();
+    return 0;
+  }
+  if (nshortest == 1) return oracle_shortest_path(f, eq_mode, out, nullptr, nullptr);
+  if (!shortest_path_n_impl(*f, (size_t)nshortest, delta, *res)) return 1;
+  *out = res.release();
+  return 0;
+}
+
+uint64_t oracle_shortest_distance(const oracle_fst* f, float delta, float* distance, uint64_t cap) {
+  DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  std::vector<float> d = shortest_distance_impl(*f, delta);
+  for (uint64_t i = 0; i < cap; ++i) distance[i] = i < d.size() ? d[i] : INF;
+  return d.size();
+}
+
+int oracle_reverse(const oracle_fst* f, oracle_fst** out) {
+  DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  auto res = std::make_unique<oracle_fst>();
+  reverse_impl(*f, *res);
   *out = res.release();
   return 0;
 }

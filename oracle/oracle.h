@@ -73,6 +73,14 @@ int oracle_connect(oracle_fst*);
  * Optional outputs (may be NULL): distance[n_states], total weight of the chosen path. */
 int oracle_shortest_path(const oracle_fst* f, int eq_mode, oracle_fst** out, float* distance,
                          float* total_weight);
+/* shortest_path_with_config(nshortest = n, unique = false): shortest_path.rs:107-170,284-518
+ * (shortest_distance.rs:153-237 + reverse.rs:33-87 + n_shortest_path heap search + connect). */
+int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out);
+/* shortest_distance_with_config(fst, reverse = false, delta): shortest_distance.rs:313-323.  Writes
+ * min(cap, len) values (unreached = +inf beyond the reference's shorter vector); returns the reference length. */
+uint64_t oracle_shortest_distance(const oracle_fst* f, float delta, float* distance, uint64_t cap);
+/* reverse(): reverse.rs:33-87 (super-initial state 0, state i -> i+1) */
+int oracle_reverse(const oracle_fst* f, oracle_fst** out);
 /* name of the queue discipline AutoQueue picked for the last oracle_shortest_path call on
  * this thread (queues/auto_queue.rs:23-99): "state_order","top_order","lifo","top_order_scc","scc" */
 const char* oracle_last_queue_kind(void);

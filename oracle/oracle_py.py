@@ -60,6 +60,10 @@ def lib():
         L.oracle_connect.argtypes = [vp]
         L.oracle_shortest_path.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.POINTER(f32)]
         L.oracle_shortest_path_canonical.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(f32), C.POINTER(u32)]
+        L.oracle_shortest_path_n.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
+        L.oracle_shortest_distance.argtypes = [vp, f32, vp, u64]
+        L.oracle_shortest_distance.restype = u64
+        L.oracle_reverse.argtypes = [vp, C.POINTER(vp)]
         L.oracle_bruteforce_min_weight.argtypes = [vp, u32]
         L.oracle_bruteforce_min_weight.restype = f32
         L.oracle_path_in_fst.argtypes = [vp, vp, C.POINTER(f32)]
@@ -189,6 +193,23 @@ class OracleFst:
         if want_distance:
             res.distance = dist
         return res
+
+    def shortest_path_n(self, nshortest, delta=1e-6, eq_mode=EQ_REF_KDELTA):
+        out = C.c_void_p()
+        if lib().oracle_shortest_path_n(self._h, nshortest, delta, eq_mode, C.byref(out)):
+            raise _err()
+        return OracleFst(out.value)
+
+    def shortest_distance(self, delta=1e-6):
+        n = self.num_states
+        dist = np.zeros(n, dtype=np.float32)
+        lib().oracle_shortest_distance(self._h, delta, dist.ctypes.data, n)
+        return dist
+
+    def reverse(self):
+        out = C.c_void_p()
+        lib().oracle_reverse(self._h, C.byref(out))
+        return OracleFst(out.value)
 
     def shortest_path_canonical(self):
         out = C.c_void_p()

@@ -258,9 +258,13 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
       return;
     }
     // nshortest == 1 returns before `unique` is looked at (shortest_path.rs:122-133)
-    if (c.nshortest != 1)
-      throw Error("unsupported: nshortest > 1 is not implemented on the GPU path; use the CPU path");
-    *out = shortest_path_n1(ctx, fst);
+    if (c.nshortest == 1) {
+      *out = shortest_path_n1(ctx, fst);
+      return;
+    }
+    if (c.unique)  // needs determinize_with_distance (shortest_path.rs:157-165): not on the GPU path
+      throw Error("unsupported: unique = true with nshortest > 1 is not implemented on the GPU path; use the CPU path");
+    *out = shortest_path_nbest(ctx, fst, c.nshortest, c.delta);
   });
 }
 

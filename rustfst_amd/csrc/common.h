@@ -148,6 +148,8 @@ struct wfst_fst {
   bool has_negative = false;  // some arc weight < 0
   HostCsr host;
   DeviceCsr dev;
+  // reverse(fst) (reverse.rs:33-87) as host CSR: built on the GPU on first use by the n>1 shortest-path search
+  std::shared_ptr<HostCsr> rev_host;
 };
 
 namespace wfst {
@@ -170,6 +172,8 @@ void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
 // sssp.hip
 wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
+// nshortest.hip
+wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
 // compose.hip
 wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect);
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,

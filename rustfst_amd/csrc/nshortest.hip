@@ -1,0 +1,360 @@
+// nshortest.hip — shortest_path_with_config for nshortest > 1, unique = false
+// (rustfst/src/algorithms/shortest_path.rs:135-170):
+//   1. distance = shortest_distance(ifst)           shortest_distance.rs:153-237   -> sssp.hip relaxation (GPU)
+//   2. rfst = reverse(ifst)                         reverse.rs:33-87               -> CSR transpose kernels below (GPU)
+//   3. d = (+) over rfst.trs(0) of w (x) distance   shortest_path.rs:143-153       -> host, O(#finals)
+//   4. n_shortest_path(rfst, [d]++distance, n)      shortest_path.rs:284-518       -> host: an inherently sequential
+//      best-first search (custom binary heap) that pops at most n times per state; it touches a few
+//      thousand arcs, so it runs on the host against the reversed CSR (downloaded once per FST handle).
+//   5. connect + shortest_path_properties(.., false)  shortest_path.rs:512-517     -> host, on the small result
+// Steps 3-5 keep the reference's TropicalWeight semantics verbatim (approximate ==, approx_equal(delta)):
+// they decide heap order and must not deviate.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "fst_props.h"
+
+namespace wfst {
+
+namespace {
+
+// ---------------------------------------------------------------- reverse(): counting sort by nextstate
+__global__ void rev_count_kernel(const wfst_tr* __restrict__ arcs, uint64_t n_arcs, uint32_t* __restrict__ counts) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_arcs; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&counts[arcs[i].nextstate], 1u);
+}
+// slot reservation in arbitrary order; the arc index is kept so that each target's segment can be put back
+// into (source state, arc position) order = the order reverse() pushes arcs (reverse.rs:62-67)
+__global__ void rev_place_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs, uint32_t n_states,
+                                 const uint32_t* __restrict__ roff, uint32_t* __restrict__ cursor,
+                                 uint2* __restrict__ tmp) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = tid & 15u;
+  for (uint32_t s = tid >> 4; s < n_states; s += (gridDim.x * blockDim.x) >> 4)
+    for (uint32_t i = offsets[s] + lane; i < offsets[s + 1]; i += 16) {
+      const uint32_t t = arcs[i].nextstate;
+      const uint32_t slot = roff[t] + atomicAdd(&cursor[t], 1u);
+      tmp[slot] = make_uint2(i, s);
+    }
+}
+// per target: sort the segment by arc index (insertion sort; segments are in-degree sized), emit reversed arcs
+__global__ void rev_emit_kernel(const wfst_tr* __restrict__ arcs, const uint32_t* __restrict__ roff, uint2* __restrict__ tmp,
+                                uint32_t n_states, wfst_tr* __restrict__ rarcs) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_states) return;
+  const uint32_t b = roff[t], e = roff[t + 1];
+  for (uint32_t i = b + 1; i < e; ++i) {
+    const uint2 v = tmp[i];
+    uint32_t j = i;
+    while (j > b && tmp[j - 1].x > v.x) {
+      tmp[j] = tmp[j - 1];
+      --j;
+    }
+    tmp[j] = v;
+  }
+  for (uint32_t i = b; i < e; ++i) {
+    const uint2 v = tmp[i];
+    wfst_tr a = arcs[v.x];
+    a.nextstate = v.y + 1;  // state i -> i + 1 (super-initial state 0)
+    rarcs[i] = a;
+  }
+}
+
+std::shared_ptr<HostCsr> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
+  ensure_device(const_cast<wfst_fst*>(f));
+  const uint32_t n = f->n_states;
+  const uint64_t E = f->n_arcs;
+  hipStream_t st = ctx->stream;
+  DevicePool& pool = *ctx->pool;
+  auto rev = std::make_shared<HostCsr>();
+  std::vector<uint32_t> counts(n + 1, 0);
+  std::vector<float> finals(n);
+  DBuf<uint32_t> d_counts(pool, (size_t)n + 1);
+  HIP_CHECK(hipMemsetAsync(d_counts.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
+  const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((E + 255) / 256, (uint64_t)ctx->n_cus * 8));
+  if (E) rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.arcs, E, d_counts.p);
+  HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (n) HIP_CHECK(hipMemcpyAsync(finals.data(), f->dev.finals, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  // device-side offsets of the in-arc segments (targets 0..n-1), exclusive scan on the host
+  std::vector<uint32_t> roff(n + 1);
+  uint64_t acc = 0;
+  for (uint32_t t = 0; t < n; ++t) {
+    roff[t] = (uint32_t)acc;
+    acc += counts[t];
+  }
+  roff[n] = (uint32_t)acc;
+  if (acc != E) throw Error("reverse: inconsistent arc count");
+  std::vector<wfst_tr> in_arcs(E);
+  if (E) {
+    DBuf<uint32_t> d_roff(pool, (size_t)n + 1), d_cursor(pool, n);
+    DBuf<uint2> d_tmp(pool, E);
+    DBuf<wfst_tr> d_rarcs(pool, E);
+    HIP_CHECK(hipMemcpyAsync(d_roff.p, roff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, (size_t)n * sizeof(uint32_t), st));
+    rev_place_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.arcs, n, d_roff.p, d_cursor.p, d_tmp.p);
+    rev_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.arcs, d_roff.p, d_tmp.p, n, d_rarcs.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(in_arcs.data(), d_rarcs.p, E * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  // assemble rfst: state 0 = super-initial with one eps:eps arc per final state, in state order (reverse.rs:56-60)
+  std::vector<wfst_tr> super;
+  for (uint32_t s = 0; s < n; ++s)
+    if (finals[s] != INF) super.push_back(wfst_tr{0u, 0u, finals[s], s + 1});
+  rev->offsets.resize((size_t)n + 2);
+  rev->offsets[0] = 0;
+  rev->offsets[1] = (uint32_t)super.size();
+  for (uint32_t t = 0; t < n; ++t) rev->offsets[t + 2] = rev->offsets[1] + roff[t + 1];
+  rev->arcs.reserve(super.size() + E);
+  rev->arcs.insert(rev->arcs.end(), super.begin(), super.end());
+  rev->arcs.insert(rev->arcs.end(), in_arcs.begin(), in_arcs.end());
+  rev->finals.assign((size_t)n + 1, INF);
+  if (f->start >= 0) rev->finals[(size_t)f->start + 1] = 0.0f;  // reverse.rs:53-55
+  return rev;
+}
+
+// ---------------------------------------------------------------- TropicalWeight with the reference's semantics
+inline float wplus(float a, float b) { return b < a ? b : a; }
+inline float wtimes(float a, float b) { return a == INF ? a : (b == INF ? b : a + b); }
+inline bool weq(float a, float b) { return props::approx_eq(a, b); }  // KDELTA (semiring.rs:159-168)
+inline bool approx_equal(float a, float b, float delta) { return std::fabs(a - b) <= delta; }
+inline bool natural_less(float w1, float w2) { return weq(wplus(w1, w2), w1) && !weq(w1, w2); }  // shortest_path.rs:284-286
+
+struct Pair {
+  bool some;
+  uint32_t state;
+  float w;
+};
+// Heap (:340-407) ordered by ShortestPathCompare (:288-338)
+struct Heap {
+  std::vector<uint32_t> data;
+  const std::vector<Pair>* pairs;
+  const std::vector<float>* distance;
+  float delta;
+  float pweight(const Pair& p) const {
+    if (!p.some) return 0.0f;
+    return p.state < distance->size() ? (*distance)[p.state] : INF;
+  }
+  bool less(uint32_t x, uint32_t y) const {
+    const Pair& px = (*pairs)[x];
+    const Pair& py = (*pairs)[y];
+    const float wx = wtimes(pweight(px), px.w);
+    const float wy = wtimes(pweight(py), py.w);
+    if (!px.some && py.some) return natural_less(wy, wx) || approx_equal(wx, wy, delta);
+    if (px.some && !py.some) return natural_less(wy, wx) && !approx_equal(wx, wy, delta);
+    return natural_less(wy, wx);
+  }
+  void push(uint32_t v) {
+    data.push_back(v);
+    size_t idx = data.size() - 1;
+    while (idx > 0) {
+      const size_t parent = (idx - 1) / 2;
+      if (!less(data[parent], data[idx])) break;
+      std::swap(data[idx], data[parent]);
+      idx = parent;
+    }
+  }
+  uint32_t pop() {
+    const uint32_t top = data[0];
+    if (data.size() == 1) {
+      data.clear();
+      return top;
+    }
+    data[0] = data.back();
+    data.pop_back();
+    size_t idx = 0;
+    for (;;) {
+      const uint32_t cur = data[idx];
+      const size_t c1 = 2 * idx + 1, c2 = 2 * idx + 2;
+      size_t big;
+      if (c1 >= data.size() && c2 >= data.size()) break;
+      if (c1 < data.size() && c2 >= data.size())
+        big = c1;
+      else if (less(data[c1], data[c2]))
+        big = c2;
+      else
+        big = c1;
+      if (less(data[big], cur)) break;
+      std::swap(data[idx], data[big]);
+      idx = big;
+    }
+    return top;
+  }
+};
+
+// small mutable output FST with the reference's property bookkeeping (mutable_fst.rs)
+struct OutFst {
+  struct St {
+    bool has_final = false;
+    float final_w = INF;
+    std::vector<wfst_tr> trs;
+  };
+  std::vector<St> states;
+  int64_t start = -1;
+  uint64_t p = props::NULL_PROPS;
+  uint32_t add_state() {
+    states.emplace_back();
+    p = props::add_state(p);
+    return (uint32_t)states.size() - 1;
+  }
+  void set_start(uint32_t s) {
+    start = s;
+    p = props::set_start(p);
+  }
+  void set_final(uint32_t s, float w) {
+    p = props::set_final(p, states[s].has_final ? &states[s].final_w : nullptr, &w);
+    states[s].has_final = true;
+    states[s].final_w = w;
+  }
+  void add_tr(uint32_t s, const wfst_tr& tr) {
+    states[s].trs.push_back(tr);
+    const size_t k = states[s].trs.size();
+    p = props::add_tr(p, s, states[s].trs.back(), k > 1 ? &states[s].trs[k - 2] : nullptr);
+  }
+  // connect (connect.rs:51-66): keep access & coaccess, stable renumbering (mutable_fst.rs:132-189)
+  void connect() {
+    const size_t n = states.size();
+    std::vector<uint8_t> access(n, 0), coaccess(n, 0);
+    std::vector<uint32_t> stack;
+    if (start >= 0) {
+      access[(size_t)start] = 1;
+      stack.push_back((uint32_t)start);
+      while (!stack.empty()) {
+        const uint32_t s = stack.back();
+        stack.pop_back();
+        for (const wfst_tr& tr : states[s].trs)
+          if (!access[tr.nextstate]) {
+            access[tr.nextstate] = 1;
+            stack.push_back(tr.nextstate);
+          }
+      }
+    }
+    std::vector<std::vector<uint32_t>> rev(n);
+    for (size_t s = 0; s < n; ++s)
+      for (const wfst_tr& tr : states[s].trs) rev[tr.nextstate].push_back((uint32_t)s);
+    for (size_t s = 0; s < n; ++s)
+      if (states[s].has_final) {
+        coaccess[s] = 1;
+        stack.push_back((uint32_t)s);
+      }
+    while (!stack.empty()) {
+      const uint32_t s = stack.back();
+      stack.pop_back();
+      for (uint32_t q : rev[s])
+        if (!coaccess[q]) {
+          coaccess[q] = 1;
+          stack.push_back(q);
+        }
+    }
+    std::vector<int64_t> new_id(n, -1);
+    size_t k = 0;
+    for (size_t s = 0; s < n; ++s)
+      if (access[s] && coaccess[s]) new_id[s] = (int64_t)k++;
+    std::vector<St> kept(k);
+    for (size_t s = 0; s < n; ++s) {
+      if (new_id[s] < 0) continue;
+      St& dst = kept[(size_t)new_id[s]];
+      dst.has_final = states[s].has_final;
+      dst.final_w = states[s].final_w;
+      for (const wfst_tr& tr : states[s].trs)
+        if (new_id[tr.nextstate] >= 0) {
+          wfst_tr t2 = tr;
+          t2.nextstate = (uint32_t)new_id[tr.nextstate];
+          dst.trs.push_back(t2);
+        }
+    }
+    states.swap(kept);
+    start = (start >= 0 && new_id[(size_t)start] >= 0) ? new_id[(size_t)start] : -1;
+    p = props::delete_states(p);
+    p = (p & ~(props::ACCESSIBLE | props::COACCESSIBLE)) | props::ACCESSIBLE | props::COACCESSIBLE;
+  }
+};
+
+}  // namespace
+
+wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta) {
+  OutFst ofst;
+  auto finish = [&]() {
+    HostCsr h;
+    h.offsets.push_back(0);
+    for (const OutFst::St& st : ofst.states) {
+      h.arcs.insert(h.arcs.end(), st.trs.begin(), st.trs.end());
+      h.offsets.push_back((uint32_t)h.arcs.size());
+      h.finals.push_back(st.has_final ? st.final_w : INF);
+    }
+    return make_host_fst(ctx, (uint32_t)ofst.states.size(), ofst.start, ofst.p, std::move(h));
+  };
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) return finish();  // shortest_distance -> [] ; istart check fails -> FO::new()
+  // 1. forward distances (GPU relaxation; exact fixed point == the reference's on grid weights)
+  std::vector<float> distance(n);
+  shortest_distance(ctx, f, distance.data(), nullptr);
+  // 2. reversed FST (GPU transpose, cached on the handle)
+  wfst_fst* mf = const_cast<wfst_fst*>(f);
+  if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
+  const HostCsr& r = *mf->rev_host;
+  // 3. distance of the super-initial state (shortest_path.rs:143-153)
+  float d = INF;
+  for (uint32_t i = r.offsets[0]; i < r.offsets[1]; ++i) {
+    const uint32_t state = r.arcs[i].nextstate - 1;
+    if (state < distance.size()) d = wplus(d, wtimes(r.arcs[i].weight, distance[state]));
+  }
+  std::vector<float> distance_2;
+  distance_2.reserve((size_t)n + 1);
+  distance_2.push_back(d);
+  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+  // 4. n_shortest_path(rfst, distance_2, nshortest, delta)   shortest_path.rs:409-518
+  const uint32_t istart = 0;  // rfst.start()
+  if (distance_2.size() <= istart || props::is_zero(distance_2[istart])) return finish();
+  const uint32_t ostart = ofst.add_state();
+  ofst.set_start(ostart);
+  const uint32_t final_state = ofst.add_state();
+  ofst.set_final(final_state, 0.0f);
+  std::vector<Pair> pairs(final_state + 1, Pair{false, 0, INF});
+  pairs[final_state] = Pair{true, istart, 0.0f};
+  Heap heap;
+  heap.pairs = &pairs;
+  heap.distance = &distance_2;
+  heap.delta = delta;
+  heap.push(final_state);
+  const float limit = wtimes(distance_2[istart], INF);
+  std::vector<uint64_t> rcount;
+  while (!heap.data.empty()) {
+    const uint32_t state = heap.pop();
+    const Pair p = pairs[state];
+    const int64_t p_first_real = (p.some ? (int64_t)p.state : -1) + 1;
+    const float dd = p.some ? (p.state < distance_2.size() ? distance_2[p.state] : INF) : 0.0f;
+    if (natural_less(limit, wtimes(dd, p.w))) continue;
+    while ((int64_t)rcount.size() <= p_first_real) rcount.push_back(0);
+    rcount[(size_t)p_first_real] += 1;
+    if (!p.some) ofst.add_tr((uint32_t)ofst.start, wfst_tr{0u, 0u, 0.0f, state});
+    if (!p.some && rcount[(size_t)p_first_real] == nshortest) break;
+    if (rcount[(size_t)p_first_real] > nshortest) continue;
+    if (!p.some) continue;
+    for (uint32_t i = r.offsets[p.state]; i < r.offsets[p.state + 1]; ++i) {
+      wfst_tr tr = r.arcs[i];
+      const float weight = wtimes(p.w, tr.weight);
+      const uint32_t next = ofst.add_state();
+      pairs.push_back(Pair{true, tr.nextstate, weight});
+      tr.nextstate = state;
+      ofst.add_tr(next, tr);
+      heap.push(next);
+    }
+    const float fw = r.finals[p.state];
+    if (fw != INF && !props::is_zero(fw)) {
+      const float weight = wtimes(p.w, fw);
+      const uint32_t next = ofst.add_state();
+      pairs.push_back(Pair{false, 0, weight});
+      ofst.add_tr(next, wfst_tr{0u, 0u, fw, state});
+      heap.push(next);
+    }
+  }
+  // 5. connect + property word (shortest_path.rs:512-517)
+  ofst.connect();
+  ofst.p = props::shortest_path(ofst.p, false) & props::ALL;
+  return finish();
+}
+
+}  // namespace wfst

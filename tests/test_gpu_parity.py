@@ -145,7 +145,7 @@ def test_error_behaviour(gpu_ctx):
     with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
         rustfst_amd.acceptor([1]).compose(rustfst_amd.acceptor([1]), ComposeConfig(ComposeFilter.MATCHFILTER))
     with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
-        rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=3))
+        rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=3, unique=True))
     assert rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=0)).num_states() == 0
     # invalid CSR is rejected at the boundary, not on the device
     with pytest.raises(rustfst_amd.WfstError, match="nextstate"):
@@ -432,3 +432,48 @@ def test_near_far_schedule_does_not_change_results(oracle, delta):
             assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"delta={delta} n={n}")
     finally:
         del os.environ["WFST_SSSP_DELTA"]
+
+
+# ------------------------------------------------------------------ n > 1 shortest paths (B4-B6)
+def test_nshortest_known_graph(gpu_ctx, oracle):
+    """The K2 graph (test_shortest_path.py:5-30) asked for 2 and 3 paths."""
+    g = golden("k2_shortest_path.json")
+    v = vbuild(g["fst"])
+    o = oracle.OracleFst()
+    for _ in range(4):
+        o.add_state()
+    o.set_start(0)
+    o.set_final(3, 2.0)
+    for s, il, ol, w, ns in g["fst"]["arcs"]:
+        o.add_tr(s, il, ol, w, ns)
+    for n in (2, 3, 7):
+        got = v.to_device().shortest_path(ShortestPathConfig(nshortest=n)).to_flat()
+        assert_flat_identical(got, o.shortest_path_n(n).to_flat(), f"K2 graph n={n}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed):
+    rng = np.random.default_rng(700 + seed)
+    flat = random_fst_flat(rng, int(rng.integers(3, 60)), 4, 5, p_eps_i=0.1, p_final=0.2, min_fanout=1,
+                           acyclic=bool(seed % 2))
+    for n in (2, 5):
+        exp = to_oracle(oracle, flat).shortest_path_n(n).to_flat()
+        got = to_device(flat).shortest_path(ShortestPathConfig(nshortest=n)).to_flat()
+        assert_flat_identical(got, exp, f"seed {seed} n={n}")
+
+
+def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle):
+    t = synth.make_transducer(20_000, 8, 64, 0.02, seed=5)
+    accs = synth.make_acceptors(t, 2, 40, seed0=1000)
+    dt, ot = to_device(t), to_oracle(oracle, t)
+    exp = ot.shortest_path_n(10).to_flat()
+    got = dt.shortest_path(ShortestPathConfig(nshortest=10)).to_flat()
+    assert_flat_identical(got, exp, "T n=10")
+    assert exp["n_states"] > 10
+    # BASELINE config 5 shape (without look-ahead): compose then 10 shortest paths
+    dc = to_device(accs[0]).compose(dt)
+    oc = to_oracle(oracle, accs[0]).compose(ot)
+    assert_flat_identical(dc.shortest_path(ShortestPathConfig(nshortest=10)).to_flat(), oc.shortest_path_n(10).to_flat(),
+                          "lattice n=10")
+    # reverse distance bookkeeping: asking twice reuses the cached transpose and gives the same answer
+    assert_flat_identical(dt.shortest_path(ShortestPathConfig(nshortest=10)).to_flat(), exp, "T n=10 again")

@@ -218,3 +218,56 @@ def test_queue_disciplines(oracle):
     sp = c.shortest_path()
     assert sp.queue_kind in ("top_order_scc", "scc")
     assert sp.num_states == 13
+
+
+# ---------------------------------------------------------------- n > 1 (shortest_distance + reverse + n_shortest_path)
+def all_path_weights(flat, max_len=12):
+    """weights of all successful paths of a small acyclic FST (left fold f32)."""
+    out = []
+    off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
+
+    def rec(s, acc, depth):
+        if np.isfinite(fin[s]):
+            out.append(float(np.float32(acc + fin[s])))
+        if depth == max_len:
+            return
+        for a in arcs[off[s]:off[s + 1]]:
+            rec(int(a["nextstate"]), np.float32(acc + a["weight"]), depth + 1)
+
+    if flat["start"] is not None:
+        rec(flat["start"], np.float32(0.0), 0)
+    return sorted(out)
+
+
+def tree_path_weights(flat):
+    """path weights of the tree-shaped n-shortest output."""
+    return all_path_weights(flat, max_len=64)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nshortest_weights_are_the_n_smallest(oracle, seed):
+    rng = np.random.default_rng(900 + seed)
+    flat = random_fst_flat(rng, int(rng.integers(3, 9)), 3, 4, p_final=0.4, acyclic=True, min_fanout=1)
+    f = to_oracle(oracle, flat)
+    brute = all_path_weights(flat)
+    for n in (1, 2, 4, 50):
+        out = f.shortest_path_n(n).to_flat()
+        got = tree_path_weights(out)
+        exp = brute[:n]
+        assert len(got) == len(exp), (n, got, exp)
+        np.testing.assert_allclose(got, exp, atol=1e-5)
+
+
+def test_shortest_distance_and_reverse(oracle):
+    rng = np.random.default_rng(31)
+    flat = random_fst_flat(rng, 40, 4, 5, p_final=0.2, min_fanout=1)
+    f = to_oracle(oracle, flat)
+    d = f.shortest_distance()
+    can = f.shortest_path_canonical()
+    np.testing.assert_array_equal(d, can.distance)  # grid weights: approx_equal(1e-6) == exact
+    r = f.reverse().to_flat()
+    assert r["n_states"] == flat["n_states"] + 1 and r["start"] == 0
+    n_final = int(np.isfinite(flat["finals"]).sum())
+    assert r["offsets"][1] == n_final and len(r["arcs"]) == len(flat["arcs"]) + n_final
+    rr = f.reverse().reverse().to_flat()  # reversing twice gives the language back (two extra states)
+    assert rr["n_states"] == flat["n_states"] + 2
