@@ -57,7 +57,9 @@ def main():
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # WFST_BENCH_FORCE_DIST=1 exercises the RCCL plumbing with a single rank (1-GPU boxes)
+    force_dist = os.environ.get("WFST_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if int(os.environ.get("WORLD_SIZE", "1")) != world:
             raise SystemExit("--gpus N must match WORLD_SIZE (launch with torch.distributed.run)")
@@ -87,14 +89,14 @@ def main():
         sp = dt.shortest_path()
         outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt)
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
-        if world > 1:
-            packed = wdist.pack_paths([o.to_flat() for o in outs], args.acc_len + 8)
+        if world > 1 or force_dist:
+            packed = wdist.pack_device_paths(outs, args.acc_len + 8)
             last["gathered"] = wdist.gather_paths(packed, world, device)
         return e_t + 2 * n_arcs
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -110,7 +112,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t_start
 
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -208,7 +210,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

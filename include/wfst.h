@@ -172,6 +172,11 @@ wfst_status wfst_vec_fst_to_device(wfst_ctx* ctx, const wfst_vec_fst* f, wfst_fs
 /* download + rebuild (add_states / set_start / set_trs_unchecked / set_final / set_properties) == the shim's output step */
 wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
 
+/* Packs n linear path FSTs (outputs of the calls above) into fixed-size records for one all-gather:
+ * record i = [n_arcs u32, final-weight bits u32, valid u32, 0] followed by max_arcs 16-byte arcs (zero padded),
+ * i.e. (4 + 4*max_arcs) u32 words.  KO if a path has more than max_arcs arcs or is not linear. */
+wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t max_arcs, uint32_t* out);
+
 /* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
 typedef struct {
   /* relaxation kernel (sssp_relax_*): launches, total device time from HIP events on ctx's stream,

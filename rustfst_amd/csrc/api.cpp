@@ -291,6 +291,30 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
   });
 }
 
+wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t max_arcs, uint32_t* out) {
+  return wrap([&] {
+    if ((n && !paths) || !out) throw Error("null pointer");
+    const size_t rec = 4 + 4 * (size_t)max_arcs;
+    std::memset(out, 0, n * rec * sizeof(uint32_t));
+    for (size_t i = 0; i < n; ++i) {
+      const wfst_fst* f = paths[i];
+      if (!f) throw Error("null path in batch");
+      ensure_host(f);
+      uint32_t* r = out + i * rec;
+      const float inf = INF;
+      std::memcpy(&r[1], &inf, 4);
+      if (f->n_states == 0) continue;
+      const uint64_t n_arcs = f->n_arcs;
+      if (n_arcs + 1 != f->n_states) throw Error("wfst_fst_pack_paths: not a linear path FST");
+      if (n_arcs > max_arcs) throw Error("wfst_fst_pack_paths: path longer than the record");
+      r[0] = (uint32_t)n_arcs;
+      std::memcpy(&r[1], &f->host.finals[0], 4);
+      r[2] = 1;
+      if (n_arcs) std::memcpy(&r[4], f->host.arcs.data(), n_arcs * sizeof(wfst_tr));
+    }
+  });
+}
+
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on) {
   return wrap([&] {
     if (!ctx) throw Error("null ctx");

@@ -35,6 +35,18 @@ def pack_paths(paths: Sequence[dict], max_arcs: int) -> np.ndarray:
     return out
 
 
+def pack_device_paths(paths, max_arcs: int) -> np.ndarray:
+    """Same record layout as pack_paths, filled by the library from DeviceFst path handles (one C call)."""
+    import ctypes as C
+
+    from . import _lib
+    n = len(paths)
+    out = np.zeros((n, 4 + 4 * max_arcs), dtype=np.uint32)
+    arr = (C.c_void_p * n)(*[p._h.value if isinstance(p._h, C.c_void_p) else p._h for p in paths])
+    _lib.check(_lib.lib().wfst_fst_pack_paths(arr, n, max_arcs, out.ctypes.data), "wfst_fst_pack_paths")
+    return out
+
+
 def unpack_paths(packed: np.ndarray) -> List[dict]:
     """Inverse of pack_paths (property words are not transported; they are a function of the path)."""
     res = []

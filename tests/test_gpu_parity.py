@@ -477,3 +477,20 @@ def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle):
                           "lattice n=10")
     # reverse distance bookkeeping: asking twice reuses the cached transpose and gives the same answer
     assert_flat_identical(dt.shortest_path(ShortestPathConfig(nshortest=10)).to_flat(), exp, "T n=10 again")
+
+
+def test_pack_paths_matches_python_packing(gpu_ctx, oracle):
+    from rustfst_amd import dist as wdist
+    t = synth.make_transducer(3000, 8, 32, 0.0, seed=9)
+    accs = synth.make_acceptors(t, 5, 20, seed0=50)
+    accs.append(synth.linear_acceptor_flat([1, 2, 3]))
+    outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs), to_device(t))
+    a = wdist.pack_device_paths(outs, 28)
+    b = wdist.pack_paths([o.to_flat() for o in outs], 28)
+    np.testing.assert_array_equal(a, b)
+    back = wdist.unpack_paths(a)
+    for o, u in zip(outs, back):
+        f = o.to_flat()
+        assert f["n_states"] == u["n_states"] and np.array_equal(f["arcs"], u["arcs"])
+    with pytest.raises(rustfst_amd.WfstError, match="longer"):
+        wdist.pack_device_paths(outs, 3)
