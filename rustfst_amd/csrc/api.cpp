@@ -144,6 +144,10 @@ wfst_status wfst_ctx_destroy(wfst_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& g : ctx->sweep_graph) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     ctx->pool.reset();

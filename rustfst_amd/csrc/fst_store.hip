@@ -44,13 +44,28 @@ __global__ void derive_wn_kernel(const wfst_tr* __restrict__ arcs, uint2* __rest
   }
   if (bad) atomicOr(err, 1u);
   if (ws) {
+    __shared__ double s_sum[4];
+    __shared__ unsigned long long s_cnt[4];
     for (int d = 32; d >= 1; d >>= 1) {
       sum += __shfl_xor(sum, d);
       cnt += __shfl_xor(cnt, d);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-      atomicAdd(&ws->sum, sum);
-      atomicAdd(&ws->count, cnt);
+    if ((threadIdx.x & 63) == 0) {
+      s_sum[threadIdx.x >> 6] = sum;
+      s_cnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one pair of atomics per workgroup (same-address atomics serialise)
+      double bs = 0.0;
+      unsigned long long bc = 0;
+      for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) {
+        bs += s_sum[w];
+        bc += s_cnt[w];
+      }
+      if (bc) {
+        atomicAdd(&ws->sum, bs);
+        atomicAdd(&ws->count, bc);
+      }
     }
     if (neg) ws->negative = 1u;
   }

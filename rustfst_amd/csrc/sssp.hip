@@ -21,6 +21,12 @@ namespace wfst {
 
 namespace {
 
+inline uint32_t __float_as_uint_host(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+
 constexpr uint64_t KEY_INF = ~0ull;
 constexpr uint32_t GROUP = 16;  // lanes cooperating on one frontier state (average fan-out ~10)
 
@@ -39,8 +45,11 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
 // the device from three words per sweep kept in a ring, so sweeps still launch back-to-back without a host
 // round trip, and without any same-address atomics (one conditional plain store per workgroup).
 constexpr uint32_t RING = 256;
+constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, indexed by sweep % IMP_RING
 
 struct Ctl {
+  uint32_t base;          // first sweep index of the batch being replayed (graph nodes add their static offset)
+  uint32_t pad0;
   uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
   uint32_t near[RING];    // sweep k activated at least one state with d <= tau_k
   uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
@@ -74,6 +83,7 @@ __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint3
     ctl->streak[i] = 0;
   }
   if (threadIdx.x) return;
+  ctl->base = 0;
   ctl->arcs = 0;
   ctl->states = 0;
   ctl->best = KEY_INF;
@@ -89,8 +99,11 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          const uint2* __restrict__ wn, uint64_t* __restrict__ key,
                                                          uint8_t* __restrict__ flags_cur,
                                                          uint8_t* __restrict__ flags_next, uint32_t n,
-                                                         uint32_t* __restrict__ improved, Ctl* __restrict__ ctl,
-                                                         uint32_t sweep, float delta) {
+                                                         uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
+                                                         uint32_t sweep_offset, float delta) {
+  // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
+  const uint32_t sweep = ctl->base + sweep_offset;
+  uint32_t* improved = improved_ring + (sweep % IMP_RING);
   __shared__ uint32_t s_bits;  // bit 0: some activity (improvement or deferral), bit 1: a near activation
   uint32_t streak;
   const float tau = sweep_tau(ctl, sweep, delta, &streak);
@@ -163,6 +176,14 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   }
 }
 
+// closes a batch: the next replay continues at base + count, and the flag slots half a ring ahead are recycled
+__global__ void sssp_advance_kernel(Ctl* ctl, uint32_t* improved_ring, uint32_t count) {
+  const uint32_t base = ctl->base;
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) ctl->base = base + count;
+}
+
 // profiling helper (runs outside the timed events): size of the current frontier and of its arc set
 __global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags,
                                   const uint64_t* __restrict__ key, uint32_t n, Ctl* __restrict__ ctl, uint32_t sweep,
@@ -199,11 +220,13 @@ __global__ void sssp_final_kernel(const float* __restrict__ finals, const uint64
     const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | s;
     best = c < best ? c : best;
   }
-  for (int d = 32; d >= 1; d >>= 1) {  // one atomic per wave instead of one per final state
+  for (int d = 32; d >= 1; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d);
     best = o < best ? o : best;
   }
-  if ((threadIdx.x & 63) == 0 && best != KEY_INF) atomicMin(&ctl->best, best);
+  // few atomics on the single result word: only waves that can still lower it try (same-address atomics cost ~12 ns each)
+  if ((threadIdx.x & 63) == 0 && best != KEY_INF && best < __hip_atomic_load(&ctl->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMin(&ctl->best, best);
 }
 
 // parent[t] = min (s,pos) over arcs with (d[s]+w, hops[s]+1) == (d[t], hops[t])
@@ -283,22 +306,23 @@ struct Solve {
 constexpr uint32_t MAX_BATCH = 64;
 
 // Runs the relaxation to its fixed point. f must have a device copy and a start state.
-// Sweeps are launched in batches without returning to the host; a sweep that improves nothing leaves an
-// empty frontier, so the rest of its batch are no-ops and the host stops at the first zero flag.
+// Sweeps are launched in batches without returning to the host, and the NEXT batch is enqueued before the
+// host looks at the previous batch's flags (two batches in flight), so the device never idles on a host round
+// trip.  A sweep that changes nothing leaves an empty frontier: everything enqueued behind it is a ~3 us no-op.
 void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   const uint32_t n = f->n_states;
   DevicePool& pool = *ctx->pool;
   sv.key = DBuf<uint64_t>(pool, n);
-  sv.flags = DBuf<uint8_t>(pool, 2 * (size_t)n);
-  sv.improved = DBuf<uint32_t>(pool, MAX_BATCH);
+  const size_t n_pad = ((size_t)n + 15) & ~(size_t)15;
+  sv.flags = DBuf<uint8_t>(pool, 2 * n_pad);
+  sv.improved = DBuf<uint32_t>(pool, IMP_RING);
   sv.ctl = DBuf<Ctl>(pool, 1);
   hipStream_t st = ctx->stream;
   HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
-  HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * (size_t)n, st));
-  uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n};
+  HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
+  HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
+  uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n_pad};
   sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
-  uint32_t* h_imp = (uint32_t*)ctx->pinned.get(MAX_BATCH * sizeof(uint32_t) + sizeof(Ctl));
-  Ctl* h_ctl = (Ctl*)(h_imp + MAX_BATCH);
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
   // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
@@ -306,50 +330,98 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) delta = 1.5f * f->mean_weight;
   if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
   if (!(delta > 0.0f)) delta = INF;
-  uint32_t sweep = 0;
-  uint32_t batch = ctx->profiling ? 1 : 8;
-  bool done = false;
+  const uint64_t sweep_cap = 4ull * n + 64;
   ctx->stats.sweeps = 0;
-  while (!done) {
-    if (sweep > 4ull * n + 64) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
-    HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, batch * sizeof(uint32_t), st));
-    for (uint32_t k = 0; k < batch; ++k) {
-      uint8_t* fc = fl[(sweep + k) & 1u];
-      uint8_t* fn = fl[((sweep + k) & 1u) ^ 1u];
-      if (ctx->profiling) {
-        sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fc, sv.key.p, n, sv.ctl.p, sweep + k, delta);
-        HIP_CHECK(hipEventRecord(ctx->ev0, st));
-      }
-      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fc, fn, n, sv.improved.p + k,
-                                                sv.ctl.p, sweep + k, delta);
-      if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
-    }
-    HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (ctx->profiling) {
+
+  uint32_t sweeps_done = 0;
+  if (ctx->profiling) {
+    // one sweep at a time, bracketed by events; a counting kernel (outside the events) sizes the frontier
+    uint32_t* h_imp = (uint32_t*)ctx->pinned.get(64 + sizeof(Ctl));
+    Ctl* h_ctl = (Ctl*)((char*)h_imp + 64);
+    for (uint32_t k = 0;; ++k) {
+      if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+      sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta);
+      HIP_CHECK(hipEventRecord(ctx->ev0, st));
+      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
+                                                sv.improved.p, sv.ctl.p, 0u, delta);
+      HIP_CHECK(hipEventRecord(ctx->ev1, st));
+      sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u);
+      HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
       ctx->stats.relax_ms += ms;
       ctx->stats.relax_launches += 1;
+      sweeps_done = k + 1;
+      if (!h_imp[0]) break;
     }
-    for (uint32_t k = 0; k < batch; ++k) {
-      sweep++;
-      if (!h_imp[k]) {
-        done = true;
-        break;
-      }
-    }
-    // constant small batches while the solve is shallow (few wasted no-op launches), larger ones for deep lattices
-    batch = ctx->profiling ? 1 : (sweep >= 64 ? MAX_BATCH : 8);
-  }
-  sv.sweeps = sweep;
-  ctx->stats.sweeps = sweep;
-  if (ctx->profiling) {
     HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     ctx->stats.relax_arcs += h_ctl->arcs;
     ctx->stats.relax_states += h_ctl->states;
+  } else {
+    // One HIP graph = one batch: `count` sweep launches (static offsets 0..count-1 from the device-side base),
+    // the advance kernel, and the copy of the flag ring to pinned host memory.  Replaying a graph costs one
+    // host call instead of count+2 (a lone sweep on a small frontier takes ~4 us, less than a launch).
+    uint32_t* h_imp = (uint32_t*)ctx->pinned_flags.get(2 * IMP_RING * sizeof(uint32_t));
+    auto get_graph = [&](int which, uint32_t count) -> hipGraphExec_t {
+      wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
+      const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn, (uint64_t)sv.key.p, (uint64_t)sv.flags.p,
+                               (uint64_t)sv.improved.p, (uint64_t)sv.ctl.p, ((uint64_t)n << 32) | __float_as_uint_host(delta),
+                               (uint64_t)(h_imp + which * IMP_RING)};
+      if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
+      if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
+      if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
+      g.exec = nullptr;
+      g.graph = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      for (uint32_t j = 0; j < count; ++j)  // batches start at multiples of their size: flag parity is static
+        sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[j & 1u], fl[(j & 1u) ^ 1u], n,
+                                                  sv.improved.p, sv.ctl.p, j, delta);
+      HIP_CHECK(hipMemcpyAsync(h_imp + which * IMP_RING, sv.improved.p, IMP_RING * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, count);
+      HIP_CHECK(hipStreamEndCapture(st, &g.graph));
+      HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+      std::memcpy(g.key, key, sizeof(key));
+      return g.exec;
+    };
+    struct Batch {
+      uint32_t first, count;
+      int which;
+    };
+    uint32_t next_sweep = 0;
+    auto enqueue_batch = [&](hipEvent_t ev) {
+      Batch b{next_sweep, next_sweep >= 64 ? MAX_BATCH : 8u, next_sweep >= 64 ? 1 : 0};
+      HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
+      HIP_CHECK(hipEventRecord(ev, st));
+      next_sweep += b.count;
+      return b;
+    };
+    hipEvent_t evs[2] = {ctx->ev0, ctx->ev1};
+    Batch cur = enqueue_batch(evs[0]);
+    int which = 0;
+    for (;;) {
+      if (next_sweep > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+      // keep the device busy while the host inspects `cur`: the next batch is enqueued first.  Its copy of the
+      // flag ring is a superset of cur's (slots are recycled half a ring later), so reading after it is safe.
+      const Batch nxt = enqueue_batch(evs[which ^ 1]);
+      HIP_CHECK(hipEventSynchronize(evs[which]));
+      bool done = false;
+      const uint32_t* hf = h_imp + cur.which * IMP_RING;
+      for (uint32_t k = 0; k < cur.count; ++k) {
+        sweeps_done = cur.first + k + 1;
+        if (!hf[(cur.first + k) % IMP_RING]) {
+          done = true;
+          break;
+        }
+      }
+      if (done) break;
+      cur = nxt;
+      which ^= 1;
+    }
   }
+  sv.sweeps = sweeps_done;
+  ctx->stats.sweeps = sweeps_done;
 }
 
 // Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
@@ -410,7 +482,7 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   hipStream_t st = ctx->stream;
   Solve sv;
   run_relaxation(ctx, f, sv);
-  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p, n,
+  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus), 256, 0, st>>>(f->dev.finals, sv.key.p, n,
                                                                                                       sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
   Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
