@@ -108,13 +108,13 @@ struct wfst_ctx {
   bool profiling = false;
   wfst_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // cached HIP graph of one batch of relaxation sweeps (sssp.hip); rebuilt when any captured pointer changes
+  // cached HIP graph of one batch of relaxation sweeps (sssp.hip); rebuilt when any node argument changes
   struct SweepGraph {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   } sweep_graph[2];  // [0]: 8 sweeps per replay, [1]: 64
-  wfst::PinnedBuf pinned_flags;  // host mirror of the per-sweep flags (address captured in the graph)
+  wfst::PinnedBuf pinned_flags;  // host mirror of the per-sweep activity flags (its address is baked into the graphs)
   int n_cus = 256;
 };
 

@@ -360,9 +360,12 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     ctx->stats.relax_arcs += h_ctl->arcs;
     ctx->stats.relax_states += h_ctl->states;
   } else {
-    // One HIP graph = one batch: `count` sweep launches (static offsets 0..count-1 from the device-side base),
-    // the advance kernel, and the copy of the flag ring to pinned host memory.  Replaying a graph costs one
-    // host call instead of count+2 (a lone sweep on a small frontier takes ~4 us, less than a launch).
+    // One HIP graph = one batch: `count` sweep kernels (static offsets 0..count-1 from the device-side base), the
+    // copy of the flag ring to pinned host memory and the advance kernel, chained.  A replay is ONE host call
+    // instead of count+2, which matters twice: a sweep on a small frontier (~4 us) is shorter than a launch, and
+    // the host thread of another context (bench.py overlaps the batch pipeline on a second stream) is not starved
+    // of the runtime.  The graph is built with explicit nodes — stream capture would make every other thread's
+    // hipStreamSynchronize fail while it is active.  Two replays are kept in flight.
     uint32_t* h_imp = (uint32_t*)ctx->pinned_flags.get(2 * IMP_RING * sizeof(uint32_t));
     auto get_graph = [&](int which, uint32_t count) -> hipGraphExec_t {
       wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
@@ -374,13 +377,48 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
       g.exec = nullptr;
       g.graph = nullptr;
-      HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      for (uint32_t j = 0; j < count; ++j)  // batches start at multiples of their size: flag parity is static
-        sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[j & 1u], fl[(j & 1u) ^ 1u], n,
-                                                  sv.improved.p, sv.ctl.p, j, delta);
-      HIP_CHECK(hipMemcpyAsync(h_imp + which * IMP_RING, sv.improved.p, IMP_RING * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, count);
-      HIP_CHECK(hipStreamEndCapture(st, &g.graph));
+      HIP_CHECK(hipGraphCreate(&g.graph, 0));
+      hipGraphNode_t prev = nullptr;
+      const uint32_t* a_offsets = f->dev.offsets;
+      const uint2* a_wn = f->dev.wn;
+      uint64_t* a_key = sv.key.p;
+      uint32_t a_n = n;
+      uint32_t* a_imp = sv.improved.p;
+      Ctl* a_ctl = sv.ctl.p;
+      float a_delta = delta;
+      for (uint32_t j = 0; j < count; ++j) {  // batches start at multiples of their size: flag parity is static
+        uint8_t* a_fc = fl[j & 1u];
+        uint8_t* a_fn = fl[(j & 1u) ^ 1u];
+        uint32_t a_off = j;
+        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta};
+        hipKernelNodeParams kp{};
+        kp.func = (void*)sssp_relax_kernel;
+        kp.gridDim = dim3(blocks);
+        kp.blockDim = dim3(256);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        hipGraphNode_t node;
+        HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
+      }
+      {
+        hipGraphNode_t node;
+        HIP_CHECK(hipGraphAddMemcpyNode1D(&node, g.graph, &prev, 1, h_imp + which * IMP_RING, sv.improved.p,
+                                          IMP_RING * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        prev = node;
+      }
+      {
+        uint32_t a_count = count;
+        void* args[] = {&a_ctl, &a_imp, &a_count};
+        hipKernelNodeParams kp{};
+        kp.func = (void*)sssp_advance_kernel;
+        kp.gridDim = dim3(1);
+        kp.blockDim = dim3(64);
+        kp.kernelParams = args;
+        hipGraphNode_t node;
+        HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, &prev, 1, &kp));
+      }
       HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
       std::memcpy(g.key, key, sizeof(key));
       return g.exec;
@@ -391,6 +429,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     };
     uint32_t next_sweep = 0;
     auto enqueue_batch = [&](hipEvent_t ev) {
+      // constant small batches while the solve is shallow, larger ones for deep lattices
       Batch b{next_sweep, next_sweep >= 64 ? MAX_BATCH : 8u, next_sweep >= 64 ? 1 : 0};
       HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
       HIP_CHECK(hipEventRecord(ev, st));
