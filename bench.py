@@ -197,6 +197,16 @@ def main():
                     "solve_frac": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "re_relaxation_factor": round(st["relax_arcs"] / max(1, e_t), 3),
                 }
+                # HBM-side traffic cannot be counted live: it comes from the committed rocprofv3 PMC passes of this
+                # same command (profiles/pmc_relax_traffic.json, regenerated by tools/profile_round.sh), per launch
+                tp = os.path.join(ROOT, "profiles", "pmc_relax_traffic.json")
+                default_cfg = (args.states, args.fanout, args.sigma) == (1_000_000, 10, 256)
+                if os.path.exists(tp) and default_cfg:
+                    with open(tp) as fh:
+                        pmc = json.load(fh)
+                    roofline["traffic"] = round(pmc["traffic_bytes_per_solve"] / max(1, st["relax_launches"]))
+                    roofline["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / algo_bytes, 2)
+                    roofline["traffic_source"] = pmc["source"] + "; " + pmc["correction"]
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle
     cpu_baseline = None
