@@ -133,6 +133,12 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* ---- tr_sort (rustfst/src/algorithms/tr_sort.rs:13-62; FFI fst_tr_sort, rustfst-ffi/src/algorithms/tr_sort.rs:15):
+ *      in-place, stable, per-state sort of the device-resident arcs by ilabel (ilabel_cmp != 0, ILabelCompare)
+ *      or olabel (OLabelCompare), followed by the reference's property update.  This is what makes an FST
+ *      acceptable to wfst_compose (SortedMatcher needs the sorted bit). ---- */
+wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp);
+
 /* ---- fused batch: for each acceptor i: shortest_path(compose(acceptors[i], t)) — the loop a
  * caller writes around the two reference entry points; here one device-resident pipeline.
  * outs[i] are small host-resident FSTs. composed_arcs (may be NULL) receives the total number of

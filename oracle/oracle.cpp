@@ -1489,20 +1489,21 @@ Fst* load_vector_fst(const uint8_t* data, size_t len) {
     return nullptr;
   }
   std::string fst_type = r.str(), arc_type = r.str();
-  if (!r.ok || fst_type != "vector" || arc_type != "standard") {
-    t_err = "expected fst_type=vector arc_type=standard, got '" + fst_type + "'/'" + arc_type + "'";
+  const bool is_const = fst_type == "const";
+  if (!r.ok || (fst_type != "vector" && !is_const) || arc_type != "standard") {
+    t_err = "expected fst_type=vector|const arc_type=standard, got '" + fst_type + "'/'" + arc_type + "'";
     return nullptr;
   }
   int32_t version = r.get<int32_t>();
-  if (!r.ok || version < 2) {
-    t_err = "unsupported vector fst version";
+  if (!r.ok || version < (is_const ? 1 : 2)) {  // VECTOR_MIN_FILE_VERSION = 2, CONST_MIN_FILE_VERSION = 1
+    t_err = "unsupported fst version";
     return nullptr;
   }
   uint32_t flags = r.get<uint32_t>();
   uint64_t props = r.get<uint64_t>();
   int64_t start = r.get<int64_t>();
   int64_t num_states = r.get<int64_t>();
-  (void)r.get<int64_t>();  // num_trs: ignored by the reference parser (serializable_fst.rs:157)
+  int64_t num_trs_hdr = r.get<int64_t>();  // ignored by the vector parser (serializable_fst.rs:157), used by const
   if (!r.ok || (flags & ~7u)) {
     t_err = "bad header";
     return nullptr;
@@ -1517,6 +1518,52 @@ Fst* load_vector_fst(const uint8_t* data, size_t len) {
   }
   auto fst = std::make_unique<Fst>();
   fst->states.resize((size_t)num_states);
+  if (is_const) {  // parse_const_fst: const_fst/serializable_fst.rs:176-237 (aligned when version == 1)
+    const bool aligned = version == 1;
+    auto align16 = [&]() {
+      if (aligned && (r.off % 16) != 0) r.off += 16 - (r.off % 16);
+    };
+    if (num_states > 0) align16();
+    std::vector<uint32_t> pos((size_t)num_states), ntrs((size_t)num_states);
+    for (int64_t s = 0; s < num_states; ++s) {
+      State& st = fst->states[(size_t)s];
+      float fw = r.get<float>();
+      pos[(size_t)s] = (uint32_t)r.get<int32_t>();
+      ntrs[(size_t)s] = (uint32_t)r.get<int32_t>();
+      st.niepsilons = (size_t)r.get<int32_t>();
+      st.noepsilons = (size_t)r.get<int32_t>();
+      float saved = t_delta;
+      t_delta = KDELTA;
+      if (!weq(fw, INF)) {
+        st.has_final = true;
+        st.final_w = fw;
+      }
+      t_delta = saved;
+    }
+    if (num_trs_hdr > 0) align16();
+    std::vector<Tr> trs((size_t)std::max<int64_t>(num_trs_hdr, 0));
+    for (auto& tr : trs) {
+      tr.ilabel = (uint32_t)r.get<int32_t>();
+      tr.olabel = (uint32_t)r.get<int32_t>();
+      tr.weight = r.get<float>();
+      tr.nextstate = (uint32_t)r.get<int32_t>();
+    }
+    if (!r.ok) {
+      t_err = "Error while parsing binary ConstFst";
+      return nullptr;
+    }
+    for (int64_t s = 0; s < num_states; ++s) {
+      if ((uint64_t)pos[(size_t)s] + ntrs[(size_t)s] > trs.size()) {
+        t_err = "Error while parsing binary ConstFst";
+        return nullptr;
+      }
+      fst->states[(size_t)s].trs.assign(trs.begin() + pos[(size_t)s], trs.begin() + pos[(size_t)s] + ntrs[(size_t)s]);
+    }
+    fst->has_start = start != -1;
+    fst->start = start == -1 ? 0u : (uint32_t)start;
+    fst->properties = props & P::ALL;
+    return fst.release();
+  }
   for (int64_t s = 0; s < num_states; ++s) {
     State& st = fst->states[(size_t)s];
     float fw = r.get<float>();

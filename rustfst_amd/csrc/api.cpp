@@ -280,6 +280,13 @@ wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* di
   });
 }
 
+wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp) {
+  return wrap([&] {
+    if (!ctx || !fst) throw Error("null pointer");
+    tr_sort_device(ctx, fst, ilabel_cmp != 0);
+  });
+}
+
 wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
                                              const wfst_fst* t, const wfst_compose_config* ccfg,
                                              const wfst_shortest_path_config* scfg, wfst_fst** outs,

@@ -181,6 +181,8 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
 // nshortest.hip
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
+// tr_sort.hip
+void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
 // compose.hip
 wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect);
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,

@@ -1,4 +1,6 @@
-// openfst_io.cpp — OpenFST binary "vector"/"standard" reader and writer (host side).
+// openfst_io.cpp — OpenFST binary reader ("vector" and "const", "standard" arcs) and "vector" writer (host side).
+// const format (CSR on disk, 16-byte aligned blocks when version == 1):
+// rustfst/src/fst_impls/const_fst/serializable_fst.rs:176-237, const_fst/mod.rs:11-14.
 // Format: rustfst/src/parsers/bin_fst/fst_header.rs:71-137 (header),
 // rustfst/src/fst_impls/vector_fst/serializable_fst.rs:45-168 (body, store()),
 // rustfst/src/parsers/bin_fst/utils_parsing.rs:10-44 (start / final / arc),
@@ -48,17 +50,19 @@ wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len)
   Cursor c{data, len};
   if (c.get<int32_t>() != FST_MAGIC) throw Error("Error while parsing binary VectorFst: bad magic number");
   std::string fst_type = c.str(), arc_type = c.str();
-  if (fst_type != "vector")
-    throw Error("Error while parsing binary VectorFst: fst_type is '" + fst_type + "', expected 'vector'");
+  const bool is_const = fst_type == "const";
+  if (fst_type != "vector" && !is_const)
+    throw Error("Error while parsing binary Fst: fst_type is '" + fst_type + "', expected 'vector' or 'const'");
   if (arc_type != "standard")  // Tr::<TropicalWeight>::tr_type(), tr.rs:68-76
     throw Error("Error while parsing binary VectorFst: arc_type is '" + arc_type + "', expected 'standard'");
-  if (c.get<int32_t>() < 2) throw Error("Error while parsing binary VectorFst: version < 2");  // :127
+  const int32_t version = c.get<int32_t>();
+  if (version < (is_const ? 1 : 2)) throw Error("Error while parsing binary Fst: unsupported version");  // :127 / mod.rs:11
   uint32_t flags = c.get<uint32_t>();
   if (flags & ~7u) throw Error("Could not parse Fst Flags");
   uint64_t props = c.get<uint64_t>();
   int64_t start = c.get<int64_t>();
   int64_t num_states = c.get<int64_t>();
-  (void)c.get<int64_t>();  // num_arcs: may be 0 in vector files; the reference ignores it (:157)
+  const int64_t num_arcs_hdr = c.get<int64_t>();  // may be 0 in vector files (ignored there, :157); exact in const files
   if (flags & 1u) skip_symt(c);
   if (flags & 2u) skip_symt(c);
   if (num_states < 0 || num_states >= 0x7FFFFFFF) throw Error("Error while parsing binary VectorFst: bad num_states");
@@ -66,6 +70,40 @@ wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len)
   h.offsets.reserve((size_t)num_states + 1);
   h.finals.reserve((size_t)num_states);
   h.offsets.push_back(0);
+  if (is_const) {  // parse_const_fst: const_fst/serializable_fst.rs:198-237
+    const bool aligned = version == 1;
+    auto align16 = [&]() {
+      if (aligned && (c.off % 16) != 0) c.off += 16 - (c.off % 16);
+      if (c.off > c.n) throw Error("Error while parsing binary ConstFst");
+    };
+    if (num_arcs_hdr < 0 || (uint64_t)num_arcs_hdr > len / 16) throw Error("Error while parsing binary ConstFst");
+    if (num_states > 0) align16();
+    std::vector<uint32_t> pos((size_t)num_states), ntrs((size_t)num_states);
+    for (int64_t s = 0; s < num_states; ++s) {
+      const float fw = c.get<float>();
+      pos[(size_t)s] = (uint32_t)c.get<int32_t>();
+      ntrs[(size_t)s] = (uint32_t)c.get<int32_t>();
+      (void)c.get<int32_t>();  // niepsilons / noepsilons are recomputed on the device
+      (void)c.get<int32_t>();
+      h.finals.push_back(props::is_zero(fw) ? INF : fw);
+    }
+    if (num_arcs_hdr > 0) align16();
+    h.arcs.resize((size_t)num_arcs_hdr);
+    for (int64_t i = 0; i < num_arcs_hdr; ++i) {
+      wfst_tr& tr = h.arcs[(size_t)i];
+      tr.ilabel = (uint32_t)c.get<int32_t>();
+      tr.olabel = (uint32_t)c.get<int32_t>();
+      tr.weight = c.get<float>();
+      tr.nextstate = (uint32_t)c.get<int32_t>();
+    }
+    for (int64_t s = 0; s < num_states; ++s) {  // states must tile the arc array in order (they do in OpenFST files)
+      if (pos[(size_t)s] != h.offsets.back() || (uint64_t)pos[(size_t)s] + ntrs[(size_t)s] > (uint64_t)num_arcs_hdr)
+        throw Error("Error while parsing binary ConstFst: state arc ranges are not contiguous");
+      h.offsets.push_back(pos[(size_t)s] + ntrs[(size_t)s]);
+    }
+    if (start < -1 || start >= num_states) throw Error("Error while parsing binary ConstFst: start out of range");
+    return upload_from_host(ctx, (uint32_t)num_states, start, h.offsets.data(), h.arcs.data(), h.finals.data(), props);
+  }
   for (int64_t s = 0; s < num_states; ++s) {
     float fw = c.get<float>();
     int64_t ntrs = c.get<int64_t>();

@@ -227,6 +227,13 @@ class DeviceFst:
         check(_lib.lib().wfst_shortest_path(self.ctx._h, self._h, cfg, C.byref(out)), "Error computing shortest path")
         return DeviceFst(out, self.ctx)
 
+    def tr_sort(self, ilabel_cmp: bool = True) -> "DeviceFst":
+        """In-place stable per-state arc sort on the device by ilabel (ILabelCompare) or olabel
+        (OLabelCompare) + the reference's property update: algorithms/tr_sort.rs:13-62,
+        rustfst-python fst.tr_sort (rustfst/algorithms/tr_sort.py)."""
+        check(_lib.lib().wfst_fst_tr_sort(self.ctx._h, self._h, 1 if ilabel_cmp else 0), "Error during tr_sort")
+        return self
+
     def shortest_distance(self, want_hops: bool = False):
         n = self.num_states
         dist = np.zeros(n, dtype=np.float32)

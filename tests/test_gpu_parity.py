@@ -494,3 +494,102 @@ def test_pack_paths_matches_python_packing(gpu_ctx, oracle):
         assert f["n_states"] == u["n_states"] and np.array_equal(f["arcs"], u["arcs"])
     with pytest.raises(rustfst_amd.WfstError, match="longer"):
         wdist.pack_device_paths(outs, 3)
+
+
+# ------------------------------------------------------------------ §8(f) N3: const-format loader; N2: device tr_sort
+@pytest.mark.parametrize("name", ["fst_012_hcl.fst", "fst_014_hcl.fst", "fst_012_gp.fst", "fst_014_g.fst",
+                                  "fst_020_patterns_fst.fst"])
+def test_openfst_loader_const_and_vector(gpu_ctx, oracle, name):
+    data = open(os.path.join(GOLDEN, name), "rb").read()
+    d = rustfst_amd.DeviceFst.from_bytes(data)
+    o = oracle.OracleFst.load(data)
+    assert_flat_identical(d.to_flat(), o.to_flat(), name)
+    assert d.to_bytes() == o.store()
+
+
+def _unsorted_flat(rng, n_states, max_fanout, sigma, hub_degrees=(), acceptor=False):
+    f = random_fst_flat(rng, n_states, max_fanout, sigma, p_eps_i=0.15, p_eps_o=0.15, sort="none")
+    # re-build with a few hub states of prescribed degree (exercise the 17..256 rank path and the rocPRIM path)
+    offsets = [0]
+    rows = []
+    for s in range(n_states):
+        a = f["arcs"][f["offsets"][s]:f["offsets"][s + 1]]
+        if s < len(hub_degrees):
+            k = hub_degrees[s]
+            a = np.zeros(k, dtype=f["arcs"].dtype)
+            a["ilabel"] = rng.integers(0, sigma + 1, k)
+            a["olabel"] = rng.integers(0, sigma + 1, k)
+            a["weight"] = rng.integers(0, 2560, k) / 512.0
+            a["nextstate"] = rng.integers(0, n_states, k)
+        rows.append(a)
+        offsets.append(offsets[-1] + len(a))
+    arcs = np.concatenate(rows) if rows else f["arcs"]
+    props = 0
+    if acceptor:
+        arcs["olabel"] = arcs["ilabel"]
+        props |= synth.ACCEPTOR
+    return dict(n_states=n_states, start=0, offsets=np.array(offsets, dtype=np.uint32), arcs=arcs, finals=f["finals"],
+                props=props)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("ilabel_cmp", [True, False])
+def test_tr_sort_matches_oracle(gpu_ctx, oracle, seed, ilabel_cmp):
+    rng = np.random.default_rng(900 + seed)
+    hubs = [(), (17, 64, 255), (256, 257, 1000), (5000, 3), (16, 15, 1), (300,)][seed]
+    flat = _unsorted_flat(rng, int(rng.integers(6, 400)), 14, int(rng.integers(2, 40)), hubs, acceptor=(seed == 4))
+    d = to_device(flat)
+    o = to_oracle(oracle, flat)
+    d.tr_sort(ilabel_cmp)
+    o.tr_sort(by_olabel=not ilabel_cmp)
+    assert_flat_identical(d.to_flat(), o.to_flat(), f"tr_sort seed {seed}")
+    # the derived {weight,next} array was rebuilt too: distances over the sorted arcs agree with the oracle
+    np.testing.assert_allclose(d.shortest_distance(), o.shortest_path_canonical().distance, rtol=0, atol=1e-5)
+    before = d.to_flat()
+    d.tr_sort(ilabel_cmp)  # idempotent
+    assert_flat_identical(d.to_flat(), before, "tr_sort twice")
+
+
+def test_tr_sort_large_is_sorted_and_stable(gpu_ctx):
+    """BASELINE-sized T (1M states / ~10M arcs) sorted by olabel: size-independent properties — per-state
+    non-decreasing olabels, stability (ties keep their ilabel-sorted input order), multiset preserved."""
+    t = synth.make_transducer(1_000_000, 10, 50_000, 0.1, seed=42)
+    d = to_device(t)
+    d.tr_sort(False)
+    out = d.to_flat()
+    assert out["props"] & synth.O_LABEL_SORTED and not out["props"] & synth.I_LABEL_SORTED
+    a, off = out["arcs"], out["offsets"].astype(np.int64)
+    state_of = np.repeat(np.arange(t["n_states"]), np.diff(off))
+    same = state_of[1:] == state_of[:-1]
+    ol = a["olabel"].astype(np.int64)
+    assert np.all(ol[1:][same] >= ol[:-1][same])
+    tie = same & (ol[1:] == ol[:-1])
+    il = a["ilabel"].astype(np.int64)
+    assert np.all(il[1:][tie] >= il[:-1][tie])  # input was ilabel-sorted => stable output keeps that order on ties
+    ref = t["arcs"].copy()
+    order = np.lexsort((np.arange(len(ref)), ref["olabel"], np.repeat(np.arange(t["n_states"]), np.diff(off))))
+    np.testing.assert_array_equal(a.view(np.uint32), ref[order].view(np.uint32))
+    d.tr_sort(True)  # and back by ilabel: ties now keep the olabel-sorted order
+    order2 = np.lexsort((np.arange(len(a)), a["ilabel"], state_of))
+    back = d.to_flat()
+    np.testing.assert_array_equal(back["arcs"].view(np.uint32), a[order2].view(np.uint32))
+    assert back["props"] & synth.I_LABEL_SORTED and not back["props"] & synth.O_LABEL_SORTED
+
+
+@pytest.mark.parametrize("hcl,g", [("fst_014_hcl.fst", "fst_014_g.fst"), ("fst_012_hcl.fst", "fst_012_gp.fst")])
+def test_hcl_compose_g(gpu_ctx, oracle, hcl, g):
+    """HCL (const file) o G (vector file), the pairing of the reference's fst_014.h / fst_012.h, with the
+    arc sorting done on the device."""
+    da, db = (open(os.path.join(GOLDEN, n), "rb").read() for n in (hcl, g))
+    a, b = rustfst_amd.DeviceFst.from_bytes(da), rustfst_amd.DeviceFst.from_bytes(db)
+    oa, ob = oracle.OracleFst.load(da), oracle.OracleFst.load(db)
+    a.tr_sort(False), b.tr_sort(True)
+    oa.tr_sort(by_olabel=True), ob.tr_sort(by_olabel=False)
+    for connect in (True, False):
+        c = a.compose(b, ComposeConfig(connect=connect))
+        oc = oa.compose(ob, connect=connect)
+        assert_flat_identical(c.to_flat(), oc.to_flat(), f"{hcl} o {g} connect={connect}")
+    sp = c.shortest_path()
+    assert_flat_identical(sp.to_flat(), oc.shortest_path_canonical().to_flat(), "shortest path of HCL o G")
+    outs, _ = rustfst_amd.compose_shortest_path_batch([a], b)
+    assert_flat_identical(outs[0].to_flat(), oa.compose(ob).shortest_path_canonical().to_flat(), "fused HCL o G")

@@ -146,6 +146,41 @@ def test_k4_loader_fixtures(oracle, name, n_states, n_arcs):
     assert again == f and again.properties == f.properties
 
 
+# const-format files of the reference's test data (rustfst-tests-data/fst_012, fst_014: ConstFst::Read;
+# parse_const_fst, const_fst/serializable_fst.rs:176-237).  Independent check of the aligned v1 layout: the
+# per-state niepsilons/noepsilons counters STORED in the file must equal the counters recomputed from the arcs.
+@pytest.mark.parametrize("name,n_states,n_arcs", [("fst_012_hcl.fst", 215, 942), ("fst_014_hcl.fst", 85, 310)])
+def test_const_loader_fixtures(oracle, name, n_states, n_arcs):
+    data = open(os.path.join(GOLDEN, name), "rb").read()
+    assert data[8:13] == b"const"
+    f = oracle.OracleFst.load(data)
+    assert (f.num_states, f.num_arcs, f.start) == (n_states, n_arcs, 0)
+    flat = f.to_flat()
+    ni, no = f.eps_counts()
+    for s in range(n_states):
+        a = flat["arcs"][flat["offsets"][s]:flat["offsets"][s + 1]]
+        assert (ni[s], no[s]) == (int((a["ilabel"] == 0).sum()), int((a["olabel"] == 0).sum()))
+    assert int(flat["arcs"]["nextstate"].max()) < n_states
+    again = oracle.OracleFst.load(f.store())  # written back as a vector file
+    assert again == f
+
+
+@pytest.mark.parametrize("hcl,g", [("fst_014_hcl.fst", "fst_014_g.fst"), ("fst_012_hcl.fst", "fst_012_gp.fst")])
+def test_hcl_compose_g_oracle(oracle, hcl, g):
+    """The pairing the reference's own data generator sets up (fst_014.h / fst_012.h): HCL o G after arc sorting."""
+    a = oracle.OracleFst.load(open(os.path.join(GOLDEN, hcl), "rb").read())
+    b = oracle.OracleFst.load(open(os.path.join(GOLDEN, g), "rb").read())
+    a.tr_sort(by_olabel=True)
+    b.tr_sort(by_olabel=False)
+    c = a.compose(b)
+    assert c.num_states > 0 and c.num_arcs > 0
+    sp = c.shortest_path()
+    can = c.shortest_path_canonical()
+    assert sp.num_states > 0 and can.num_states > 0
+    ok, w = c.contains_path(sp)
+    assert ok and w == pytest.approx(can.total_weight, abs=1e-5)
+
+
 # ---------------------------------------------------------------- invariants on random small FSTs
 @pytest.mark.parametrize("seed", range(12))
 def test_shortest_path_weight_is_bruteforce_min(oracle, seed):
