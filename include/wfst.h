@@ -133,6 +133,16 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* asynchronous form of the fused batch: _begin enqueues the whole pipeline on ctx's stream and returns at once
+ * (so that the caller can issue other work, e.g. wfst_shortest_path on ANOTHER context, which then overlaps on
+ * the GPU); _end waits, fills outs[0..n) / composed_arcs exactly like the synchronous call and frees the job
+ * (also on error).  One job in flight per context; acceptors and t must stay alive until _end. */
+typedef struct wfst_batch_job wfst_batch_job;
+wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
+                                                   const wfst_fst* t, const wfst_compose_config* ccfg,
+                                                   const wfst_shortest_path_config* scfg, wfst_batch_job** job);
+wfst_status wfst_compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs);
+
 /* ---- tr_sort (rustfst/src/algorithms/tr_sort.rs:13-62; FFI fst_tr_sort, rustfst-ffi/src/algorithms/tr_sort.rs:15):
  *      in-place, stable, per-state sort of the device-resident arcs by ilabel (ilabel_cmp != 0, ILabelCompare)
  *      or olabel (OLabelCompare), followed by the reference's property update.  This is what makes an FST
@@ -202,6 +212,9 @@ typedef struct {
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on);
 wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out);
 wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx);
+/* per-launch trace of the last profiled relaxation (profiling on): launch k relaxed arcs[k] arcs leaving
+ * states[k] frontier states in ms[k] milliseconds.  Copies min(cap, *n) entries; arrays may be NULL to query *n. */
+wfst_status wfst_ctx_get_sweep_trace(wfst_ctx* ctx, double* ms, uint64_t* arcs, uint64_t* states, size_t cap, size_t* n);
 
 #ifdef __cplusplus
 }

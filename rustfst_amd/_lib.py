@@ -55,6 +55,9 @@ SYMBOLS = [
     ("wfst_shortest_distance", C.c_int, [_vp, _vp, _vp, _vp]),
     ("wfst_compose_shortest_path_batch", C.c_int,
      [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _P(_vp), _P(_u64)]),
+    ("wfst_compose_shortest_path_batch_begin", C.c_int,
+     [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _P(_vp)]),
+    ("wfst_compose_shortest_path_batch_end", C.c_int, [_vp, _P(_vp), _P(_u64)]),
     ("wfst_fst_pack_paths", C.c_int, [_P(_vp), _sz, _u32, _vp]),
     ("wfst_fst_tr_sort", C.c_int, [_vp, _vp, C.c_int]),
     ("wfst_vec_fst_new", C.c_int, [_P(_vp)]),
@@ -78,6 +81,7 @@ SYMBOLS = [
     ("wfst_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
     ("wfst_ctx_get_stats", C.c_int, [_vp, _P(Stats)]),
     ("wfst_ctx_reset_stats", C.c_int, [_vp]),
+    ("wfst_ctx_get_sweep_trace", C.c_int, [_vp, _vp, _vp, _vp, _sz, _P(_sz)]),
 ]
 
 _lib = None

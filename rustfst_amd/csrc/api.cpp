@@ -302,6 +302,37 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
   });
 }
 
+wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
+                                                   const wfst_fst* t, const wfst_compose_config* ccfg,
+                                                   const wfst_shortest_path_config* scfg, wfst_batch_job** job) {
+  return wrap([&] {
+    if (!ctx || !t || !job || (n && !acceptors)) throw Error("null pointer");
+    *job = nullptr;
+    wfst_compose_config c = ccfg ? *ccfg : wfst_compose_config{0, 1};
+    wfst_shortest_path_config s = scfg ? *scfg : wfst_shortest_path_config{1e-6f, 1, 0};
+    if (c.compose_filter != 0 && c.compose_filter != 3) throw Error("unsupported: compose_filter");
+    if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
+    if (ctx->batch_in_flight) throw Error("a fused batch is already in flight on this context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *job = compose_shortest_path_batch_begin(ctx, acceptors, n, t);
+    ctx->batch_in_flight = true;
+  });
+}
+
+wfst_status wfst_compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs) {
+  return wrap([&] {
+    if (!job) throw Error("null job");
+    wfst_ctx* ctx = batch_job_ctx(job);
+    ctx->batch_in_flight = false;
+    if (!outs) {
+      compose_shortest_path_batch_abandon(job);
+      throw Error("null pointer");
+    }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    compose_shortest_path_batch_end(job, outs, composed_arcs);
+  });
+}
+
 wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t max_arcs, uint32_t* out) {
   return wrap([&] {
     if ((n && !paths) || !out) throw Error("null pointer");
@@ -336,6 +367,17 @@ wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out) {
   return wrap([&] {
     if (!ctx || !out) throw Error("null pointer");
     *out = ctx->stats;
+  });
+}
+wfst_status wfst_ctx_get_sweep_trace(wfst_ctx* ctx, double* ms, uint64_t* arcs, uint64_t* states, size_t cap, size_t* n) {
+  return wrap([&] {
+    if (!ctx || !n) throw Error("null pointer");
+    *n = ctx->sweep_trace.size();
+    for (size_t i = 0; i < std::min(cap, *n); ++i) {
+      if (ms) ms[i] = ctx->sweep_trace[i].ms;
+      if (arcs) arcs[i] = ctx->sweep_trace[i].arcs;
+      if (states) states[i] = ctx->sweep_trace[i].states;
+    }
   });
 }
 wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx) {

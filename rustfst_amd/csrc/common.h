@@ -106,7 +106,13 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned;      // small D2H/H2D staging
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
+  bool batch_in_flight = false;  // wfst_compose_shortest_path_batch_begin .. _end
   wfst_stats stats{};
+  struct SweepSample {
+    double ms;
+    uint64_t arcs, states;
+  };
+  std::vector<SweepSample> sweep_trace;  // profiling only: one entry per relaxation launch of the last solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // cached HIP graph of one batch of relaxation sweeps (sssp.hip); rebuilt when any node argument changes
   struct SweepGraph {
@@ -187,4 +193,8 @@ void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
 wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect);
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,
                                  wfst_fst** outs, uint64_t* composed_arcs);
+wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t);
+void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs);
+void compose_shortest_path_batch_abandon(wfst_batch_job* job);
+wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 }  // namespace wfst

@@ -989,35 +989,58 @@ struct BatchRun {
   Caps caps{};
   DBuf<wfst_tr> paths;
   std::vector<wfst_tr> h_paths;
+  // in flight between launch_begin and launch_end
+  size_t n = 0;
+  bool want_paths = false;
+  uint32_t path_cap = 1;
+  DBuf<ProblemDesc> d_desc;
+  DBuf<Result> d_res;
+  DBuf<uint32_t> d_cursor;
+  Result* h_res = nullptr;      // pinned (ctx->pinned_big): one batch in flight per context
+  uint32_t* h_cursor = nullptr;
 };
 
+// Enqueues descriptors, the kernel and the result copies on ctx's stream and returns without waiting.
 template <uint32_t FLAGS>
-void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
-            bool want_paths) {
+void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
+                  bool want_paths) {
   const size_t n = descs.size();
   DevicePool& pool = *ctx->pool;
   hipStream_t st = ctx->stream;
+  run.n = n;
+  run.want_paths = want_paths;
   run.caps = caps;
   run.stride = arena_bytes(caps);
   run.arena = DBuf<char>(pool, run.stride * n);
-  DBuf<ProblemDesc> d_desc(pool, n);
-  DBuf<Result> d_res(pool, n);
-  DBuf<uint32_t> d_cursor(pool, 1);
+  run.d_desc = DBuf<ProblemDesc>(pool, n);
+  run.d_res = DBuf<Result>(pool, n);
+  run.d_cursor = DBuf<uint32_t>(pool, 1);
   const uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
+  run.path_cap = path_cap;
   run.paths = DBuf<wfst_tr>(pool, path_cap);
   ProblemDesc* h_desc = (ProblemDesc*)ctx->pinned_big.get(n * sizeof(ProblemDesc) + n * sizeof(Result) + 64);
   std::memcpy(h_desc, descs.data(), n * sizeof(ProblemDesc));
-  HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, sizeof(uint32_t), st));
+  HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(run.d_cursor.p, 0, sizeof(uint32_t), st));
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(d_desc.p, f2, caps, run.arena.p, run.stride, d_res.p, run.paths.p,
-                                                          path_cap, d_cursor.p);
+  compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, caps, run.arena.p, run.stride, run.d_res.p,
+                                                          run.paths.p, path_cap, run.d_cursor.p);
   HIP_CHECK(hipGetLastError());
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
-  Result* h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
-  uint32_t* h_cursor = (uint32_t*)((char*)h_res + n * sizeof(Result));
-  HIP_CHECK(hipMemcpyAsync(h_res, d_res.p, n * sizeof(Result), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  run.h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
+  run.h_cursor = (uint32_t*)((char*)run.h_res + n * sizeof(Result));
+  HIP_CHECK(hipMemcpyAsync(run.h_res, run.d_res.p, n * sizeof(Result), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(run.h_cursor, run.d_cursor.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+}
+
+// Waits for the batch enqueued by launch_begin and brings results (and the path arcs) to the host.
+void launch_end(wfst_ctx* ctx, BatchRun& run) {
+  const size_t n = run.n;
+  hipStream_t st = ctx->stream;
+  Result* h_res = run.h_res;
+  uint32_t* h_cursor = run.h_cursor;
+  const bool want_paths = run.want_paths;
+  const uint32_t path_cap = run.path_cap;
   HIP_CHECK(hipStreamSynchronize(st));
   if (ctx->profiling) {
     float ms = 0;
@@ -1042,6 +1065,13 @@ void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView&
       HIP_CHECK(hipStreamSynchronize(st));
     }
   }
+}
+
+template <uint32_t FLAGS>
+void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
+            bool want_paths) {
+  launch_begin<FLAGS>(ctx, descs, f2, caps, run, want_paths);
+  launch_end(ctx, run);
 }
 
 // builds the reference's linear shortest-path FST (see sssp.hip::build_path_fst)
@@ -1135,55 +1165,81 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
   }
 }
 
-void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool /*connect*/,
-                                 wfst_fst** outs, uint64_t* composed_arcs) {
-  if (composed_arcs) *composed_arcs = 0;
-  if (n == 0) return;
+}  // namespace wfst
+
+// One fused batch in flight: begin enqueues everything on the context's stream and returns; end waits,
+// re-runs the (rare) problems whose arena overflowed with 4x capacities, and assembles the path FSTs.
+struct wfst_batch_job {
+  wfst_ctx* ctx = nullptr;
+  size_t n = 0;
+  wfst::FstView v2{};
+  std::vector<wfst::ProblemDesc> descs;
+  std::vector<size_t> todo;
+  uint64_t est_s = 0, est_a = 0;
+  wfst::BatchRun run;
+};
+
+namespace wfst {
+
+wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t) {
+  auto job = std::make_unique<wfst_batch_job>();
+  job->ctx = ctx;
+  job->n = n;
+  if (n == 0) return job.release();
   ensure_device(const_cast<wfst_fst*>(t));
-  const FstView v2 = view_of(t);
-  std::vector<ProblemDesc> descs(n);
-  std::vector<size_t> todo(n);
+  job->v2 = view_of(t);
+  job->descs.resize(n);
+  job->todo.resize(n);
   uint64_t max_states = 64;
   for (size_t i = 0; i < n; ++i) {
     if (!accs[i]) throw Error("null acceptor in batch");
-    descs[i].mode = decide_match_mode(accs[i]->props, t->props);
+    job->descs[i].mode = decide_match_mode(accs[i]->props, t->props);
     ensure_device(const_cast<wfst_fst*>(accs[i]));
-    descs[i].f1 = view_of(accs[i]);
-    descs[i].pad = 0;
-    todo[i] = i;
+    job->descs[i].f1 = view_of(accs[i]);
+    job->descs[i].pad = 0;
+    job->todo[i] = i;
     max_states = std::max<uint64_t>(max_states, accs[i]->n_states);
-    outs[i] = nullptr;
   }
-  uint64_t est_s = 4ull * max_states + 256;
-  uint64_t est_a = 2ull * est_s;
+  job->est_s = 4ull * max_states + 256;
+  job->est_a = 2ull * job->est_s;
+  launch_begin<FLAG_SP>(ctx, job->descs, job->v2, make_caps(job->est_s, job->est_a), job->run, true);
+  return job.release();
+}
+
+void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, uint64_t* composed_arcs) {
+  std::unique_ptr<wfst_batch_job> job(job_raw);  // consumed whatever happens
+  wfst_ctx* ctx = job->ctx;
+  const size_t n = job->n;
+  if (composed_arcs) *composed_arcs = 0;
+  if (n == 0) return;
+  for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
   uint64_t tot_arcs = 0, tot_states = 0;
   double ms = 0;
   try {
-    for (int attempt = 0; !todo.empty(); ++attempt) {
-      Caps caps = make_caps(est_s, est_a);
-      std::vector<ProblemDesc> cur(todo.size());
-      for (size_t k = 0; k < todo.size(); ++k) cur[k] = descs[todo[k]];
-      BatchRun run;
-      launch<FLAG_SP>(ctx, cur, v2, caps, run, true);
+    for (int attempt = 0;; ++attempt) {
+      launch_end(ctx, job->run);
       ms += ctx->stats.compose_ms;
       std::vector<size_t> again;
-      for (size_t k = 0; k < todo.size(); ++k) {
-        const Result& r = run.results[k];
+      for (size_t k = 0; k < job->todo.size(); ++k) {
+        const Result& r = job->run.results[k];
         if (r.status != ST_OK) {
-          again.push_back(todo[k]);
+          again.push_back(job->todo[k]);
           continue;
         }
         tot_arcs += r.n_arcs;
         tot_states += r.n_states;
-        outs[todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? run.h_paths.data() + r.path_off : nullptr);
+        outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.h_paths.data() + r.path_off : nullptr);
       }
-      if (!again.empty()) {
-        ctx->stats.compose_retries++;
-        if (attempt > 24) throw Error("compose_shortest_path_batch: arena overflow after retries");
-        est_s *= 4;
-        est_a *= 4;
-      }
-      todo.swap(again);
+      job->todo.swap(again);
+      if (job->todo.empty()) break;
+      ctx->stats.compose_retries++;
+      if (attempt > 24) throw Error("compose_shortest_path_batch: arena overflow after retries");
+      job->est_s *= 4;
+      job->est_a *= 4;
+      std::vector<ProblemDesc> cur(job->todo.size());
+      for (size_t k = 0; k < job->todo.size(); ++k) cur[k] = job->descs[job->todo[k]];
+      job->run = BatchRun{};
+      launch_begin<FLAG_SP>(ctx, cur, job->v2, make_caps(job->est_s, job->est_a), job->run, true);
     }
   } catch (...) {
     for (size_t i = 0; i < n; ++i) {
@@ -1196,6 +1252,19 @@ void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, siz
   ctx->stats.compose_arcs = tot_arcs;
   ctx->stats.compose_ms = ms;
   if (composed_arcs) *composed_arcs = tot_arcs;
+}
+
+wfst_ctx* batch_job_ctx(const wfst_batch_job* job) { return job->ctx; }
+
+void compose_shortest_path_batch_abandon(wfst_batch_job* job) {
+  if (!job) return;
+  if (job->n) hipStreamSynchronize(job->ctx->stream);  // the kernel may still be writing into the job's buffers
+  delete job;
+}
+
+void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool /*connect*/,
+                                 wfst_fst** outs, uint64_t* composed_arcs) {
+  compose_shortest_path_batch_end(compose_shortest_path_batch_begin(ctx, accs, n, t), outs, composed_arcs);
 }
 
 }  // namespace wfst

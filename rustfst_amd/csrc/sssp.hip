@@ -338,6 +338,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     // one sweep at a time, bracketed by events; a counting kernel (outside the events) sizes the frontier
     uint32_t* h_imp = (uint32_t*)ctx->pinned.get(64 + sizeof(Ctl));
     Ctl* h_ctl = (Ctl*)((char*)h_imp + 64);
+    ctx->sweep_trace.clear();
+    uint64_t prev_arcs = 0, prev_states = 0;
     for (uint32_t k = 0;; ++k) {
       if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
       sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta);
@@ -347,9 +349,13 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      ctx->sweep_trace.push_back({(double)ms, h_ctl->arcs - prev_arcs, h_ctl->states - prev_states});
+      prev_arcs = h_ctl->arcs;
+      prev_states = h_ctl->states;
       ctx->stats.relax_ms += ms;
       ctx->stats.relax_launches += 1;
       sweeps_done = k + 1;

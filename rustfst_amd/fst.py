@@ -77,6 +77,17 @@ class Context:
     def reset_stats(self):
         check(_lib.lib().wfst_ctx_reset_stats(self._h))
 
+    def sweep_trace(self):
+        """(ms, arcs, states) arrays, one entry per relaxation launch of the last profiled solve."""
+        n = C.c_size_t()
+        check(_lib.lib().wfst_ctx_get_sweep_trace(self._h, None, None, None, 0, C.byref(n)))
+        ms = np.zeros(n.value, dtype=np.float64)
+        arcs = np.zeros(n.value, dtype=np.uint64)
+        states = np.zeros(n.value, dtype=np.uint64)
+        check(_lib.lib().wfst_ctx_get_sweep_trace(self._h, ms.ctypes.data, arcs.ctypes.data, states.ctypes.data,
+                                                  n.value, C.byref(n)))
+        return ms, arcs, states
+
     def stats(self) -> dict:
         st = _lib.Stats()
         check(_lib.lib().wfst_ctx_get_stats(self._h, C.byref(st)))
@@ -243,13 +254,54 @@ class DeviceFst:
         return (dist, hops) if want_hops else dist
 
 
+class BatchJob:
+    """A fused batch in flight (wfst_compose_shortest_path_batch_begin); finish() = ..._end."""
+
+    def __init__(self, job, n, ctx, keep_alive):
+        self._job, self._n, self._ctx, self._keep = job, n, ctx, keep_alive
+
+    def finish(self):
+        if self._job is None:
+            raise WfstError("batch job already finished")
+        outs = (C.c_void_p * self._n)()
+        na = C.c_uint64()
+        job, self._job = self._job, None
+        check(_lib.lib().wfst_compose_shortest_path_batch_end(job, outs, C.byref(na)),
+              "wfst_compose_shortest_path_batch_end")
+        self._keep = None
+        return [DeviceFst(C.c_void_p(outs[i]), self._ctx) for i in range(self._n)], na.value
+
+    def __del__(self):
+        if getattr(self, "_job", None) is not None:  # abandoned: wait for the kernel and free the job
+            _lib.lib().wfst_compose_shortest_path_batch_end(self._job, None, None)
+            self._job = None
+
+
+def compose_shortest_path_batch_begin(acceptors: Sequence[DeviceFst], t: DeviceFst,
+                                      compose_config: Optional["ComposeConfig"] = None,
+                                      shortest_path_config: Optional["ShortestPathConfig"] = None,
+                                      ctx: Optional[Context] = None) -> BatchJob:
+    """Enqueue the fused batch on `ctx`'s stream (default: t's context) and return at once; work issued
+    afterwards on ANOTHER context (e.g. shortest_path of a large FST) overlaps with it on the GPU."""
+    n = len(acceptors)
+    ctx = ctx or t.ctx
+    arr = (C.c_void_p * n)(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in acceptors])
+    job = C.c_void_p()
+    check(_lib.lib().wfst_compose_shortest_path_batch_begin(
+        ctx._h, arr, n, t._h, compose_config._c() if compose_config else None,
+        shortest_path_config._c() if shortest_path_config else None, C.byref(job)),
+        "wfst_compose_shortest_path_batch_begin")
+    return BatchJob(job, n, ctx, (list(acceptors), t, arr))
+
+
 def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
                                 compose_config: Optional["ComposeConfig"] = None,
-                                shortest_path_config: Optional["ShortestPathConfig"] = None):
+                                shortest_path_config: Optional["ShortestPathConfig"] = None,
+                                ctx: Optional[Context] = None):
     """for a in acceptors: shortest_path(compose(a, t)) as one device-resident pipeline.
     Returns (list of DeviceFst paths, total composed arcs before trimming)."""
     n = len(acceptors)
-    ctx = t.ctx
+    ctx = ctx or t.ctx
     arr = (C.c_void_p * n)(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in acceptors])
     outs = (C.c_void_p * n)()
     na = C.c_uint64()

@@ -593,3 +593,35 @@ def test_hcl_compose_g(gpu_ctx, oracle, hcl, g):
     assert_flat_identical(sp.to_flat(), oc.shortest_path_canonical().to_flat(), "shortest path of HCL o G")
     outs, _ = rustfst_amd.compose_shortest_path_batch([a], b)
     assert_flat_identical(outs[0].to_flat(), oa.compose(ob).shortest_path_canonical().to_flat(), "fused HCL o G")
+
+
+def test_async_batch_overlaps_with_shortest_path(gpu_ctx, oracle):
+    """begin/end form of the fused batch on a second context, with shortest_path(T) issued in between on the
+    first: both results are bit-identical to the synchronous calls and to the oracle."""
+    torch = pytest.importorskip("torch")
+    t = synth.make_transducer(20000, 6, 32, 0.0, seed=11)
+    accs = synth.make_acceptors(t, 24, 60, seed0=500)
+    ctx = rustfst_amd.default_context()
+    s2 = torch.cuda.Stream()
+    ctx2 = rustfst_amd.Context(0, stream=s2.cuda_stream)
+    dt = to_device(t, ctx)
+    daccs = rustfst_amd.DeviceFst.upload_many(accs, ctx2)
+    sync_outs, sync_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt, ctx=ctx2)
+    sync_sp = dt.shortest_path().to_flat()
+    for _ in range(3):
+        job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
+        with pytest.raises(rustfst_amd.WfstError, match="in flight"):
+            rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
+        sp = dt.shortest_path()
+        outs, n_arcs = job.finish()
+        assert n_arcs == sync_arcs
+        assert_flat_identical(sp.to_flat(), sync_sp, "shortest_path(T) while a batch is in flight")
+        for a, b in zip(outs, sync_outs):
+            assert_flat_identical(a.to_flat(), b.to_flat(), "async batch vs sync batch")
+    ot = to_oracle(oracle, t)
+    for i in (0, 7, 23):
+        ref = to_oracle(oracle, accs[i]).compose(ot).shortest_path_canonical().to_flat()
+        assert_flat_identical(outs[i].to_flat(), ref, f"async batch problem {i}")
+    with pytest.raises(rustfst_amd.WfstError):
+        job.finish()
+    del rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)._keep  # abandoned job is reclaimed
