@@ -42,16 +42,23 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
 // Near-far schedule (a Delta-stepping relative that needs no buckets): sweep k only relaxes active states
 // with d <= tau_k; the others stay in the frontier.  When a sweep activates nothing near, tau advances by
 // delta (doubling on consecutive empty sweeps so that gaps are crossed in log time).  All of it is decided on
-// the device from three words per sweep kept in a ring, so sweeps still launch back-to-back without a host
-// round trip, and without any same-address atomics (one conditional plain store per workgroup).
+// the device from a few words per sweep kept in a ring, so sweeps still launch back-to-back without a host
+// round trip.  When the near set is too small to fill the GPU (< near_low activations: such a sweep costs the
+// launch floor whatever it does) and shrinking — the tail of a band — the band is widened by delta at once
+// instead of draining through half a dozen near-empty sweeps.  Activations are counted with ONE atomicAdd per workgroup on a
+// counter sharded 16 ways (same-address atomics serialise at ~12 ns each).
 constexpr uint32_t RING = 256;
+constexpr uint32_t NEAR_SHARDS = 16;
+constexpr uint32_t NEAR_RING = 4;     // sweep k writes slot k % 4, reads k-1 and k-2, recycles k+1
+constexpr uint32_t NEAR_STRIDE = 32;  // one shard per 128-B line: atomics on one LINE serialise like one address
 constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, indexed by sweep % IMP_RING
 
 struct Ctl {
   uint32_t base;          // first sweep index of the batch being replayed (graph nodes add their static offset)
   uint32_t pad0;
   uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
-  uint32_t near[RING];    // sweep k activated at least one state with d <= tau_k
+  // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
+  uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
   uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
   unsigned long long arcs;    // arcs leaving the current frontier (profiling only)
   unsigned long long states;  // frontier states (profiling only)
@@ -63,13 +70,26 @@ struct Ctl {
 };
 
 // threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
-__device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t* streak) {
+// Called by one full wave (all 64 lanes): lanes 0..15 fetch the shards of sweep-1's counter, lanes 16..31 those of
+// sweep-2's, so the whole decision costs one load latency.
+__device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
+                                           uint32_t* streak) {
   *streak = 0;
   if (sweep == 0) return delta;
   const uint32_t p = (sweep - 1) % RING;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t mine = 0;
+  if (lane < NEAR_SHARDS) mine = ctl->near[(sweep - 1) % NEAR_RING][lane * NEAR_STRIDE];
+  else if (lane < 2 * NEAR_SHARDS && sweep >= 2) mine = ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE];
   const float prev = __uint_as_float(ctl->tau[p]);
-  if (ctl->near[p]) return prev;
-  const uint32_t st = min(ctl->streak[p] + 1u, 30u);
+  const uint32_t prev_streak = ctl->streak[p];
+  for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
+  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
+  if (cnt >= near_low) return prev;
+  // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
+  // widen the band by delta and keep relaxing
+  if (cnt) return cnt < before ? prev + delta : prev;
+  const uint32_t st = min(prev_streak + 1u, 30u);
   *streak = st;
   return prev + delta * (float)(1u << (st - 1u));
 }
@@ -79,9 +99,9 @@ __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint3
   flags0[start] = 1;
   for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
     ctl->tau[i] = 0;
-    ctl->near[i] = 0;
     ctl->streak[i] = 0;
   }
+  for (uint32_t i = threadIdx.x; i < NEAR_RING * NEAR_SHARDS * NEAR_STRIDE; i += blockDim.x) (&ctl->near[0][0])[i] = 0;
   if (threadIdx.x) return;
   ctl->base = 0;
   ctl->arcs = 0;
@@ -100,22 +120,33 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          uint8_t* __restrict__ flags_cur,
                                                          uint8_t* __restrict__ flags_next, uint32_t n,
                                                          uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
-                                                         uint32_t sweep_offset, float delta) {
+                                                         uint32_t sweep_offset, float delta, uint32_t near_low) {
   // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
   const uint32_t sweep = ctl->base + sweep_offset;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
-  __shared__ uint32_t s_bits;  // bit 0: some activity (improvement or deferral), bit 1: a near activation
-  uint32_t streak;
-  const float tau = sweep_tau(ctl, sweep, delta, &streak);
+  __shared__ uint32_t s_any;   // some activity (improvement or deferral) in this workgroup
+  __shared__ uint32_t s_near;  // near activations of this workgroup
+  __shared__ float s_tau;
   const uint32_t slot = sweep % RING;
-  if (threadIdx.x == 0) s_bits = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctl->tau[slot] = __float_as_uint(tau);
-    ctl->streak[slot] = streak;
-    ctl->near[(sweep + 1) % RING] = 0;  // recycle the slot the next sweep will fill
+  if (threadIdx.x < 64) {
+    uint32_t streak;
+    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak);
+    if (threadIdx.x == 0) {
+      s_tau = t0;
+      s_any = 0;
+      s_near = 0;
+    }
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) {
+        ctl->tau[slot] = __float_as_uint(t0);
+        ctl->streak[slot] = streak;
+      }
+      if (threadIdx.x < NEAR_SHARDS) ctl->near[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;  // recycle
+    }
   }
   __syncthreads();
-  bool near_any = false;
+  const float tau = s_tau;
+  uint32_t near_cnt = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = lane % GROUP;         // lane inside its group
   const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
@@ -126,10 +157,16 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
     const uint32_t sc = base + lane;
     bool act = sc < n && flags_cur[sc] != 0;
     if (__ballot(act) == 0) continue;
+    // the lane that owns an active state fetches everything the relaxation of that state needs: ONE memory
+    // round trip for the whole 64-state chunk; the groups below get it by shuffle
+    uint64_t my_ks = 0;
+    uint32_t my_b = 0, my_e = 0;
     if (act) {
       flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
-      const uint32_t ed = (uint32_t)(key[sc] >> 32);
-      if (dec_f32(ed) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
+      my_ks = key[sc];
+      my_b = offsets[sc];
+      my_e = offsets[sc + 1];
+      if (dec_f32((uint32_t)(my_ks >> 32)) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
         flags_next[sc] = 1;
         any = true;
         act = false;
@@ -137,42 +174,67 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
     }
     uint64_t mask = __ballot(act);
     while (mask) {
-      // the wave's 4 groups take the 4 lowest set bits
+      // each of the wave's 4 groups takes TWO states per round (the 8 lowest set bits): two independent
+      // load -> pre-check -> atomic chains per lane are in flight at once (the kernel is latency bound)
       const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
-      const uint64_t mine = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
-      mask = m3 & (m3 - 1);
-      if (mine == 0) continue;
-      const uint32_t s = base + (uint32_t)__ffsll((unsigned long long)mine) - 1u;
-      const uint64_t ks = key[s];
-      const float d = dec_f32((uint32_t)(ks >> 32));
-      const uint32_t h1 = (uint32_t)ks + 1u;
-      const uint32_t b = offsets[s], e = offsets[s + 1];
-      for (uint32_t i = b + sub; i < e; i += GROUP) {
-        const uint2 a = wn[i];
-        const float c = (d + __uint_as_float(a.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-        if (!(c < INF)) continue;                           // +inf never improves (shortest_path.rs:226)
-        const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
-        const uint32_t t = a.y;
-        if (ck < key[t]) {  // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
-          const uint64_t old = atomicMin((unsigned long long*)&key[t], (unsigned long long)ck);
-          if (ck < old) {
-            flags_next[t] = 1;
-            any = true;
-            near_any |= c <= tau;
-          }
+      const uint64_t m4 = m3 & (m3 - 1), m5 = m4 & (m4 - 1), m6 = m5 & (m5 - 1), m7 = m6 & (m6 - 1);
+      const uint64_t mine_a = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
+      const uint64_t mine_b = grp == 0 ? m4 : grp == 1 ? m5 : grp == 2 ? m6 : m7;
+      mask = m7 & (m7 - 1);
+      const bool has_a = mine_a != 0, has_b = mine_b != 0;
+      const int la = has_a ? __ffsll((unsigned long long)mine_a) - 1 : 0;
+      const int lb = has_b ? __ffsll((unsigned long long)mine_b) - 1 : 0;
+      const uint64_t ks_a = __shfl(my_ks, la), ks_b = __shfl(my_ks, lb);
+      uint32_t ia = __shfl(my_b, la) + sub, ib = __shfl(my_b, lb) + sub;
+      // (shuffles stay outside any lane-dependent condition: a bpermute reads 0 from a lane that is masked off)
+      const uint32_t ea_all = __shfl(my_e, la), eb_all = __shfl(my_e, lb);
+      const uint32_t ea = has_a ? ea_all : 0u, eb = has_b ? eb_all : 0u;
+      const float da = dec_f32((uint32_t)(ks_a >> 32)), db = dec_f32((uint32_t)(ks_b >> 32));
+      const uint32_t ha = (uint32_t)ks_a + 1u, hb = (uint32_t)ks_b + 1u;
+      while (__any(ia < ea || ib < eb)) {
+        const bool va = ia < ea, vb = ib < eb;
+        uint2 aa = make_uint2(0x7F800000u, 0u), ab = make_uint2(0x7F800000u, 0u);  // {+inf, state 0}: never relaxes
+        if (va) aa = wn[ia];
+        if (vb) ab = wn[ib];
+        const float ca = (da + __uint_as_float(aa.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+        const float cb = (db + __uint_as_float(ab.x)) + 0.0f;
+        const bool fa = va && ca < INF, fb = vb && cb < INF;  // +inf never improves (shortest_path.rs:226)
+        const uint64_t cka = ((uint64_t)enc_f32(ca) << 32) | ha, ckb = ((uint64_t)enc_f32(cb) << 32) | hb;
+        // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
+        uint64_t ka = 0, kb = 0;
+        if (fa) ka = key[aa.y];
+        if (fb) kb = key[ab.y];
+        const bool ta = fa && cka < ka, tb = fb && ckb < kb;
+        uint64_t olda = 0, oldb = 0;
+        if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
+        if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
+        if (ta && cka < olda) {
+          flags_next[aa.y] = 1;
+          any = true;
+          near_cnt += ca <= tau ? 1u : 0u;
         }
+        if (tb && ckb < oldb) {
+          flags_next[ab.y] = 1;
+          any = true;
+          near_cnt += cb <= tau ? 1u : 0u;
+        }
+        ia += GROUP;
+        ib += GROUP;
       }
     }
   }
-  // one conditional plain store per workgroup (thousands of same-address stores/atomics per sweep would
-  // serialise at ~12 ns each)
-  const uint32_t bits = (__any(any) ? 1u : 0u) | (__any(near_any) ? 2u : 0u);
-  if (lane == 0 && bits) atomicOr(&s_bits, bits);
+  // one conditional plain store + one sharded atomicAdd per workgroup (thousands of same-address atomics per
+  // sweep would serialise at ~12 ns each)
+  for (int d = 32; d >= 1; d >>= 1) near_cnt += __shfl_xor(near_cnt, d);
+  const bool wave_any = __any(any);
+  if (lane == 0) {
+    if (wave_any) s_any = 1u;
+    if (near_cnt) atomicAdd(&s_near, near_cnt);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t b = s_bits;
-    if ((b & 1u) && *improved == 0u) *improved = 1u;
-    if ((b & 2u) && ctl->near[slot] == 0u) ctl->near[slot] = 1u;
+    if (s_any && *improved == 0u) *improved = 1u;
+    if (s_near) atomicAdd(&ctl->near[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_near);
   }
 }
 
@@ -187,9 +249,9 @@ __global__ void sssp_advance_kernel(Ctl* ctl, uint32_t* improved_ring, uint32_t 
 // profiling helper (runs outside the timed events): size of the current frontier and of its arc set
 __global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags,
                                   const uint64_t* __restrict__ key, uint32_t n, Ctl* __restrict__ ctl, uint32_t sweep,
-                                  float delta) {
+                                  float delta, uint32_t near_low) {
   uint32_t streak_unused;
-  const float tau = sweep_tau(ctl, sweep, delta, &streak_unused);
+  const float tau = sweep_tau(ctl, sweep, delta, near_low, &streak_unused);
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long arcs = 0, states = 0;
   for (; s < n; s += gridDim.x * blockDim.x)
@@ -330,6 +392,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) delta = 1.5f * f->mean_weight;
   if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
   if (!(delta > 0.0f)) delta = INF;
+  uint32_t near_low = 4096;  // activations below which a sweep is launch-latency bound anyway
+  if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) near_low = (uint32_t)std::atol(e);
   const uint64_t sweep_cap = 4ull * n + 64;
   ctx->stats.sweeps = 0;
 
@@ -342,10 +406,10 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     uint64_t prev_arcs = 0, prev_states = 0;
     for (uint32_t k = 0;; ++k) {
       if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
-      sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta);
+      sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta, near_low);
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
       sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
-                                                sv.improved.p, sv.ctl.p, 0u, delta);
+                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low);
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -377,7 +441,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
       const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn, (uint64_t)sv.key.p, (uint64_t)sv.flags.p,
                                (uint64_t)sv.improved.p, (uint64_t)sv.ctl.p, ((uint64_t)n << 32) | __float_as_uint_host(delta),
-                               (uint64_t)(h_imp + which * IMP_RING)};
+                               (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
       if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
       if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
       if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
@@ -392,11 +456,12 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       uint32_t* a_imp = sv.improved.p;
       Ctl* a_ctl = sv.ctl.p;
       float a_delta = delta;
+      uint32_t a_low = near_low;
       for (uint32_t j = 0; j < count; ++j) {  // batches start at multiples of their size: flag parity is static
         uint8_t* a_fc = fl[j & 1u];
         uint8_t* a_fn = fl[(j & 1u) ^ 1u];
         uint32_t a_off = j;
-        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta};
+        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low};
         hipKernelNodeParams kp{};
         kp.func = (void*)sssp_relax_kernel;
         kp.gridDim = dim3(blocks);

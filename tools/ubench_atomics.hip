@@ -25,6 +25,11 @@ __global__ void k(uint64_t* a64, uint32_t* a32, const uint32_t* idx, uint32_t n_
     if (MODE == 7) { if (v < a64[t]) acc += atomicMin((unsigned long long*)&a64[t], (unsigned long long)v); }  // precheck + min
     if (MODE == 8) { acc += __hip_atomic_fetch_min(&a64[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // wg-scope
     if (MODE == 9) { acc += atomicExch(&a32[t], (uint32_t)v); }
+    // XCD-private partitions: block b runs on XCD b % 8 (observed mapping); partition = bits 4..6 of the index (128-B lines)
+    if (MODE == 10) { uint32_t tp = (t & ~(7u << 4)) | ((blockIdx.x & 7u) << 4); acc += __hip_atomic_fetch_min(&a64[tp], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    if (MODE == 11) { uint32_t tp = (t & ~(7u << 4)) | ((blockIdx.x & 7u) << 4); acc += atomicMin((unsigned long long*)&a64[tp], (unsigned long long)v); }
+    if (MODE == 12) { uint32_t tp = (t & ~(7u << 4)) | ((blockIdx.x & 7u) << 4); acc += a64[tp]; }
+    if (MODE == 13) { uint32_t tp = (t & ~(7u << 4)) | ((blockIdx.x & 7u) << 4); if (v < a64[tp]) a64[tp] = v; }
   }
   if (acc == 0x1234567) sink[0] = acc;
 }
@@ -38,8 +43,8 @@ int main() {
   for (uint32_t i = 0; i < n_ops; ++i) { s = s * 6364136223846793005ull + 1442695040888963407ull; h[i] = (uint32_t)(s >> 33) % n; }
   CK(hipMemcpy(idx, h.data(), n_ops * 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const char* names[] = {"atomicMin u64 ret", "atomicMin u64 noret", "atomicMin u32 ret", "atomicMin u32 noret", "gather u64", "scatter u64", "gather u32", "precheck+atomicMin u64 (2nd pass: mostly fails)", "fetch_min u64 workgroup scope", "atomicExch u32 ret"};
-  for (int mode = 0; mode < 10; ++mode) {
+  const char* names[] = {"atomicMin u64 ret", "atomicMin u64 noret", "atomicMin u32 ret", "atomicMin u32 noret", "gather u64", "scatter u64", "gather u32", "precheck+atomicMin u64 (2nd pass: mostly fails)", "fetch_min u64 workgroup scope", "atomicExch u32 ret", "XCD-private lines: fetch_min u64 wg scope", "XCD-private lines: atomicMin u64 device scope", "XCD-private lines: gather u64", "XCD-private lines: racy check+store u64"};
+  for (int mode = 0; mode < 14; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipMemset(a64, 0xFF, n * 8)); CK(hipMemset(a32, 0xFF, n * 4));
       if (mode == 7) { k<0><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); }
@@ -56,6 +61,10 @@ int main() {
         case 7: k<7><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
         case 8: k<8><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
         case 9: k<9><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
+        case 10: k<10><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
+        case 11: k<11><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
+        case 12: k<12><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
+        case 13: k<13><<<2048, 256>>>(a64, a32, idx, n_ops, n, sink); break;
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
