@@ -162,7 +162,11 @@ struct wfst_fst {
   HostCsr host;
   DeviceCsr dev;
   // reverse(fst) (reverse.rs:33-87) as host CSR: built on the GPU on first use by the n>1 shortest-path search
-  std::shared_ptr<HostCsr> rev_host;
+  mutable std::shared_ptr<HostCsr> rev_host;
+  // bin layout of the relaxation's candidate bins (sssp.hip MODE_BINS): prefix sums of the in-degree of every
+  // partition of 4096 states; derived from the arcs on first use
+  mutable std::shared_ptr<wfst::DBuf<uint32_t>> pb_bin_off;
+  mutable uint32_t pb_parts = 0;
 };
 
 namespace wfst {

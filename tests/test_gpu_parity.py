@@ -625,3 +625,21 @@ def test_async_batch_overlaps_with_shortest_path(gpu_ctx, oracle):
     with pytest.raises(rustfst_amd.WfstError):
         job.finish()
     del rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)._keep  # abandoned job is reclaimed
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_shortest_path_binned_sweeps_match_oracle(gpu_ctx, oracle, seed, monkeypatch):
+    """The experimental workgroup-owned-partition ("propagation blocking") sweeps, forced on for every sweep:
+    same canonical result as the oracle, bit for bit (several partitions, near-far on and off)."""
+    monkeypatch.setenv("WFST_SSSP_BINS", "1")
+    monkeypatch.setenv("WFST_SSSP_BINS_MIN_STATES", "0")
+    monkeypatch.setenv("WFST_SSSP_BINS_LOW", "0" if seed % 2 == 0 else "64")
+    if seed >= 2:
+        monkeypatch.setenv("WFST_SSSP_DELTA", "1.5")
+    t = synth.make_transducer(20000 + 3000 * seed, 6, 32, 0.05 * (seed % 2), seed=70 + seed)
+    d = to_device(t)
+    o = to_oracle(oracle, t)
+    ref = o.shortest_path_canonical()
+    assert_flat_identical(d.shortest_path().to_flat(), ref.to_flat(), f"binned sweeps seed {seed}")
+    dist, hops = d.shortest_distance(want_hops=True)
+    np.testing.assert_array_equal(dist.view(np.uint32), np.asarray(ref.distance, dtype=np.float32).view(np.uint32))
