@@ -143,6 +143,13 @@ struct DeviceCsr {
   const uint4* srec = nullptr;        // [n] {arc begin, arc count, final bits, noeps}: one 16-B load per state in compose
 };
 
+namespace wfst {
+struct RevCsr {
+  DBuf<uint32_t> off;  // [n+1]
+  DBuf<uint2> arc;     // [E] {source state, position of the arc in the source's arc list}
+};
+}  // namespace wfst
+
 struct HostCsr {
   std::vector<uint32_t> offsets;
   std::vector<wfst_tr> arcs;
@@ -163,10 +170,10 @@ struct wfst_fst {
   DeviceCsr dev;
   // reverse(fst) (reverse.rs:33-87) as host CSR: built on the GPU on first use by the n>1 shortest-path search
   mutable std::shared_ptr<HostCsr> rev_host;
-  // bin layout of the relaxation's candidate bins (sssp.hip MODE_BINS): prefix sums of the in-degree of every
-  // partition of 4096 states; derived from the arcs on first use
-  mutable std::shared_ptr<wfst::DBuf<uint32_t>> pb_bin_off;
-  mutable uint32_t pb_parts = 0;
+  // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second
+  // shortest_path query of a large FST (sssp.hip reverse_csr)
+  mutable std::shared_ptr<wfst::RevCsr> rev_dev;
+  mutable uint32_t sp_queries = 0;
 };
 
 namespace wfst {

@@ -23,6 +23,8 @@
 //   - after the level, first occurrences are ranked with ballots: new ids = reference BFS ids.
 // Everything stays in HBM/L2 between phases: the fused pipeline (compose -> relax -> backtrace) never
 // returns to the host.
+#include <chrono>
+
 #include "common.h"
 #include "fst_props.h"
 
@@ -998,12 +1000,17 @@ struct BatchRun {
   DBuf<uint32_t> d_cursor;
   Result* h_res = nullptr;      // pinned (ctx->pinned_big): one batch in flight per context
   uint32_t* h_cursor = nullptr;
+  // the first `eager` path records are copied to pinned memory right behind the kernel (no second round trip when
+  // the paths fit, which they do unless T has input-epsilon cycles that stretch a path beyond its acceptor)
+  wfst_tr* h_eager = nullptr;
+  uint32_t eager = 0;
+  const wfst_tr* host_paths = nullptr;
 };
 
 // Enqueues descriptors, the kernel and the result copies on ctx's stream and returns without waiting.
 template <uint32_t FLAGS>
 void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
-                  bool want_paths) {
+                  bool want_paths, uint32_t eager_paths = 0) {
   const size_t n = descs.size();
   DevicePool& pool = *ctx->pool;
   hipStream_t st = ctx->stream;
@@ -1018,7 +1025,9 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   const uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
   run.path_cap = path_cap;
   run.paths = DBuf<wfst_tr>(pool, path_cap);
-  ProblemDesc* h_desc = (ProblemDesc*)ctx->pinned_big.get(n * sizeof(ProblemDesc) + n * sizeof(Result) + 64);
+  run.eager = want_paths ? std::min(eager_paths, path_cap) : 0u;
+  ProblemDesc* h_desc = (ProblemDesc*)ctx->pinned_big.get(n * sizeof(ProblemDesc) + n * sizeof(Result) + 64 +
+                                                          (size_t)run.eager * sizeof(wfst_tr));
   std::memcpy(h_desc, descs.data(), n * sizeof(ProblemDesc));
   HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(run.d_cursor.p, 0, sizeof(uint32_t), st));
@@ -1031,6 +1040,9 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   run.h_cursor = (uint32_t*)((char*)run.h_res + n * sizeof(Result));
   HIP_CHECK(hipMemcpyAsync(run.h_res, run.d_res.p, n * sizeof(Result), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(run.h_cursor, run.d_cursor.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  run.h_eager = (wfst_tr*)((char*)run.h_cursor + 64);
+  if (run.eager)
+    HIP_CHECK(hipMemcpyAsync(run.h_eager, run.paths.p, (size_t)run.eager * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
 }
 
 // Waits for the batch enqueued by launch_begin and brings results (and the path arcs) to the host.
@@ -1059,10 +1071,13 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
 #endif
   if (want_paths) {
     const uint32_t used = std::min<uint32_t>(*h_cursor, path_cap);
-    run.h_paths.resize(used);
-    if (used) {
+    if (used <= run.eager) {
+      run.host_paths = run.h_eager;
+    } else {
+      run.h_paths.resize(used);
       HIP_CHECK(hipMemcpyAsync(run.h_paths.data(), run.paths.p, (size_t)used * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
+      run.host_paths = run.h_paths.data();
     }
   }
 }
@@ -1077,29 +1092,22 @@ void launch(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView&
 // builds the reference's linear shortest-path FST (see sssp.hip::build_path_fst)
 wfst_fst* path_to_fst(wfst_ctx* ctx, const Result& r, const wfst_tr* path_arcs) {
   HostCsr h;
-  uint64_t p = props::NULL_PROPS;
   uint32_t n_states = 0;
   int64_t start = -1;
-  h.offsets.push_back(0);
   if (r.has_path) {
     n_states = r.hops + 1;
     h.finals.assign(n_states, INF);
-    for (uint32_t k = 0; k <= r.hops; ++k) {
-      p = props::add_state(p);
-      if (k == 0) {
-        h.finals[0] = r.final_weight;
-        p = props::set_final(p, nullptr, &r.final_weight);
-      } else {
-        h.arcs.push_back(path_arcs[k - 1]);
-        p = props::add_tr(p, k, path_arcs[k - 1], nullptr);
-      }
-      h.offsets.push_back((uint32_t)h.arcs.size());
-    }
+    h.finals[0] = r.final_weight;
+    if (r.hops) h.arcs.assign(path_arcs, path_arcs + r.hops);
+    h.offsets.resize((size_t)n_states + 1);
+    h.offsets[0] = 0;
+    for (uint32_t k = 0; k <= r.hops; ++k) h.offsets[k + 1] = k;
     start = r.hops;
-    p = props::set_start(p);
+  } else {
+    h.offsets.push_back(0);
   }
-  p = props::shortest_path(p, true) & props::ALL;
-  return make_host_fst(ctx, n_states, start, p, std::move(h));
+  return make_host_fst(ctx, n_states, start, props::linear_path_props(r.has_path != 0, r.hops, r.final_weight, path_arcs),
+                       std::move(h));
 }
 
 const char* status_name(uint32_t s) {
@@ -1202,7 +1210,10 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   }
   job->est_s = 4ull * max_states + 256;
   job->est_a = 2ull * job->est_s;
-  launch_begin<FLAG_SP>(ctx, job->descs, job->v2, make_caps(job->est_s, job->est_a), job->run, true);
+  uint64_t eager = 0;  // a path through A_i o T has at most |A_i| - 1 arcs unless T loops on input epsilons
+  for (size_t i = 0; i < n; ++i) eager += accs[i]->n_states;
+  launch_begin<FLAG_SP>(ctx, job->descs, job->v2, make_caps(job->est_s, job->est_a), job->run, true,
+                        (uint32_t)std::min<uint64_t>(eager, 1u << 22));
   return job.release();
 }
 
@@ -1215,9 +1226,14 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
   for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
   uint64_t tot_arcs = 0, tot_states = 0;
   double ms = 0;
+  const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
   try {
     for (int attempt = 0;; ++attempt) {
       launch_end(ctx, job->run);
+      auto t_b = tnow();
+      if (timing) std::fprintf(stderr, "[batch_end] wait+copy %.1f us\n", std::chrono::duration<double, std::micro>(t_b - t_a).count());
       ms += ctx->stats.compose_ms;
       std::vector<size_t> again;
       for (size_t k = 0; k < job->todo.size(); ++k) {
@@ -1228,8 +1244,9 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
         }
         tot_arcs += r.n_arcs;
         tot_states += r.n_states;
-        outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.h_paths.data() + r.path_off : nullptr);
+        outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
       }
+      if (timing) std::fprintf(stderr, "[batch_end] assemble %.1f us\n", std::chrono::duration<double, std::micro>(tnow() - t_b).count());
       job->todo.swap(again);
       if (job->todo.empty()) break;
       ctx->stats.compose_retries++;

@@ -45,57 +45,23 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
 // the device from a few words per sweep kept in a ring, so sweeps still launch back-to-back without a host
 // round trip.  When the near set is too small to fill the GPU (< near_low activations: such a sweep costs the
 // launch floor whatever it does) and shrinking — the tail of a band — the band is widened by delta at once
-// instead of draining through half a dozen near-empty sweeps.  Activations are counted with ONE atomicAdd per
-// workgroup on a counter sharded 16 ways, one shard per 128-B line (atomics on one LINE serialise at ~12 ns each).
+// instead of draining through half a dozen near-empty sweeps.  Activations are counted with ONE atomicAdd per workgroup on a
+// counter sharded 16 ways (same-address atomics serialise at ~12 ns each).
 constexpr uint32_t RING = 256;
 constexpr uint32_t NEAR_SHARDS = 16;
 constexpr uint32_t NEAR_RING = 4;     // sweep k writes slot k % 4, reads k-1 and k-2, recycles k+1
-constexpr uint32_t NEAR_STRIDE = 32;  // one shard per 128-B line
-constexpr uint32_t IMP_RING = 512;    // per-sweep "something happened" flags, indexed by sweep % IMP_RING
-
-// How a sweep hands its candidates (t, d[s] + w, hops[s] + 1) to the target states:
-//  MODE_ATOMIC  atomicMin on key[t] after a plain pre-check.  Bound by the atomic rate of the memory system
-//               (26.5 G/s on MI355X whatever the width, scope or locality: tools/ubench_atomics.hip), fine for
-//               the many small sweeps.
-//  MODE_BINS    "propagation blocking": the state space is cut into partitions of PB_PART states, workgroup p OWNS
-//               partition p.  A sweep appends every candidate to the bin of its target's partition (12-B records,
-//               space reserved per (workgroup, bin) from a two-pass LDS histogram); the NEXT sweep's workgroup p
-//               first merges bin p into its partition with ds_min_u64 on an LDS copy of the keys, writes back the
-//               improved keys and frontier flags, then scans its own partition.  No global atomics on keys, no
-//               random gathers: arcs, candidates and keys all stream.  Used for the big sweeps.
-enum : uint32_t { MODE_ATOMIC = 0, MODE_BINS = 1 };
-constexpr uint32_t PB_SHIFT = 12;
-constexpr uint32_t PB_PART = 1u << PB_SHIFT;              // states owned by one workgroup (32 KB of keys in LDS)
-constexpr uint32_t PB_THREADS = 1024;
-constexpr uint32_t PB_WAVES = PB_THREADS / 64;            // 16
-constexpr uint32_t PB_CHUNKS = PB_PART / 64 / PB_WAVES;   // 64-state chunks scanned by each wave: 4
-constexpr uint32_t PB_MAX_PARTS = 2048;                   // LDS histogram size: n <= 8.4M states
-constexpr uint32_t PB_OFF = 0xFFFFFFFFu;                  // pb_low value that disables MODE_BINS
-
-struct Cand {
-  uint32_t enc, hops, t;  // candidate key (enc(d) : hops) for state t
-};
-
-struct PbArgs {
-  uint32_t* tails;          // [2][parts]: candidates waiting in each bin of buffer (sweep & 1)
-  const uint32_t* bin_off;  // [parts + 1]: bin q = [bin_off[q], bin_off[q+1]) — sized by the in-degree of partition q
-  Cand* cand;               // [2][cand_stride]
-  uint64_t cand_stride;     // = number of arcs (a sweep emits at most one candidate per arc)
-  uint32_t parts;
-  uint32_t pb_low;          // estimated activations from which a sweep goes through the bins; PB_OFF = never
-};
+constexpr uint32_t NEAR_STRIDE = 32;  // one shard per 128-B line: atomics on one LINE serialise like one address
+constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, indexed by sweep % IMP_RING
 
 struct Ctl {
   uint32_t base;          // first sweep index of the batch being replayed (graph nodes add their static offset)
   uint32_t pad0;
   uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
-  uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
-  uint32_t mode[RING];    // how sweep k emitted its candidates
-  // activations with d <= tau_k made by sweep k / states left in the far set by sweep k: counters sharded 16
-  // ways, shard j at [j * NEAR_STRIDE].  (A MODE_BINS sweep counts candidates / 4: it cannot know which improve.)
+  // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
   uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
-  uint32_t far[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
-  unsigned long long prof[NEAR_SHARDS][16];  // [shard][0] arcs relaxed, [shard][1] frontier states relaxed (cumulative)
+  uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
+  unsigned long long arcs;    // arcs leaving the current frontier (profiling only)
+  unsigned long long states;  // frontier states (profiling only)
   unsigned long long best;    // enc(total) << 32 | final state
   // backtrace header
   uint32_t f_parent, hops;
@@ -103,215 +69,52 @@ struct Ctl {
   uint32_t has_path, pad;
 };
 
-struct SweepPlan {
-  float tau;
-  uint32_t streak, mode, prev_mode;
-};
-
-// Threshold and emission mode of sweep k from what sweeps k-1 and k-2 left in the rings.  Called by one full
-// wave (all 64 lanes): lanes 0..15 fetch the shards of near[k-1], 16..31 those of near[k-2], 32..47 far[k-1], so the
-// whole decision costs one load latency.  Every workgroup computes the same plan.
-__device__ __forceinline__ SweepPlan sweep_plan(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
-                                                uint32_t pb_low) {
-  SweepPlan pl{delta, 0u, MODE_ATOMIC, MODE_ATOMIC};
-  if (sweep == 0) return pl;
+// threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
+// Called by one full wave (all 64 lanes): lanes 0..15 fetch the shards of sweep-1's counter, lanes 16..31 those of
+// sweep-2's, so the whole decision costs one load latency.
+__device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
+                                           uint32_t* streak) {
+  *streak = 0;
+  if (sweep == 0) return delta;
   const uint32_t p = (sweep - 1) % RING;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t mine = 0;
   if (lane < NEAR_SHARDS) mine = ctl->near[(sweep - 1) % NEAR_RING][lane * NEAR_STRIDE];
-  else if (lane < 2 * NEAR_SHARDS) mine = sweep >= 2 ? ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE] : 0u;
-  else if (lane < 3 * NEAR_SHARDS) mine = ctl->far[(sweep - 1) % NEAR_RING][(lane - 2 * NEAR_SHARDS) * NEAR_STRIDE];
+  else if (lane < 2 * NEAR_SHARDS && sweep >= 2) mine = ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE];
   const float prev = __uint_as_float(ctl->tau[p]);
   const uint32_t prev_streak = ctl->streak[p];
-  pl.prev_mode = ctl->mode[p];
   for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
-  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16), far = __shfl(mine, 32);
-  bool advance = false;
-  if (cnt >= near_low) {
-    pl.tau = prev;
-  } else if (cnt) {
-    // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
-    // widen the band by delta and keep relaxing
-    advance = cnt < before;
-    pl.tau = advance ? prev + delta : prev;
-  } else {
-    const uint32_t st = min(prev_streak + 1u, 30u);
-    pl.streak = st;
-    pl.tau = prev + delta * (float)(1u << (st - 1u));
-    advance = true;
-  }
-  const uint64_t est = (uint64_t)cnt + (advance ? far : 0u);  // activations this sweep will find in its frontier
-  pl.mode = (pb_low != PB_OFF && est >= pb_low) ? MODE_BINS : MODE_ATOMIC;
-  return pl;
+  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
+  if (cnt >= near_low) return prev;
+  // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
+  // widen the band by delta and keep relaxing
+  if (cnt) return cnt < before ? prev + delta : prev;
+  const uint32_t st = min(prev_streak + 1u, 30u);
+  *streak = st;
+  return prev + delta * (float)(1u << (st - 1u));
 }
 
 __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start) {
-  // ctl was zeroed by a memset
   key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
   flags0[start] = 1;
+  for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
+    ctl->tau[i] = 0;
+    ctl->streak[i] = 0;
+  }
+  for (uint32_t i = threadIdx.x; i < NEAR_RING * NEAR_SHARDS * NEAR_STRIDE; i += blockDim.x) (&ctl->near[0][0])[i] = 0;
+  if (threadIdx.x) return;
+  ctl->base = 0;
+  ctl->arcs = 0;
+  ctl->states = 0;
   ctl->best = KEY_INF;
+  ctl->has_path = 0;
 }
 
-struct SweepCounts {
-  uint32_t near = 0, far = 0, states = 0, arcs = 0;
-  bool any = false;
-};
-
-// Loads a 64-state chunk of the frontier: the lane that owns an active state fetches everything the relaxation of
-// that state needs (ONE memory round trip for the whole chunk; the groups get it by shuffle later), clears its
-// flag, and re-files the state in the next frontier when it is beyond tau.  Returns the mask of states to relax.
-__device__ __forceinline__ uint64_t load_chunk(uint32_t base, uint32_t lane, uint32_t n, const uint32_t* __restrict__ offsets,
-                                               const uint64_t* __restrict__ key, uint8_t* __restrict__ flags_cur,
-                                               uint8_t* __restrict__ flags_next, float tau, uint64_t& my_ks, uint32_t& my_b,
-                                               uint32_t& my_e, SweepCounts& cn, uint32_t flag) {
-  const uint32_t sc = base + lane;
-  bool act = flag != 0;
-  my_ks = 0;
-  my_b = 0;
-  my_e = 0;
-  if (__ballot(act) == 0) return 0;
-  if (act) {
-    flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
-    my_ks = key[sc];
-    my_b = offsets[sc];
-    my_e = offsets[sc + 1];
-    if (dec_f32((uint32_t)(my_ks >> 32)) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
-      flags_next[sc] = 1;
-      cn.any = true;
-      cn.far += 1;
-      act = false;
-    } else {
-      cn.states += 1;
-      cn.arcs += my_e - my_b;
-    }
-  }
-  return __ballot(act);
-}
-
-// MODE_ATOMIC emission for one chunk.  GROUP lanes share a state so that its arcs (contiguous 8-B {w,next} records)
-// are read by consecutive lanes; each of the wave's 4 groups takes TWO states per round, so two independent
-// load -> pre-check -> atomic chains per lane are in flight at once (these sweeps are latency bound).
-__device__ __forceinline__ void relax_chunk_atomic(uint64_t mask, uint32_t lane, uint64_t my_ks, uint32_t my_b, uint32_t my_e,
-                                                   const uint2* __restrict__ wn, uint64_t* __restrict__ key,
-                                                   uint8_t* __restrict__ flags_next, float tau, SweepCounts& cn) {
-  const uint32_t sub = lane % GROUP;  // lane inside its group
-  const uint32_t grp = lane / GROUP;  // group inside the wave (0..3)
-  while (mask) {
-    const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
-    const uint64_t m4 = m3 & (m3 - 1), m5 = m4 & (m4 - 1), m6 = m5 & (m5 - 1), m7 = m6 & (m6 - 1);
-    const uint64_t mine_a = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
-    const uint64_t mine_b = grp == 0 ? m4 : grp == 1 ? m5 : grp == 2 ? m6 : m7;
-    mask = m7 & (m7 - 1);
-    const bool has_a = mine_a != 0, has_b = mine_b != 0;
-    const int la = has_a ? __ffsll((unsigned long long)mine_a) - 1 : 0;
-    const int lb = has_b ? __ffsll((unsigned long long)mine_b) - 1 : 0;
-    // (shuffles stay outside any lane-dependent condition: a bpermute reads 0 from a lane that is masked off)
-    const uint64_t ks_a = __shfl(my_ks, la), ks_b = __shfl(my_ks, lb);
-    uint32_t ia = __shfl(my_b, la) + sub, ib = __shfl(my_b, lb) + sub;
-    const uint32_t ea_all = __shfl(my_e, la), eb_all = __shfl(my_e, lb);
-    const uint32_t ea = has_a ? ea_all : 0u, eb = has_b ? eb_all : 0u;
-    const float da = dec_f32((uint32_t)(ks_a >> 32)), db = dec_f32((uint32_t)(ks_b >> 32));
-    const uint32_t ha = (uint32_t)ks_a + 1u, hb = (uint32_t)ks_b + 1u;
-    while (__any(ia < ea || ib < eb)) {
-      const bool va = ia < ea, vb = ib < eb;
-      uint2 aa = make_uint2(0x7F800000u, 0u), ab = make_uint2(0x7F800000u, 0u);  // {+inf, state 0}: never relaxes
-      if (va) aa = wn[ia];
-      if (vb) ab = wn[ib];
-      const float ca = (da + __uint_as_float(aa.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-      const float cb = (db + __uint_as_float(ab.x)) + 0.0f;
-      const bool fa = va && ca < INF, fb = vb && cb < INF;  // +inf never improves (shortest_path.rs:226)
-      const uint64_t cka = ((uint64_t)enc_f32(ca) << 32) | ha, ckb = ((uint64_t)enc_f32(cb) << 32) | hb;
-      // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
-      uint64_t ka = 0, kb = 0;
-      if (fa) ka = key[aa.y];
-      if (fb) kb = key[ab.y];
-      const bool ta = fa && cka < ka, tb = fb && ckb < kb;
-      uint64_t olda = 0, oldb = 0;
-      if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
-      if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
-      if (ta && cka < olda) {
-        flags_next[aa.y] = 1;
-        cn.any = true;
-        if (ca <= tau) cn.near += 1; else cn.far += 1;
-      }
-      if (tb && ckb < oldb) {
-        flags_next[ab.y] = 1;
-        cn.any = true;
-        if (cb <= tau) cn.near += 1; else cn.far += 1;
-      }
-      ia += GROUP;
-      ib += GROUP;
-    }
-  }
-}
-
-struct SweepShared {
-  uint32_t any, near, far, states, arcs, mode, prev_mode;
-  float tau;
-};
-
-// wave 0 plans the sweep; workgroup 0 publishes the plan and recycles the next sweep's counter slots
-__device__ __forceinline__ void sweep_prologue(Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low, uint32_t pb_low,
-                                               SweepShared& sh) {
-  if (threadIdx.x < 64) {
-    const SweepPlan pl = sweep_plan(ctl, sweep, delta, near_low, pb_low);
-    if (threadIdx.x == 0) {
-      sh.tau = pl.tau;
-      sh.mode = pl.mode;
-      sh.prev_mode = pl.prev_mode;
-      sh.any = sh.near = sh.far = sh.states = sh.arcs = 0;
-    }
-    if (blockIdx.x == 0) {
-      const uint32_t slot = sweep % RING;
-      if (threadIdx.x == 0) {
-        ctl->tau[slot] = __float_as_uint(pl.tau);
-        ctl->streak[slot] = pl.streak;
-        ctl->mode[slot] = pl.mode;
-      }
-      if (threadIdx.x < NEAR_SHARDS) {
-        ctl->near[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;
-        ctl->far[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// one conditional plain store + a few sharded atomicAdds per workgroup
-__device__ __forceinline__ void sweep_epilogue(Ctl* ctl, uint32_t* improved, uint32_t sweep, SweepCounts cn, SweepShared& sh) {
-  const uint32_t lane = threadIdx.x & 63u;
-  for (int d = 32; d >= 1; d >>= 1) {
-    cn.near += __shfl_xor(cn.near, d);
-    cn.far += __shfl_xor(cn.far, d);
-    cn.states += __shfl_xor(cn.states, d);
-    cn.arcs += __shfl_xor(cn.arcs, d);
-  }
-  const bool wave_any = __any(cn.any);
-  if (lane == 0) {
-    if (wave_any) sh.any = 1u;
-    if (cn.near) atomicAdd(&sh.near, cn.near);
-    if (cn.far) atomicAdd(&sh.far, cn.far);
-    if (cn.states) {
-      atomicAdd(&sh.states, cn.states);
-      atomicAdd(&sh.arcs, cn.arcs);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t shard = blockIdx.x % NEAR_SHARDS;
-    if (sh.any && *improved == 0u) *improved = 1u;
-    if (sh.near) atomicAdd(&ctl->near[sweep % NEAR_RING][shard * NEAR_STRIDE], sh.near);
-    if (sh.far) atomicAdd(&ctl->far[sweep % NEAR_RING][shard * NEAR_STRIDE], sh.far);
-    if (sh.states) {
-      atomicAdd(&ctl->prof[shard][0], (unsigned long long)sh.arcs);
-      atomicAdd(&ctl->prof[shard][1], (unsigned long long)sh.states);
-    }
-  }
-}
-
-// One sweep, MODE_ATOMIC only (small FSTs, or bins switched off): relax every arc leaving the near frontier.
-// The frontier is a byte flag per state (idempotent plain stores: no queue, no dedupe atomics); a wave scans 64
-// flags with one coalesced load + ballot.
+// One sweep: relax every arc leaving the current frontier.
+// The frontier is a byte flag per state (idempotent plain stores: no queue, no dedupe atomics); a wave
+// scans 64 flags with one coalesced load + ballot, then GROUP lanes share each active state so its arcs
+// (contiguous 8-B {w,next} records) are read by consecutive lanes.  The only atomic is the atomicMin of
+// relaxations that pass the plain pre-check.
 __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restrict__ offsets,
                                                          const uint2* __restrict__ wn, uint64_t* __restrict__ key,
                                                          uint8_t* __restrict__ flags_cur,
@@ -320,185 +123,154 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          uint32_t sweep_offset, float delta, uint32_t near_low) {
   // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
   const uint32_t sweep = ctl->base + sweep_offset;
-  __shared__ SweepShared sh;
-  sweep_prologue(ctl, sweep, delta, near_low, PB_OFF, sh);
-  const float tau = sh.tau;
+  uint32_t* improved = improved_ring + (sweep % IMP_RING);
+  __shared__ uint32_t s_any;   // some activity (improvement or deferral) in this workgroup
+  __shared__ uint32_t s_near;  // near activations of this workgroup
+  __shared__ float s_tau;
+  const uint32_t slot = sweep % RING;
+  if (threadIdx.x < 64) {
+    uint32_t streak;
+    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak);
+    if (threadIdx.x == 0) {
+      s_tau = t0;
+      s_any = 0;
+      s_near = 0;
+    }
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) {
+        ctl->tau[slot] = __float_as_uint(t0);
+        ctl->streak[slot] = streak;
+      }
+      if (threadIdx.x < NEAR_SHARDS) ctl->near[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;  // recycle
+    }
+  }
+  __syncthreads();
+  const float tau = s_tau;
+  uint32_t near_cnt = 0;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = lane % GROUP;         // lane inside its group
+  const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-  SweepCounts cn;
+  bool any = false;
   for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
-    uint64_t my_ks;
-    uint32_t my_b, my_e;
-    const uint32_t flag = base + lane < n ? flags_cur[base + lane] : 0u;
-    const uint64_t mask = load_chunk(base, lane, n, offsets, key, flags_cur, flags_next, tau, my_ks, my_b, my_e, cn, flag);
-    relax_chunk_atomic(mask, lane, my_ks, my_b, my_e, wn, key, flags_next, tau, cn);
-  }
-  sweep_epilogue(ctl, improved_ring + (sweep % IMP_RING), sweep, cn, sh);
-}
-
-// visits the arcs of the states in `mask` (8 states per round: two per group of GROUP lanes, so that two arc loads
-// per lane are in flight) and calls fn(candidate weight, hops, target)
-template <class F>
-__device__ __forceinline__ void for_each_candidate(uint64_t mask, uint32_t lane, uint64_t my_ks, uint32_t my_b, uint32_t my_e,
-                                                   const uint2* __restrict__ wn, F&& fn) {
-  const uint32_t sub = lane % GROUP, grp = lane / GROUP;
-  while (mask) {
-    const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
-    const uint64_t m4 = m3 & (m3 - 1), m5 = m4 & (m4 - 1), m6 = m5 & (m5 - 1), m7 = m6 & (m6 - 1);
-    const uint64_t mine_a = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
-    const uint64_t mine_b = grp == 0 ? m4 : grp == 1 ? m5 : grp == 2 ? m6 : m7;
-    mask = m7 & (m7 - 1);
-    const bool has_a = mine_a != 0, has_b = mine_b != 0;
-    const int la = has_a ? __ffsll((unsigned long long)mine_a) - 1 : 0;
-    const int lb = has_b ? __ffsll((unsigned long long)mine_b) - 1 : 0;
-    const uint64_t ks_a = __shfl(my_ks, la), ks_b = __shfl(my_ks, lb);
-    uint32_t ia = __shfl(my_b, la) + sub, ib = __shfl(my_b, lb) + sub;
-    const uint32_t ea_all = __shfl(my_e, la), eb_all = __shfl(my_e, lb);
-    const uint32_t ea = has_a ? ea_all : 0u, eb = has_b ? eb_all : 0u;
-    const float da = dec_f32((uint32_t)(ks_a >> 32)), db = dec_f32((uint32_t)(ks_b >> 32));
-    const uint32_t ha = (uint32_t)ks_a + 1u, hb = (uint32_t)ks_b + 1u;
-    while (__any(ia < ea || ib < eb)) {
-      const bool va = ia < ea, vb = ib < eb;
-      uint2 aa = make_uint2(0x7F800000u, 0u), ab = make_uint2(0x7F800000u, 0u);
-      if (va) aa = wn[ia];
-      if (vb) ab = wn[ib];
-      const float ca = (da + __uint_as_float(aa.x)) + 0.0f, cb = (db + __uint_as_float(ab.x)) + 0.0f;
-      if (va && ca < INF) fn(ca, ha, aa.y);
-      if (vb && cb < INF) fn(cb, hb, ab.y);
-      ia += GROUP;
-      ib += GROUP;
-    }
-  }
-}
-
-// One sweep with workgroup-owned partitions (see MODE_BINS above).  grid = number of partitions, 1024 threads.
-//   1. if the previous sweep emitted through the bins: merge my bin into my partition (LDS), write back, set flags
-//   2. scan: my own partition after a MODE_BINS sweep (only its owner knows when its flags are complete), else a
-//      grid-strided share of all chunks
-//   3. emit: MODE_ATOMIC as in sssp_relax_kernel, or MODE_BINS: count per target bin (LDS histogram), reserve space in
-//      every bin with one atomicAdd per (workgroup, bin), write the 12-B candidate records
-__global__ void __launch_bounds__(PB_THREADS) sssp_sweep_bins_kernel(const uint32_t* __restrict__ offsets,
-                                                                     const uint2* __restrict__ wn, uint64_t* __restrict__ key,
-                                                                     uint8_t* __restrict__ flags_cur,
-                                                                     uint8_t* __restrict__ flags_next, uint32_t n,
-                                                                     uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
-                                                                     uint32_t sweep_offset, float delta, uint32_t near_low,
-                                                                     PbArgs pb) {
-  __shared__ unsigned long long lds_key[PB_PART];
-  __shared__ uint32_t lds_imp[PB_PART / 32];
-  __shared__ uint32_t lds_hist[PB_MAX_PARTS];
-  __shared__ SweepShared sh;
-  const uint32_t sweep = ctl->base + sweep_offset;
-  sweep_prologue(ctl, sweep, delta, near_low, pb.pb_low, sh);
-  const float tau = sh.tau;
-  const uint32_t mode = sh.mode, prev_mode = sh.prev_mode;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, p = blockIdx.x;
-  SweepCounts cn;
-
-  // ---- 1. merge the candidates the previous sweep left in my bin
-  if (prev_mode == MODE_BINS) {
-    uint32_t* my_tail = pb.tails + ((sweep - 1u) & 1u) * pb.parts + p;
-    const uint32_t cnt = *my_tail;
-    if (cnt) {  // uniform over the workgroup
-      const uint32_t s0 = p * PB_PART;
-      for (uint32_t i = tid; i < PB_PART; i += PB_THREADS) lds_key[i] = s0 + i < n ? key[s0 + i] : 0ull;
-      if (tid < PB_PART / 32) lds_imp[tid] = 0;
-      __syncthreads();
-      const Cand* __restrict__ c = pb.cand + ((sweep - 1u) & 1u) * pb.cand_stride + pb.bin_off[p];
-      for (uint32_t i = tid; i < cnt; i += PB_THREADS) {
-        const Cand r = c[i];
-        const uint32_t tl = r.t & (PB_PART - 1u);
-        const unsigned long long ck = ((unsigned long long)r.enc << 32) | r.hops;
-        if (ck < lds_key[tl]) {
-          const unsigned long long old = atomicMin(&lds_key[tl], ck);
-          if (ck < old) atomicOr(&lds_imp[tl >> 5], 1u << (tl & 31u));
-        }
+    const uint32_t sc = base + lane;
+    bool act = sc < n && flags_cur[sc] != 0;
+    if (__ballot(act) == 0) continue;
+    // the lane that owns an active state fetches everything the relaxation of that state needs: ONE memory
+    // round trip for the whole 64-state chunk; the groups below get it by shuffle
+    uint64_t my_ks = 0;
+    uint32_t my_b = 0, my_e = 0;
+    if (act) {
+      flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
+      my_ks = key[sc];
+      my_b = offsets[sc];
+      my_e = offsets[sc + 1];
+      if (dec_f32((uint32_t)(my_ks >> 32)) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
+        flags_next[sc] = 1;
+        any = true;
+        act = false;
       }
-      __syncthreads();
-      for (uint32_t i = tid; i < PB_PART; i += PB_THREADS)
-        if ((lds_imp[i >> 5] >> (i & 31u)) & 1u) {
-          // when this sweep emits with global atomics, other workgroups may be lowering key[] right now
-          if (mode == MODE_ATOMIC) atomicMin((unsigned long long*)&key[s0 + i], lds_key[i]);
-          else key[s0 + i] = lds_key[i];
-          flags_cur[s0 + i] = 1;
-          cn.any = true;
+    }
+    uint64_t mask = __ballot(act);
+    while (mask) {
+      // each of the wave's 4 groups takes TWO states per round (the 8 lowest set bits): two independent
+      // load -> pre-check -> atomic chains per lane are in flight at once (the kernel is latency bound)
+      const uint64_t m1 = mask & (mask - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+      const uint64_t m4 = m3 & (m3 - 1), m5 = m4 & (m4 - 1), m6 = m5 & (m5 - 1), m7 = m6 & (m6 - 1);
+      const uint64_t mine_a = grp == 0 ? mask : grp == 1 ? m1 : grp == 2 ? m2 : m3;
+      const uint64_t mine_b = grp == 0 ? m4 : grp == 1 ? m5 : grp == 2 ? m6 : m7;
+      mask = m7 & (m7 - 1);
+      const bool has_a = mine_a != 0, has_b = mine_b != 0;
+      const int la = has_a ? __ffsll((unsigned long long)mine_a) - 1 : 0;
+      const int lb = has_b ? __ffsll((unsigned long long)mine_b) - 1 : 0;
+      const uint64_t ks_a = __shfl(my_ks, la), ks_b = __shfl(my_ks, lb);
+      uint32_t ia = __shfl(my_b, la) + sub, ib = __shfl(my_b, lb) + sub;
+      // (shuffles stay outside any lane-dependent condition: a bpermute reads 0 from a lane that is masked off)
+      const uint32_t ea_all = __shfl(my_e, la), eb_all = __shfl(my_e, lb);
+      const uint32_t ea = has_a ? ea_all : 0u, eb = has_b ? eb_all : 0u;
+      const float da = dec_f32((uint32_t)(ks_a >> 32)), db = dec_f32((uint32_t)(ks_b >> 32));
+      const uint32_t ha = (uint32_t)ks_a + 1u, hb = (uint32_t)ks_b + 1u;
+      while (__any(ia < ea || ib < eb)) {
+        const bool va = ia < ea, vb = ib < eb;
+        uint2 aa = make_uint2(0x7F800000u, 0u), ab = make_uint2(0x7F800000u, 0u);  // {+inf, state 0}: never relaxes
+        if (va) aa = wn[ia];
+        if (vb) ab = wn[ib];
+        const float ca = (da + __uint_as_float(aa.x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+        const float cb = (db + __uint_as_float(ab.x)) + 0.0f;
+        const bool fa = va && ca < INF, fb = vb && cb < INF;  // +inf never improves (shortest_path.rs:226)
+        const uint64_t cka = ((uint64_t)enc_f32(ca) << 32) | ha, ckb = ((uint64_t)enc_f32(cb) << 32) | hb;
+        // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
+        uint64_t ka = 0, kb = 0;
+        if (fa) ka = key[aa.y];
+        if (fb) kb = key[ab.y];
+        const bool ta = fa && cka < ka, tb = fb && ckb < kb;
+        uint64_t olda = 0, oldb = 0;
+        if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
+        if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
+        if (ta && cka < olda) {
+          flags_next[aa.y] = 1;
+          any = true;
+          near_cnt += ca <= tau ? 1u : 0u;
         }
-      if (tid == 0) *my_tail = 0;
-      __syncthreads();  // the flags and keys just written are read back by this workgroup's scan
+        if (tb && ckb < oldb) {
+          flags_next[ab.y] = 1;
+          any = true;
+          near_cnt += cb <= tau ? 1u : 0u;
+        }
+        ia += GROUP;
+        ib += GROUP;
+      }
     }
   }
-
-  // ---- 2. scan   ---- 3. emit
-  uint64_t my_ks[PB_CHUNKS], masks[PB_CHUNKS];
-  uint32_t my_b[PB_CHUNKS], my_e[PB_CHUNKS];
-  if (mode == MODE_BINS)
-    for (uint32_t q = tid; q < pb.parts; q += PB_THREADS) lds_hist[q] = 0;
-  uint32_t chunk_base[PB_CHUNKS], flag[PB_CHUNKS];
-#pragma unroll
-  for (uint32_t j = 0; j < PB_CHUNKS; ++j) {  // all flag loads of this wave in flight together
-    const uint32_t chunk = prev_mode == MODE_BINS ? p * (PB_PART / 64u) + wv + PB_WAVES * j
-                                                  : (p * PB_WAVES + wv) + j * (gridDim.x * PB_WAVES);
-    chunk_base[j] = chunk * 64u;
-    flag[j] = chunk_base[j] + lane < n ? flags_cur[chunk_base[j] + lane] : 0u;
+  // one conditional plain store + one sharded atomicAdd per workgroup (thousands of same-address atomics per
+  // sweep would serialise at ~12 ns each)
+  for (int d = 32; d >= 1; d >>= 1) near_cnt += __shfl_xor(near_cnt, d);
+  const bool wave_any = __any(any);
+  if (lane == 0) {
+    if (wave_any) s_any = 1u;
+    if (near_cnt) atomicAdd(&s_near, near_cnt);
   }
-#pragma unroll
-  for (uint32_t j = 0; j < PB_CHUNKS; ++j) {
-    masks[j] = load_chunk(chunk_base[j], lane, n, offsets, key, flags_cur, flags_next, tau, my_ks[j], my_b[j], my_e[j], cn,
-                          flag[j]);
-    if (mode == MODE_ATOMIC) relax_chunk_atomic(masks[j], lane, my_ks[j], my_b[j], my_e[j], wn, key, flags_next, tau, cn);
-  }
-  if (mode == MODE_BINS) {
-    __syncthreads();  // histogram zeroed
-    uint32_t c_near = 0, c_far = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PB_CHUNKS; ++j)
-      for_each_candidate(masks[j], lane, my_ks[j], my_b[j], my_e[j], wn, [&](float c, uint32_t, uint32_t t) {
-        atomicAdd(&lds_hist[t >> PB_SHIFT], 1u);
-        if (c <= tau) c_near += 1; else c_far += 1;
-      });
-    __syncthreads();
-    uint32_t* tails = pb.tails + (sweep & 1u) * pb.parts;
-    for (uint32_t q = tid; q < pb.parts; q += PB_THREADS) {
-      const uint32_t h = lds_hist[q];
-      // lds_hist[q] becomes the running write position of this workgroup inside bin q
-      if (h) lds_hist[q] = pb.bin_off[q] + atomicAdd(&tails[q], h);
-    }
-    __syncthreads();
-    Cand* __restrict__ out = pb.cand + (sweep & 1u) * pb.cand_stride;
-#pragma unroll
-    for (uint32_t j = 0; j < PB_CHUNKS; ++j)
-      for_each_candidate(masks[j], lane, my_ks[j], my_b[j], my_e[j], wn, [&](float c, uint32_t h1, uint32_t t) {
-        const uint32_t pos = atomicAdd(&lds_hist[t >> PB_SHIFT], 1u);
-        out[pos] = Cand{enc_f32(c), h1, t};
-      });
-    // which candidates improve is only known after the merge: count a quarter of them as activations
-    cn.near += (c_near + 3u) / 4u;
-    cn.far += (c_far + 3u) / 4u;
-    cn.any |= (c_near | c_far) != 0;
-  }
-  sweep_epilogue(ctl, improved_ring + (sweep % IMP_RING), sweep, cn, sh);
-}
-
-// in-degree of every partition = capacity of its bin (a sweep emits at most one candidate per arc)
-__global__ void __launch_bounds__(256) pb_indegree_kernel(const uint2* __restrict__ wn, uint64_t n_arcs, uint32_t parts,
-                                                          uint32_t* __restrict__ counts) {
-  __shared__ uint32_t h[PB_MAX_PARTS];
-  for (uint32_t q = threadIdx.x; q < parts; q += blockDim.x) h[q] = 0;
   __syncthreads();
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_arcs; i += (uint64_t)gridDim.x * blockDim.x)
-    atomicAdd(&h[wn[i].y >> PB_SHIFT], 1u);
-  __syncthreads();
-  for (uint32_t q = threadIdx.x; q < parts; q += blockDim.x)
-    if (h[q]) atomicAdd(&counts[q], h[q]);
+  if (threadIdx.x == 0) {
+    if (s_any && *improved == 0u) *improved = 1u;
+    if (s_near) atomicAdd(&ctl->near[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_near);
+  }
 }
 
 // closes a batch: the next replay continues at base + count, and the flag slots half a ring ahead are recycled
-__global__ void sssp_advance_kernel(Ctl* ctl, uint32_t* improved_ring, uint32_t count) {
+// and the batch's flags are mirrored into pinned host memory (plain stores over the bus: cheaper than a copy node)
+__global__ void sssp_advance_kernel(Ctl* ctl, uint32_t* improved_ring, uint32_t count, uint32_t* host_ring) {
   const uint32_t base = ctl->base;
-  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+    if (host_ring) host_ring[(base + i) % IMP_RING] = improved_ring[(base + i) % IMP_RING];
+    improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
+  }
   __syncthreads();
   if (threadIdx.x == 0) ctl->base = base + count;
+}
+
+// profiling helper (runs outside the timed events): size of the current frontier and of its arc set
+__global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags,
+                                  const uint64_t* __restrict__ key, uint32_t n, Ctl* __restrict__ ctl, uint32_t sweep,
+                                  float delta, uint32_t near_low) {
+  uint32_t streak_unused;
+  const float tau = sweep_tau(ctl, sweep, delta, near_low, &streak_unused);
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long arcs = 0, states = 0;
+  for (; s < n; s += gridDim.x * blockDim.x)
+    if (flags[s] && dec_f32((uint32_t)(key[s] >> 32)) <= tau) {
+      arcs += offsets[s + 1] - offsets[s];
+      states += 1;
+    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    arcs += __shfl_xor(arcs, d);
+    states += __shfl_xor(states, d);
+  }
+  if ((threadIdx.x & 63) == 0 && states) {
+    atomicAdd(&ctl->arcs, arcs);
+    atomicAdd(&ctl->states, states);
+  }
 }
 
 // f_parent = argmin over final states of (d[s] (x) rho(s), s)      (shortest_path.rs:214-220)
@@ -580,6 +352,98 @@ __global__ void sssp_backtrace_kernel(const uint32_t* __restrict__ offsets, cons
   }
 }
 
+// ---- transpose of the CSR, cached on the FST handle once it is queried again: with it the
+// canonical predecessor of the ~hops states ON the path is found by looking at their in-arcs only, instead of the
+// parent pass over all arcs (105 us on 10M arcs).
+__global__ void __launch_bounds__(256) rev_count_kernel(const uint2* __restrict__ wn, uint64_t n_arcs, uint32_t* __restrict__ indeg) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_arcs; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&indeg[wn[i].y], 1u);
+}
+// exclusive scan of n counters by ONE workgroup (n is a few million at most; runs once per FST)
+__global__ void __launch_bounds__(1024) rev_scan_kernel(const uint32_t* __restrict__ indeg, uint32_t* __restrict__ rev_off,
+                                                       uint32_t* __restrict__ cursor, uint32_t n) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n ? indeg[i] : 0u;
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < wv; ++w) before += wave_tot[w];
+    if (i < n) {
+      rev_off[i] = before + incl - v;
+      cursor[i] = before + incl - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rev_off[n] = carry;
+}
+__global__ void __launch_bounds__(256) rev_fill_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
+                                                      uint32_t n, uint32_t* __restrict__ cursor, uint2* __restrict__ rev_arc) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = tid % GROUP;
+  const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
+  for (uint32_t s = tid / GROUP; s < n; s += n_groups) {
+    const uint32_t b = offsets[s], e = offsets[s + 1];
+    for (uint32_t i = b + lane; i < e; i += GROUP) rev_arc[atomicAdd(&cursor[wn[i].y], 1u)] = make_uint2(s, i - b);
+  }
+}
+
+// single_shortest_path_backtrace (shortest_path.rs:241-282) over the transpose: one wave; at every step the
+// lanes test the in-arcs of the current state for tightness, (d[s] (x) w, hops[s] + 1) == (d[t], hops[t]), and the
+// smallest (s, pos) wins — the same predecessor sssp_parent_kernel selects.  Arcs go straight to pinned host
+// memory when the path fits in it.
+__global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* __restrict__ offsets,
+                                                               const wfst_tr* __restrict__ arcs,
+                                                               const uint2* __restrict__ wn, const uint64_t* __restrict__ key,
+                                                               const uint32_t* __restrict__ rev_off,
+                                                               const uint2* __restrict__ rev_arc, Ctl* __restrict__ ctl,
+                                                               wfst_tr* __restrict__ out, uint32_t out_cap) {
+  const uint32_t lane = threadIdx.x;
+  if (!ctl->has_path) return;
+  uint32_t cur = ctl->f_parent;
+  const uint32_t hops = ctl->hops;
+  if (hops > out_cap) return;  // the host falls back to the parent pass
+  for (uint32_t k = 0; k < hops; ++k) {
+    const uint64_t kt = key[cur];
+    unsigned long long best = ~0ull;
+    for (uint32_t j = rev_off[cur] + lane; j < rev_off[cur + 1]; j += 64) {
+      const uint2 ra = rev_arc[j];
+      const uint64_t ks = key[ra.x];
+      if (ks == KEY_INF) continue;
+      const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(wn[offsets[ra.x] + ra.y].x)) + 0.0f;
+      if (!(c < INF)) continue;
+      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
+      if (ck == kt) {
+        const unsigned long long cand = ((unsigned long long)ra.x << 32) | ra.y;
+        best = cand < best ? cand : best;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long o = __shfl_xor(best, d);
+      best = o < best ? o : best;
+    }
+    const uint32_t s = (uint32_t)(best >> 32), pos = (uint32_t)best;
+    if (lane == 0) {
+      wfst_tr tr = arcs[offsets[s] + pos];
+      tr.nextstate = k;
+      out[k] = tr;
+    }
+    cur = s;
+  }
+}
+
 __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __restrict__ dist, uint32_t* __restrict__ hops,
                                    uint32_t n) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -594,32 +458,8 @@ struct Solve {
   DBuf<uint8_t> flags;  // two frontiers of n bytes
   DBuf<uint32_t> improved;
   DBuf<Ctl> ctl;
-  DBuf<Cand> cand;      // MODE_BINS: two candidate buffers of n_arcs records
-  DBuf<uint32_t> tails; // MODE_BINS: [2][parts]
   uint32_t sweeps = 0;
 };
-
-// bin layout of an FST (prefix sums of the partitions' in-degrees): derived data, cached on the handle
-const uint32_t* pb_bin_offsets(wfst_ctx* ctx, const wfst_fst* f, uint32_t parts) {
-  if (f->pb_bin_off && f->pb_parts == parts) return f->pb_bin_off->p;
-  hipStream_t st = ctx->stream;
-  DBuf<uint32_t> counts(*ctx->pool, parts);
-  HIP_CHECK(hipMemsetAsync(counts.p, 0, parts * sizeof(uint32_t), st));
-  const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 2));
-  pb_indegree_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, parts, counts.p);
-  HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> h(parts + 1, 0);
-  HIP_CHECK(hipMemcpyAsync(h.data() + 1, counts.p, parts * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  for (uint32_t q = 0; q < parts; ++q) h[q + 1] += h[q];
-  if (h[parts] != f->n_arcs) throw Error("internal: partition in-degrees do not add up to the arc count");
-  auto buf = std::make_shared<DBuf<uint32_t>>(*ctx->pool, parts + 1);
-  HIP_CHECK(hipMemcpyAsync(buf->p, h.data(), (parts + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  f->pb_bin_off = buf;
-  f->pb_parts = parts;
-  return buf->p;
-}
 
 constexpr uint32_t MAX_BATCH = 64;
 
@@ -639,38 +479,9 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
   HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
   HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
-  HIP_CHECK(hipMemsetAsync(sv.ctl.p, 0, sizeof(Ctl), st));
   uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n_pad};
-  sssp_init_kernel<<<1, 1, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
-  uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
-  // workgroup-owned partitions + candidate bins for the big sweeps (MODE_BINS).  EXPERIMENTAL, off unless
-  // WFST_SSSP_BINS=1: measured on MI355X a binned sweep has ~20 us of fixed cost (six workgroup
-  // barriers, the key-partition load, one reservation atomic per (workgroup, bin)), so it only beats the
-  // atomic-bound sweep above ~1M arcs (36 vs 46 us) and its 1024-thread workgroups raise the floor of the many
-  // small sweeps from 8 to 11 us: a net loss on the 1M-state benchmark (708 vs 597 us per solve).
-  PbArgs pb{};
-  pb.pb_low = PB_OFF;
-  {
-    uint64_t min_states = 65536, pb_low = 32768;
-    bool on = false;
-    if (const char* e = std::getenv("WFST_SSSP_BINS")) on = std::atoi(e) != 0;
-    if (const char* e = std::getenv("WFST_SSSP_BINS_MIN_STATES")) min_states = (uint64_t)std::atoll(e);
-    if (const char* e = std::getenv("WFST_SSSP_BINS_LOW")) pb_low = (uint64_t)std::atoll(e);
-    const uint32_t parts = (uint32_t)(((uint64_t)n + PB_PART - 1) >> PB_SHIFT);
-    if (on && n >= min_states && parts <= PB_MAX_PARTS && f->n_arcs > 0 && f->n_arcs < 0x7FFFFFFFull) {
-      pb.parts = parts;
-      pb.pb_low = (uint32_t)std::min<uint64_t>(pb_low, PB_OFF - 1);
-      pb.bin_off = pb_bin_offsets(ctx, f, parts);
-      pb.cand_stride = f->n_arcs;
-      sv.cand = DBuf<Cand>(pool, 2 * f->n_arcs);
-      sv.tails = DBuf<uint32_t>(pool, 2 * (size_t)parts);
-      HIP_CHECK(hipMemsetAsync(sv.tails.p, 0, 2 * (size_t)parts * sizeof(uint32_t), st));
-      pb.cand = sv.cand.p;
-      pb.tails = sv.tails.p;
-      blocks = parts;
-    }
-  }
-  const bool bins = pb.pb_low != PB_OFF;
+  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
   // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
   float delta = INF;
@@ -684,38 +495,27 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
 
   uint32_t sweeps_done = 0;
   if (ctx->profiling) {
-    // one sweep at a time, bracketed by events; the kernels count the states and arcs they relax themselves
-    auto prof_sum = [](const Ctl* c, int which) {
-      uint64_t t = 0;
-      for (uint32_t j = 0; j < NEAR_SHARDS; ++j) t += c->prof[j][which];
-      return t;
-    };
+    // one sweep at a time, bracketed by events; a counting kernel (outside the events) sizes the frontier
     uint32_t* h_imp = (uint32_t*)ctx->pinned.get(64 + sizeof(Ctl));
     Ctl* h_ctl = (Ctl*)((char*)h_imp + 64);
     ctx->sweep_trace.clear();
     uint64_t prev_arcs = 0, prev_states = 0;
     for (uint32_t k = 0;; ++k) {
       if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+      sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta, near_low);
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
-      if (bins)
-        sssp_sweep_bins_kernel<<<blocks, PB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u],
-                                                             fl[(k & 1u) ^ 1u], n, sv.improved.p, sv.ctl.p, 0u, delta,
-                                                             near_low, pb);
-      else
-        sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
-                                                  sv.improved.p, sv.ctl.p, 0u, delta, near_low);
+      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
+                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low);
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
-      sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u);
+      sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u, nullptr);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-      // (bit 63 of the state count marks a sweep that emitted through the bins)
-      ctx->sweep_trace.push_back({(double)ms, prof_sum(h_ctl, 0) - prev_arcs,
-                                  (prof_sum(h_ctl, 1) - prev_states) | ((uint64_t)(h_ctl->mode[k % RING] == MODE_BINS) << 63)});
-      prev_arcs = prof_sum(h_ctl, 0);
-      prev_states = prof_sum(h_ctl, 1);
+      ctx->sweep_trace.push_back({(double)ms, h_ctl->arcs - prev_arcs, h_ctl->states - prev_states});
+      prev_arcs = h_ctl->arcs;
+      prev_states = h_ctl->states;
       ctx->stats.relax_ms += ms;
       ctx->stats.relax_launches += 1;
       sweeps_done = k + 1;
@@ -723,8 +523,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     }
     HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    ctx->stats.relax_arcs += prof_sum(h_ctl, 0);
-    ctx->stats.relax_states += prof_sum(h_ctl, 1);
+    ctx->stats.relax_arcs += h_ctl->arcs;
+    ctx->stats.relax_states += h_ctl->states;
   } else {
     // One HIP graph = one batch: `count` sweep kernels (static offsets 0..count-1 from the device-side base), the
     // copy of the flag ring to pinned host memory and the advance kernel, chained.  A replay is ONE host call
@@ -737,8 +537,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
       const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn, (uint64_t)sv.key.p, (uint64_t)sv.flags.p,
                                (uint64_t)sv.improved.p, (uint64_t)sv.ctl.p, ((uint64_t)n << 32) | __float_as_uint_host(delta),
-                               (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48) ^ (uint64_t)pb.cand ^
-                                   ((uint64_t)pb.tails << 1) ^ ((uint64_t)pb.bin_off << 2) ^ ((uint64_t)pb.pb_low << 20)};
+                               (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
       if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
       if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
       if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
@@ -758,12 +557,11 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
         uint8_t* a_fc = fl[j & 1u];
         uint8_t* a_fn = fl[(j & 1u) ^ 1u];
         uint32_t a_off = j;
-        PbArgs a_pb = pb;
-        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low, &a_pb};
+        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low};
         hipKernelNodeParams kp{};
-        kp.func = bins ? (void*)sssp_sweep_bins_kernel : (void*)sssp_relax_kernel;
+        kp.func = (void*)sssp_relax_kernel;
         kp.gridDim = dim3(blocks);
-        kp.blockDim = dim3(bins ? PB_THREADS : 256u);
+        kp.blockDim = dim3(256);
         kp.sharedMemBytes = 0;
         kp.kernelParams = args;
         kp.extra = nullptr;
@@ -772,14 +570,9 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
         prev = node;
       }
       {
-        hipGraphNode_t node;
-        HIP_CHECK(hipGraphAddMemcpyNode1D(&node, g.graph, &prev, 1, h_imp + which * IMP_RING, sv.improved.p,
-                                          IMP_RING * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        prev = node;
-      }
-      {
         uint32_t a_count = count;
-        void* args[] = {&a_ctl, &a_imp, &a_count};
+        uint32_t* a_host = h_imp + which * IMP_RING;
+        void* args[] = {&a_ctl, &a_imp, &a_count, &a_host};
         hipKernelNodeParams kp{};
         kp.func = (void*)sssp_advance_kernel;
         kp.gridDim = dim3(1);
@@ -836,29 +629,21 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
 // word (add_state / set_final / add_tr / set_start bookkeeping, then shortest_path_properties(.., true)).
 wfst_fst* build_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final_weight, const wfst_tr* path_arcs) {
   HostCsr h;
-  uint64_t p = props::NULL_PROPS;
   uint32_t n_states = 0;
   int64_t start = -1;
-  h.offsets.push_back(0);
   if (has_path) {
     n_states = hops + 1;
     h.finals.assign(n_states, INF);
-    for (uint32_t k = 0; k <= hops; ++k) {
-      p = props::add_state(p);
-      if (k == 0) {
-        h.finals[0] = final_weight;
-        p = props::set_final(p, nullptr, &final_weight);
-      } else {
-        h.arcs.push_back(path_arcs[k - 1]);
-        p = props::add_tr(p, k, path_arcs[k - 1], nullptr);
-      }
-      h.offsets.push_back((uint32_t)h.arcs.size());
-    }
+    h.finals[0] = final_weight;
+    h.arcs.assign(path_arcs, path_arcs + hops);
+    h.offsets.resize((size_t)n_states + 1);
+    h.offsets[0] = 0;
+    for (uint32_t k = 0; k <= hops; ++k) h.offsets[k + 1] = k;  // state 0 has no arc, state k >= 1 one
     start = hops;
-    p = props::set_start(p);
+  } else {
+    h.offsets.push_back(0);
   }
-  p = props::shortest_path(p, true) & props::ALL;
-  return make_host_fst(ctx, n_states, start, p, std::move(h));
+  return make_host_fst(ctx, n_states, start, props::linear_path_props(has_path, hops, final_weight, path_arcs), std::move(h));
 }
 
 }  // namespace
@@ -883,6 +668,31 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
+// Transpose of f (in-arcs as {source, position}); built the SECOND time shortest_path sees the same large FST —
+// a one-shot query keeps the parent pass, a resident transducer that is queried again pays ~1 ms once.
+const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
+  if (f->rev_dev) return f->rev_dev.get();
+  f->sp_queries += 1;
+  if (f->sp_queries < 2 || f->n_arcs < (1u << 18) || f->n_arcs >= 0xFFFFFFFFull) return nullptr;
+  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return nullptr;
+  const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
+  auto r = std::make_shared<RevCsr>();
+  r->off = DBuf<uint32_t>(*ctx->pool, (size_t)n + 1);
+  r->arc = DBuf<uint2>(*ctx->pool, f->n_arcs);
+  DBuf<uint32_t> indeg(*ctx->pool, n), cursor(*ctx->pool, n);
+  HIP_CHECK(hipMemsetAsync(indeg.p, 0, (size_t)n * sizeof(uint32_t), st));
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
+  rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, indeg.p);
+  rev_scan_kernel<<<1, 1024, 0, st>>>(indeg.p, r->off.p, cursor.p, n);
+  const uint32_t fblocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
+  rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, cursor.p, r->arc.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));  // indeg / cursor are released here
+  f->rev_dev = r;
+  return r.get();
+}
+
 wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   const uint32_t n = f->n_states;
   if (f->start < 0 || n == 0) return build_path_fst(ctx, false, 0, INF, nullptr);  // shortest_path.rs:185-187
@@ -890,15 +700,23 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   hipStream_t st = ctx->stream;
   Solve sv;
   run_relaxation(ctx, f, sv);
-  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus), 256, 0, st>>>(f->dev.finals, sv.key.p, n,
-                                                                                                      sv.ctl.p);
+  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 8), 256, 0, st>>>(f->dev.finals, sv.key.p,
+                                                                                                          n, sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
-  Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
+  constexpr uint32_t PATH_PINNED = 4096;  // arcs of the path written straight into pinned memory by the backtrace
+  char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 64 + PATH_PINNED * sizeof(wfst_tr));
+  Ctl* hc = (Ctl*)pin;
+  wfst_tr* h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
+  const RevCsr* rev = reverse_csr(ctx, f);
+  if (rev)
+    sssp_backtrace_rev_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, f->dev.wn, sv.key.p, rev->off.p, rev->arc.p,
+                                                sv.ctl.p, h_path, PATH_PINNED);
   HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
   const uint32_t hops = hc->hops;
   const float final_weight = hc->final_weight;
+  if (rev && hops <= PATH_PINNED) return build_path_fst(ctx, true, hops, final_weight, h_path);
   std::vector<wfst_tr> path(hops);
   if (hops) {
     DBuf<unsigned long long> parent(*ctx->pool, n);

@@ -86,8 +86,7 @@ class Context:
         states = np.zeros(n.value, dtype=np.uint64)
         check(_lib.lib().wfst_ctx_get_sweep_trace(self._h, ms.ctypes.data, arcs.ctypes.data, states.ctypes.data,
                                                   n.value, C.byref(n)))
-        self.last_sweep_modes = (states >> np.uint64(63)).astype(np.uint8)  # 1 = emitted through the bins
-        return ms, arcs, states & np.uint64((1 << 63) - 1)
+        return ms, arcs, states
 
     def stats(self) -> dict:
         st = _lib.Stats()

@@ -627,19 +627,19 @@ def test_async_batch_overlaps_with_shortest_path(gpu_ctx, oracle):
     del rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)._keep  # abandoned job is reclaimed
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_shortest_path_binned_sweeps_match_oracle(gpu_ctx, oracle, seed, monkeypatch):
-    """The experimental workgroup-owned-partition ("propagation blocking") sweeps, forced on for every sweep:
-    same canonical result as the oracle, bit for bit (several partitions, near-far on and off)."""
-    monkeypatch.setenv("WFST_SSSP_BINS", "1")
-    monkeypatch.setenv("WFST_SSSP_BINS_MIN_STATES", "0")
-    monkeypatch.setenv("WFST_SSSP_BINS_LOW", "0" if seed % 2 == 0 else "64")
-    if seed >= 2:
-        monkeypatch.setenv("WFST_SSSP_DELTA", "1.5")
-    t = synth.make_transducer(20000 + 3000 * seed, 6, 32, 0.05 * (seed % 2), seed=70 + seed)
+@pytest.mark.parametrize("seed", range(3))
+def test_shortest_path_repeated_queries_use_transpose(gpu_ctx, oracle, seed):
+    """From the second query on a large FST the backtrace runs over the cached transpose instead of the parent
+    pass: every query returns the oracle's canonical path bit for bit; tr_sort invalidates the cache."""
+    t = synth.make_transducer(40000 + 5000 * seed, 8, 64, 0.05 * seed, seed=300 + seed)
+    assert t["offsets"][-1] >= 1 << 18
     d = to_device(t)
+    ref = to_oracle(oracle, t).shortest_path_canonical().to_flat()
+    for q in range(4):
+        assert_flat_identical(d.shortest_path().to_flat(), ref, f"query {q}")
+    d.tr_sort(False)  # olabel order: arc positions change, so must the transpose
     o = to_oracle(oracle, t)
-    ref = o.shortest_path_canonical()
-    assert_flat_identical(d.shortest_path().to_flat(), ref.to_flat(), f"binned sweeps seed {seed}")
-    dist, hops = d.shortest_distance(want_hops=True)
-    np.testing.assert_array_equal(dist.view(np.uint32), np.asarray(ref.distance, dtype=np.float32).view(np.uint32))
+    o.tr_sort(by_olabel=True)
+    ref2 = o.shortest_path_canonical().to_flat()
+    for q in range(3):
+        assert_flat_identical(d.shortest_path().to_flat(), ref2, f"after tr_sort, query {q}")

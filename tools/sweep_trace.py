@@ -13,8 +13,8 @@ for _ in range(2):
     d.shortest_path()
 ctx.reset_stats(); ctx.set_profiling(True); d.shortest_path(); ctx.set_profiling(False)
 ms, arcs, st = ctx.sweep_trace()
-print("sweep  states     arcs      us    Garcs/s  algGB/s mode")
+print("sweep  states     arcs      us    Garcs/s  algGB/s")
 for k in range(len(ms)):
     b = 20.0 * arcs[k] + 12.0 * st[k]
-    print(f"{k:4d} {st[k]:8d} {arcs[k]:9d} {ms[k]*1e3:8.2f} {arcs[k]/max(ms[k],1e-9)/1e6:8.2f} {b/max(ms[k],1e-9)/1e6:8.1f} {'bins' if ctx.last_sweep_modes[k] else ''}")
+    print(f"{k:4d} {st[k]:8d} {arcs[k]:9d} {ms[k]*1e3:8.2f} {arcs[k]/max(ms[k],1e-9)/1e6:8.2f} {b/max(ms[k],1e-9)/1e6:8.1f}")
 print("total", st.sum(), arcs.sum(), ms.sum() * 1e3, "us")
