@@ -83,11 +83,15 @@ wfst_status wfst_fst_upload_device(wfst_ctx* ctx, uint32_t n_states, int64_t sta
 wfst_status wfst_fst_upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts,
                                  const uint32_t* offsets_cat, const wfst_tr* arcs_cat, const float* finals_cat,
                                  const uint64_t* props, wfst_fst** outs);
-/* OpenFST binary "vector"/"standard": vec_fst_from_bytes / vec_fst_to_bytes
+/* OpenFST binary, arc type "standard": vec_fst_from_bytes / vec_fst_to_bytes
  * (rustfst-ffi/src/fst/vector_fst.rs:319-354; format rustfst/src/parsers/bin_fst/fst_header.rs:71-112,
- * rustfst/src/fst_impls/vector_fst/serializable_fst.rs:45-168). Symbol tables are skipped. */
+ * rustfst/src/fst_impls/vector_fst/serializable_fst.rs:45-168). Symbol tables are skipped.
+ * The reader accepts fst_type "vector" (version >= 2) and "const" (version 1 = 16-byte aligned blocks, version 2;
+ * rustfst/src/fst_impls/const_fst/serializable_fst.rs:176-237: const_fst_from_bytes, rustfst-ffi/src/fst/const_fst.rs).
+ * _to_openfst_bytes writes "vector" v2, _to_openfst_const_bytes writes "const" v2 (ConstFst::store, :41-89). */
 wfst_status wfst_fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len, wfst_fst** out);
 wfst_status wfst_fst_to_openfst_bytes(const wfst_fst* fst, uint8_t** data, size_t* len);
+wfst_status wfst_fst_to_openfst_const_bytes(const wfst_fst* fst, uint8_t** data, size_t* len);
 wfst_status wfst_bytes_destroy(uint8_t* data);
 
 wfst_status wfst_fst_info(const wfst_fst* fst, uint32_t* n_states, uint64_t* n_arcs, int64_t* start,

@@ -1643,6 +1643,54 @@ size_t store_vector_fst(const Fst& f, uint8_t* out, size_t cap) {
   return buf.size();
 }
 
+// ConstFst::store (const_fst/serializable_fst.rs:41-89): version 2 (unaligned), static property EXPANDED,
+// per state {final f32, pos i32, ntrs i32, niepsilons i32, noepsilons i32}, then all arcs.
+size_t store_const_fst(const Fst& f, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> buf;
+  auto put = [&](const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    buf.insert(buf.end(), b, b + n);
+  };
+  auto put_i32 = [&](int32_t v) { put(&v, 4); };
+  auto put_i64 = [&](int64_t v) { put(&v, 8); };
+  auto put_str = [&](const char* s) {
+    put_i32((int32_t)std::strlen(s));
+    put(s, std::strlen(s));
+  };
+  int64_t num_trs = 0;
+  for (const State& st : f.states) num_trs += (int64_t)st.trs.size();
+  put_i32(2125659606);
+  put_str("const");
+  put_str("standard");
+  put_i32(2);
+  uint32_t flags = 0;
+  put(&flags, 4);
+  uint64_t props = f.properties | 0x1ull;  // ConstFst::static_properties() = EXPANDED (data_structure.rs:33-35)
+  put(&props, 8);
+  put_i64(f.has_start ? (int64_t)f.start : -1);
+  put_i64((int64_t)f.states.size());
+  put_i64(num_trs);
+  int32_t pos = 0;
+  for (const State& st : f.states) {
+    float fw = st.has_final ? st.final_w : INF;
+    put(&fw, 4);
+    put_i32(pos);
+    put_i32((int32_t)st.trs.size());
+    put_i32((int32_t)st.niepsilons);
+    put_i32((int32_t)st.noepsilons);
+    pos += (int32_t)st.trs.size();
+  }
+  for (const State& st : f.states)
+    for (const Tr& tr : st.trs) {
+      put_i32((int32_t)tr.ilabel);
+      put_i32((int32_t)tr.olabel);
+      put(&tr.weight, 4);
+      put_i32((int32_t)tr.nextstate);
+    }
+  if (out && cap >= buf.size()) std::memcpy(out, buf.data(), buf.size());
+  return buf.size();
+}
+
 // ---------------------------------------------------------------- helpers for invariants
 float brute_rec(const Fst& f, uint32_t s, float acc, uint32_t depth, uint32_t max_len) {
   float best = INF;
@@ -1758,6 +1806,7 @@ void oracle_fst_eps_counts(const oracle_fst* f, uint32_t* nieps, uint32_t* noeps
 
 oracle_fst* oracle_fst_load(const uint8_t* data, size_t len) { return load_vector_fst(data, len); }
 size_t oracle_fst_store(const oracle_fst* f, uint8_t* out, size_t cap) { return store_vector_fst(*f, out, cap); }
+size_t oracle_fst_store_const(const oracle_fst* f, uint8_t* out, size_t cap) { return store_const_fst(*f, out, cap); }
 
 int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode, oracle_fst** out) {
   DeltaGuard g(eq_mode);

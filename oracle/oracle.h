@@ -62,6 +62,8 @@ void oracle_fst_eps_counts(const oracle_fst*, uint32_t* nieps, uint32_t* noeps);
 /* OpenFST binary vector/standard (parsers/bin_fst, vector_fst/serializable_fst.rs) */
 oracle_fst* oracle_fst_load(const uint8_t* data, size_t len);
 size_t oracle_fst_store(const oracle_fst*, uint8_t* out, size_t cap); /* returns needed size */
+/* ConstFst::store, const_fst/serializable_fst.rs:41-89 (version 2, unaligned) */
+size_t oracle_fst_store_const(const oracle_fst*, uint8_t* out, size_t cap);
 
 /* ---- algorithms ---- */
 /* compose_with_config(AutoFilter|SequenceFilter, connect): compose_static.rs:166-266 */

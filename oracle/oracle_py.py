@@ -56,6 +56,8 @@ def lib():
         L.oracle_fst_load.restype = vp
         L.oracle_fst_store.argtypes = [vp, vp, C.c_size_t]
         L.oracle_fst_store.restype = C.c_size_t
+        L.oracle_fst_store_const.argtypes = [vp, vp, C.c_size_t]
+        L.oracle_fst_store_const.restype = C.c_size_t
         L.oracle_compose.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_connect.argtypes = [vp]
         L.oracle_shortest_path.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.POINTER(f32)]
@@ -127,10 +129,11 @@ class OracleFst:
             raise _err()
         return cls(h)
 
-    def store(self) -> bytes:
-        n = lib().oracle_fst_store(self._h, None, 0)
+    def store(self, fst_type: str = "vector") -> bytes:
+        fn = lib().oracle_fst_store if fst_type == "vector" else lib().oracle_fst_store_const
+        n = fn(self._h, None, 0)
         buf = (C.c_uint8 * n)()
-        lib().oracle_fst_store(self._h, C.addressof(buf), n)
+        fn(self._h, C.addressof(buf), n)
         return bytes(buf)
 
     # -- inspection

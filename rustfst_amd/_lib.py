@@ -46,6 +46,7 @@ SYMBOLS = [
     ("wfst_fst_upload_many", C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _P(_vp)]),
     ("wfst_fst_from_openfst_bytes", C.c_int, [_vp, C.c_char_p, _sz, _P(_vp)]),
     ("wfst_fst_to_openfst_bytes", C.c_int, [_vp, _P(_vp), _P(_sz)]),
+    ("wfst_fst_to_openfst_const_bytes", C.c_int, [_vp, _P(_vp), _P(_sz)]),
     ("wfst_bytes_destroy", C.c_int, [_vp]),
     ("wfst_fst_info", C.c_int, [_vp, _P(_u32), _P(_u64), _P(_i64), _P(_u64)]),
     ("wfst_fst_download", C.c_int, [_vp, _vp, _vp, _vp]),

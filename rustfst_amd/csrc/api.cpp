@@ -209,6 +209,18 @@ wfst_status wfst_fst_to_openfst_bytes(const wfst_fst* fst, uint8_t** data, size_
     *len = buf.size();
   });
 }
+wfst_status wfst_fst_to_openfst_const_bytes(const wfst_fst* fst, uint8_t** data, size_t* len) {
+  return wrap([&] {
+    if (!fst || !data || !len) throw Error("null pointer");
+    std::vector<uint8_t> buf;
+    fst_to_openfst_const_bytes(fst, buf);
+    uint8_t* p = (uint8_t*)std::malloc(buf.size() ? buf.size() : 1);
+    if (!p) throw Error("out of memory");
+    std::memcpy(p, buf.data(), buf.size());
+    *data = p;
+    *len = buf.size();
+  });
+}
 wfst_status wfst_fst_info(const wfst_fst* fst, uint32_t* n_states, uint64_t* n_arcs, int64_t* start, uint64_t* props) {
   return wrap([&] {
     if (!fst) throw Error("null fst");

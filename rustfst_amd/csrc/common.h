@@ -193,6 +193,7 @@ wfst_fst* adopt_device(wfst_ctx* ctx, uint32_t n_states, uint64_t n_arcs, int64_
 // openfst_io.cpp
 wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len);
 void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
+void fst_to_openfst_const_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
 // sssp.hip
 wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);

@@ -125,6 +125,49 @@ wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len)
   return upload_from_host(ctx, (uint32_t)num_states, start, h.offsets.data(), h.arcs.data(), h.finals.data(), props);
 }
 
+// ConstFst::store (const_fst/serializable_fst.rs:41-89): version 2 (unaligned); the CSR goes out as it is
+void fst_to_openfst_const_bytes(const wfst_fst* f, std::vector<uint8_t>& out) {
+  ensure_host(f);
+  const HostCsr& h = f->host;
+  if (f->n_arcs > 0x7FFFFFFFull) throw Error("FST too large for the const format (i32 arc positions)");
+  auto put = [&](const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    out.insert(out.end(), b, b + n);
+  };
+  auto put_i32 = [&](int32_t v) { put(&v, 4); };
+  auto put_i64 = [&](int64_t v) { put(&v, 8); };
+  auto put_str = [&](const char* s) {
+    put_i32((int32_t)std::strlen(s));
+    put(s, std::strlen(s));
+  };
+  out.reserve(64 + (size_t)f->n_states * 20 + (size_t)f->n_arcs * 16);
+  put_i32(FST_MAGIC);
+  put_str("const");
+  put_str("standard");
+  put_i32(2);  // CONST_FILE_VERSION (const_fst/mod.rs:13)
+  uint32_t flags = 0;
+  put(&flags, 4);
+  uint64_t p = f->props | 0x1ull;  // ConstFst::static_properties() = EXPANDED
+  put(&p, 8);
+  put_i64(f->start);
+  put_i64((int64_t)f->n_states);
+  put_i64((int64_t)f->n_arcs);
+  for (uint32_t s = 0; s < f->n_states; ++s) {
+    const uint32_t b = h.offsets[s], e = h.offsets[s + 1];
+    int32_t nie = 0, noe = 0;
+    for (uint32_t i = b; i < e; ++i) {
+      nie += h.arcs[i].ilabel == WFST_EPS_LABEL;
+      noe += h.arcs[i].olabel == WFST_EPS_LABEL;
+    }
+    put(&h.finals[s], 4);
+    put_i32((int32_t)b);
+    put_i32((int32_t)(e - b));
+    put_i32(nie);
+    put_i32(noe);
+  }
+  if (f->n_arcs) put(h.arcs.data(), (size_t)f->n_arcs * sizeof(wfst_tr));  // {i32,i32,f32,i32} LE == wfst_tr
+}
+
 void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out) {
   ensure_host(f);
   const HostCsr& h = f->host;

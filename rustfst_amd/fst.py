@@ -181,10 +181,14 @@ class DeviceFst:
               "wfst_fst_from_openfst_bytes")
         return cls(h, ctx)
 
-    def to_bytes(self) -> bytes:
+    def to_bytes(self, fst_type: str = "vector") -> bytes:
+        """OpenFST binary: "vector" (VectorFst::store) or "const" (ConstFst::store, version 2)."""
+        if fst_type not in ("vector", "const"):
+            raise ValueError("fst_type must be 'vector' or 'const'")
         p = C.c_void_p()
         n = C.c_size_t()
-        check(_lib.lib().wfst_fst_to_openfst_bytes(self._h, C.byref(p), C.byref(n)), "wfst_fst_to_openfst_bytes")
+        fn = _lib.lib().wfst_fst_to_openfst_bytes if fst_type == "vector" else _lib.lib().wfst_fst_to_openfst_const_bytes
+        check(fn(self._h, C.byref(p), C.byref(n)), "wfst_fst_to_openfst_bytes")
         try:
             return C.string_at(p.value, n.value)
         finally:

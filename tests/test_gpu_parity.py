@@ -505,6 +505,9 @@ def test_openfst_loader_const_and_vector(gpu_ctx, oracle, name):
     o = oracle.OracleFst.load(data)
     assert_flat_identical(d.to_flat(), o.to_flat(), name)
     assert d.to_bytes() == o.store()
+    assert d.to_bytes("const") == o.store("const")
+    again = rustfst_amd.DeviceFst.from_bytes(d.to_bytes("const"))
+    assert_flat_identical(again.to_flat(), o.to_flat(), name + " via const v2")
 
 
 def _unsorted_flat(rng, n_states, max_fanout, sigma, hub_degrees=(), acceptor=False):

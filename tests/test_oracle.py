@@ -163,6 +163,15 @@ def test_const_loader_fixtures(oracle, name, n_states, n_arcs):
     assert int(flat["arcs"]["nextstate"].max()) < n_states
     again = oracle.OracleFst.load(f.store())  # written back as a vector file
     assert again == f
+    # ... and as a const file (ConstFst::store writes version 2, unaligned): same states / arcs / counters, and the
+    # unaligned body is exactly the aligned one without its padding
+    c2 = f.store("const")
+    assert c2[8:13] == b"const" and int.from_bytes(c2[25:29], "little") == 2
+    back = oracle.OracleFst.load(c2)
+    assert back == f and back.eps_counts()[0].tolist() == ni.tolist() and back.eps_counts()[1].tolist() == no.tolist()
+    body = 20 * n_states + 16 * n_arcs
+    assert c2[-16 * n_arcs:] == data[-16 * n_arcs:] and len(c2) + 32 >= len(data) >= len(c2)
+    assert c2[-body:-16 * n_arcs] in data  # the 20-byte state records, in one piece
 
 
 @pytest.mark.parametrize("hcl,g", [("fst_014_hcl.fst", "fst_014_g.fst"), ("fst_012_hcl.fst", "fst_012_gp.fst")])
