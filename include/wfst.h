@@ -103,9 +103,10 @@ wfst_status wfst_fst_destroy(wfst_fst* fst);
 /* ---- compose: fst_compose / fst_compose_with_config (rustfst-ffi/src/algorithms/compose.rs:308-372)
  *      = rustfst::algorithms::compose::{compose, compose_with_config}
  *        (rustfst/src/algorithms/compose/compose_static.rs:166-306).
- * compose_filter uses the ffi numbering (compose.rs:20-33): 0 Auto, 1 Null, 2 Trivial, 3 Sequence,
- * 4 AltSequence, 5 Match, 6 NoMatch.  Auto and Sequence (SortedMatcher x2) run on the GPU; the others
- * return KO "unsupported" so the shim can fall back to the Rust path.  cfg == NULL means
+ * compose_filter uses the ffi numbering (compose.rs:20-33): 0 Auto (= Sequence, compose_fst.rs:58-92), 1 Null,
+ * 2 Trivial, 3 Sequence, 4 AltSequence, 5 Match, 6 NoMatch — all with the default SortedMatcher pair
+ * (rustfst/src/algorithms/compose/compose_filters/{null,trivial,sequence,alt_sequence,match,no_match}_compose_filter.rs);
+ * custom matcher configs (sigma matcher) are not part of this ABI.  cfg == NULL means
  * ComposeConfig::default() = {Auto, connect = true} (compose_static.rs:56-65).
  * KO with the reference's message when neither side is known label-sorted
  * (compose/compose_fst_op.rs:169-197).  Output state ids / arc order are the reference's

@@ -456,34 +456,75 @@ struct MatcherIter {
   }
 };
 
-// SequenceComposeFilter — compose_filters/sequence_compose_filter.rs:118-175
+// The compose filters reachable through ComposeFilterEnum (compose_static.rs:19-33): one struct, one branch per
+// reference file.  Filter states: IntegerFilterState (u32, NO_STATE_ID = blocking) for Sequence / AltSequence /
+// Match; TrivialFilterState (bool, false = blocking) for Null / Trivial / NoMatch — represented here as 0 = the
+// single live state `true` and NO_STATE_ID = `false`.
+enum FilterKind : int { F_AUTO = 0, F_NULL = 1, F_TRIVIAL = 2, F_SEQUENCE = 3, F_ALT_SEQUENCE = 4, F_MATCH = 5, F_NO_MATCH = 6 };
+
 struct SequenceFilter {
   const Fst* fst1;
+  const Fst* fst2 = nullptr;
+  FilterKind kind = F_SEQUENCE;
   uint32_t s1 = NO_STATE_ID, s2 = NO_STATE_ID, fs = NO_STATE_ID;
-  bool alleps1 = false, noeps1 = false;
-  void set_state(uint32_t s1_, uint32_t s2_, uint32_t fs_) {  // :134-148
+  bool alleps1 = false, noeps1 = false, alleps2 = false, noeps2 = false;
+  // set_state: sequence_compose_filter.rs:134-148, alt_sequence_compose_filter.rs:143-158,
+  // match_compose_filter.rs:126-147 (fst1: OUTPUT epsilons, fst2: INPUT epsilons); no-op for the trivial-state filters
+  void set_state(uint32_t s1_, uint32_t s2_, uint32_t fs_) {
     if (!(s1 == s1_ && s2 == s2_ && fs == fs_)) {
       s1 = s1_;
       s2 = s2_;
       fs = fs_;
       const State& st = fst1->states[s1];
-      size_t na1 = st.trs.size();
-      size_t ne1 = st.noepsilons;
-      bool fin1 = st.has_final;
-      alleps1 = na1 == ne1 && !fin1;
-      noeps1 = ne1 == 0;
+      alleps1 = st.trs.size() == st.noepsilons && !st.has_final;
+      noeps1 = st.noepsilons == 0;
+      if (fst2) {
+        const State& st2 = fst2->states[s2];
+        alleps2 = st2.trs.size() == st2.niepsilons && !st2.has_final;
+        noeps2 = st2.niepsilons == 0;
+      }
     }
   }
-  uint32_t filter_tr(const Tr& arc1, const Tr& arc2) const {  // :150-171
-    if (arc1.olabel == NO_LABEL) {
-      if (alleps1) return NO_STATE_ID;
-      return noeps1 ? 0u : 1u;
-    } else if (arc2.ilabel == NO_LABEL) {
-      return fs != 0 ? NO_STATE_ID : 0u;
-    } else if (arc1.olabel == EPS_LABEL) {
-      return NO_STATE_ID;
+  uint32_t filter_tr(const Tr& arc1, const Tr& arc2) const {
+    switch (kind) {
+      case F_NULL:  // null_compose_filter.rs:122-129
+        return (arc1.olabel == NO_LABEL || arc2.ilabel == NO_LABEL) ? NO_STATE_ID : 0u;
+      case F_TRIVIAL:  // trivial_compose_filter.rs:122-124
+        return 0u;
+      case F_NO_MATCH:  // no_match_compose_filter.rs:122-126
+        return (arc1.olabel != EPS_LABEL || arc2.ilabel != EPS_LABEL) ? 0u : NO_STATE_ID;
+      case F_ALT_SEQUENCE:  // alt_sequence_compose_filter.rs:160-181
+        if (arc2.ilabel == NO_LABEL) {
+          if (alleps2) return NO_STATE_ID;
+          return noeps2 ? 0u : 1u;
+        } else if (arc1.olabel == NO_LABEL) {
+          return fs == 1 ? NO_STATE_ID : 0u;
+        } else if (arc1.olabel == EPS_LABEL) {
+          return NO_STATE_ID;
+        }
+        return 0u;
+      case F_MATCH:  // match_compose_filter.rs:149-205
+        if (arc2.ilabel == NO_LABEL) {  // epsilon in fst1
+          if (fs == 0) return noeps2 ? 0u : (alleps2 ? NO_STATE_ID : 1u);
+          return fs == 1 ? 1u : NO_STATE_ID;
+        } else if (arc1.olabel == NO_LABEL) {  // epsilon in fst2
+          if (fs == 0) return noeps1 ? 0u : (alleps1 ? NO_STATE_ID : 2u);
+          return fs == 2 ? 2u : NO_STATE_ID;
+        } else if (arc1.olabel == EPS_LABEL) {  // epsilon in both
+          return fs == 0 ? 0u : NO_STATE_ID;
+        }
+        return 0u;
+      default:  // F_AUTO / F_SEQUENCE: sequence_compose_filter.rs:150-171
+        if (arc1.olabel == NO_LABEL) {
+          if (alleps1) return NO_STATE_ID;
+          return noeps1 ? 0u : 1u;
+        } else if (arc2.ilabel == NO_LABEL) {
+          return fs != 0 ? NO_STATE_ID : 0u;
+        } else if (arc1.olabel == EPS_LABEL) {
+          return NO_STATE_ID;
+        }
+        return 0u;
     }
-    return 0u;
   }
 };
 
@@ -492,11 +533,12 @@ struct ComposeOp {
   const Fst& fst1;
   const Fst& fst2;
   MatchType match_type;
-  uint64_t properties;
+  uint64_t properties;  // compose_filter.properties(cprops) is the identity for all six filters
   StateTable table;
+  FilterKind filter_kind = F_SEQUENCE;
 
-  ComposeOp(const Fst& a, const Fst& b, MatchType mt)
-      : fst1(a), fst2(b), match_type(mt), properties(P::compose_properties(a.properties, b.properties)) {}
+  ComposeOp(const Fst& a, const Fst& b, MatchType mt, FilterKind fk = F_SEQUENCE)
+      : fst1(a), fst2(b), match_type(mt), properties(P::compose_properties(a.properties, b.properties)), filter_kind(fk) {}
 
   // compute_start :389-404
   bool compute_start(uint32_t* out) {
@@ -557,7 +599,7 @@ struct ComposeOp {
   // compute_trs :406-418
   std::vector<Tr> compute_trs(uint32_t state) {
     Tuple tuple = table.find_tuple(state);
-    SequenceFilter filter{&fst1};
+    SequenceFilter filter{&fst1, &fst2, filter_kind};
     filter.set_state(tuple.s1, tuple.s2, tuple.fs);
     if (match_input(tuple.s1, tuple.s2)) return ordered_expand(tuple.s2, tuple.s1, true, filter);
     return ordered_expand(tuple.s1, tuple.s2, false, filter);
@@ -580,10 +622,15 @@ void connect_impl(Fst& fst);
 
 // compose_with_config (AutoFilter / SequenceFilter + SortedMatcher) — compose_static.rs:166-266;
 // LazyFst::compute — lazy/lazy_fst.rs:226-269
-bool compose_impl(const Fst& fst1, const Fst& fst2, bool connect, Fst& fst_out, uint64_t* arcs_pre_trim) {
+bool compose_impl(const Fst& fst1, const Fst& fst2, bool connect, Fst& fst_out, uint64_t* arcs_pre_trim,
+                  int filter = F_AUTO) {
   MatchType mt;
   if (!compose_match_type(fst1, fst2, &mt)) return false;
-  ComposeOp op(fst1, fst2, mt);
+  if (filter < F_AUTO || filter > F_NO_MATCH) {
+    t_err = "unknown compose filter";
+    return false;
+  }
+  ComposeOp op(fst1, fst2, mt, filter == F_AUTO ? F_SEQUENCE : (FilterKind)filter);
   fst_out = Fst();
   uint32_t start_state;
   uint64_t n_arcs = 0;
@@ -1812,6 +1859,14 @@ int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int 
   DeltaGuard g(eq_mode);
   auto res = std::make_unique<oracle_fst>();
   if (!compose_impl(*f1, *f2, connect != 0, *res, nullptr)) return 1;
+  *out = res.release();
+  return 0;
+}
+
+int oracle_compose_filter(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode, int filter, oracle_fst** out) {
+  DeltaGuard g(eq_mode);
+  auto res = std::make_unique<oracle_fst>();
+  if (!compose_impl(*f1, *f2, connect != 0, *res, nullptr, filter)) return 1;
   *out = res.release();
   return 0;
 }

@@ -69,6 +69,10 @@ size_t oracle_fst_store_const(const oracle_fst*, uint8_t* out, size_t cap);
 /* compose_with_config(AutoFilter|SequenceFilter, connect): compose_static.rs:166-266 */
 int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode,
                    oracle_fst** out);
+/* compose_with_config with an explicit ComposeFilterEnum value (compose_static.rs:19-33,166-266):
+ * 0 Auto, 1 Null, 2 Trivial, 3 Sequence, 4 AltSequence, 5 Match, 6 NoMatch (default SortedMatchers) */
+int oracle_compose_filter(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode, int filter,
+                          oracle_fst** out);
 /* connect(): connect.rs:51-66 */
 int oracle_connect(oracle_fst*);
 /* shortest_path_with_config(nshortest=1): shortest_path.rs:107-133,173-282.

@@ -59,6 +59,7 @@ def lib():
         L.oracle_fst_store_const.argtypes = [vp, vp, C.c_size_t]
         L.oracle_fst_store_const.restype = C.c_size_t
         L.oracle_compose.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.oracle_compose_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_connect.argtypes = [vp]
         L.oracle_shortest_path.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.POINTER(f32)]
         L.oracle_shortest_path_canonical.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(f32), C.POINTER(u32)]
@@ -174,9 +175,10 @@ class OracleFst:
         return ni, no
 
     # -- algorithms
-    def compose(self, other, connect=True, eq_mode=EQ_REF_KDELTA):
+    def compose(self, other, connect=True, eq_mode=EQ_REF_KDELTA, compose_filter=0):
+        """compose_filter: ComposeFilterEnum value (0 Auto, 1 Null, 2 Trivial, 3 Sequence, 4 AltSequence, 5 Match, 6 NoMatch)."""
         out = C.c_void_p()
-        if lib().oracle_compose(self._h, other._h, 1 if connect else 0, eq_mode, C.byref(out)):
+        if lib().oracle_compose_filter(self._h, other._h, 1 if connect else 0, eq_mode, int(compose_filter), C.byref(out)):
             raise _err()
         return OracleFst(out.value)
 

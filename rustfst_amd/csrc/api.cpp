@@ -253,11 +253,9 @@ wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fs
   return wrap([&] {
     if (!ctx || !fst1 || !fst2 || !out) throw Error("null pointer");
     wfst_compose_config c = cfg ? *cfg : wfst_compose_config{0, 1};  // ComposeConfig::default(), compose_static.rs:56-65
-    if (c.compose_filter != 0 && c.compose_filter != 3)
-      throw Error("unsupported: compose_filter " + std::to_string(c.compose_filter) +
-                  " is not implemented on the GPU path (Auto=0 and Sequence=3 are); use the CPU path");
+    if (c.compose_filter > 6) throw Error("unknown compose_filter " + std::to_string(c.compose_filter));  // compose.rs:20-33
     HIP_CHECK(hipSetDevice(ctx->device));
-    *out = compose(ctx, fst1, fst2, c.connect != 0);
+    *out = compose(ctx, fst1, fst2, c.connect != 0, c.compose_filter);
   });
 }
 
@@ -307,10 +305,10 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
     if (!ctx || !t || !outs || (n && !acceptors)) throw Error("null pointer");
     wfst_compose_config c = ccfg ? *ccfg : wfst_compose_config{0, 1};
     wfst_shortest_path_config s = scfg ? *scfg : wfst_shortest_path_config{1e-6f, 1, 0};
-    if (c.compose_filter != 0 && c.compose_filter != 3) throw Error("unsupported: compose_filter");
+    if (c.compose_filter > 6) throw Error("unknown compose_filter");
     if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
     HIP_CHECK(hipSetDevice(ctx->device));
-    compose_shortest_path_batch(ctx, acceptors, n, t, c.connect != 0, outs, composed_arcs);
+    compose_shortest_path_batch(ctx, acceptors, n, t, c.connect != 0, outs, composed_arcs, c.compose_filter);
   });
 }
 
@@ -322,11 +320,11 @@ wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst
     *job = nullptr;
     wfst_compose_config c = ccfg ? *ccfg : wfst_compose_config{0, 1};
     wfst_shortest_path_config s = scfg ? *scfg : wfst_shortest_path_config{1e-6f, 1, 0};
-    if (c.compose_filter != 0 && c.compose_filter != 3) throw Error("unsupported: compose_filter");
+    if (c.compose_filter > 6) throw Error("unknown compose_filter");
     if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
     if (ctx->batch_in_flight) throw Error("a fused batch is already in flight on this context");
     HIP_CHECK(hipSetDevice(ctx->device));
-    *job = compose_shortest_path_batch_begin(ctx, acceptors, n, t);
+    *job = compose_shortest_path_batch_begin(ctx, acceptors, n, t, c.compose_filter);
     ctx->batch_in_flight = true;
   });
 }

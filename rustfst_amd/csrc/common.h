@@ -140,7 +140,7 @@ struct DeviceCsr {
   const float* finals = nullptr;      // [n], +inf = non-final
   const uint32_t* noeps = nullptr;    // [n] number of output-epsilon arcs (VectorFstState.noepsilons)
   const uint2* wn = nullptr;          // [E] packed {weight bits, nextstate}: the 8 B the relaxation needs
-  const uint4* srec = nullptr;        // [n] {arc begin, arc count, final bits, noeps}: one 16-B load per state in compose
+  const uint4* srec = nullptr;        // [n] {arc begin, arc count, final bits, SREC_* epsilon facts}: one 16-B load per state in compose
 };
 
 namespace wfst {
@@ -148,6 +148,14 @@ struct RevCsr {
   DBuf<uint32_t> off;  // [n+1]
   DBuf<uint2> arc;     // [E] {source state, position of the arc in the source's arc list}
 };
+}  // namespace wfst
+
+namespace wfst {
+// 4th word of a device state record (DeviceCsr::srec): what the compose filters' set_state needs to know
+constexpr uint32_t SREC_NO_OEPS = 1u;   // no arc with olabel 0
+constexpr uint32_t SREC_ALL_OEPS = 2u;  // every arc has olabel 0 (vacuously true without arcs)
+constexpr uint32_t SREC_NO_IEPS = 4u;   // no arc with ilabel 0
+constexpr uint32_t SREC_ALL_IEPS = 8u;  // every arc has ilabel 0
 }  // namespace wfst
 
 struct HostCsr {
@@ -202,10 +210,11 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
 // tr_sort.hip
 void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
 // compose.hip
-wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect);
+wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect, uint32_t filter = 0);
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,
-                                 wfst_fst** outs, uint64_t* composed_arcs);
-wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t);
+                                 wfst_fst** outs, uint64_t* composed_arcs, uint32_t filter = 0);
+wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t,
+                                                  uint32_t filter = 0);
 void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs);
 void compose_shortest_path_batch_abandon(wfst_batch_job* job);
 wfst_ctx* batch_job_ctx(const wfst_batch_job* job);

@@ -34,6 +34,11 @@ namespace {
 
 constexpr uint32_t NO_LABEL = WFST_NO_LABEL;
 constexpr uint32_t REJECT = 0xFFFFFFFFu;  // FilterState::new_no_state()
+// bits of the 4th word of a state record (fst_store.hip derive_noeps_kernel; common.h SREC_*)
+using wfst::SREC_ALL_IEPS;
+using wfst::SREC_ALL_OEPS;
+using wfst::SREC_NO_IEPS;
+using wfst::SREC_NO_OEPS;
 constexpr uint64_t HT_EMPTY = ~0ull;
 constexpr uint32_t HV_INIT = 0xFFFFFFFFu;
 constexpr uint32_t HV_PEND = 0x80000000u;
@@ -56,7 +61,7 @@ struct FstView {
 struct ProblemDesc {
   FstView f1;
   uint32_t mode;
-  uint32_t pad;
+  uint32_t filter;  // ComposeFilterEnum value (compose_static.rs:19-33); 0 (Auto) == 3 (Sequence)
 };
 
 struct Caps {
@@ -208,9 +213,12 @@ __device__ __forceinline__ uint32_t hash_u64(uint64_t h) {
   h ^= h >> 33;
   return (uint32_t)h;
 }
+// ComposeStateTuple {fs, s1, s2} in one u64: fs (0..2) : 2 | s1 : 30 | s2 : 32
+constexpr uint32_t TUPLE_S1_MASK = 0x3FFFFFFFu;
 __device__ __forceinline__ uint64_t pack_tuple(uint32_t fs, uint32_t s1, uint32_t s2) {
-  return ((uint64_t)fs << 63) | ((uint64_t)s1 << 32) | s2;
+  return ((uint64_t)fs << 62) | ((uint64_t)s1 << 32) | s2;
 }
+__device__ __forceinline__ uint32_t tuple_s1(uint64_t tk) { return (uint32_t)(tk >> 32) & TUPLE_S1_MASK; }
 
 // StateTable::find_id (lazy/state_table.rs:49-59) as an open-addressing table.  The value word is
 // atomicMin(first emission index of this level) while the tuple is new, then its final id.
@@ -312,24 +320,28 @@ enum : int { EXP_OK = 0, EXP_ARENA_OVERFLOW = 1, EXP_FAST_OVERFLOW = 2 };
 //                the level is ranked).
 //  FAST = true : stages the arcs in LDS at stg[*level_cnt ...]; nothing touches the hash table here.
 template <bool FAST>
-__device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode, const Arena& ar, const Caps& caps,
+__device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode, uint32_t filter, const Arena& ar,
+                            const Caps& caps,
                             uint32_t q, uint64_t tk, uint4 r1, uint4 r2, uint64_t src_sk, const Level& lv,
                             uint32_t* n_arcs_io, FastStage* stg, uint32_t* level_cnt_io, uint32_t* status) {
   const uint32_t lane = lane_id();
   const uint32_t hmask = caps.H - 1;
-  const uint32_t fs = (uint32_t)(tk >> 63);
-  const uint32_t s1 = (uint32_t)(tk >> 32) & 0x7FFFFFFFu;
+  const uint32_t fs = (uint32_t)(tk >> 62);
+  const uint32_t s1 = tuple_s1(tk);
   const uint32_t s2 = (uint32_t)tk;
   // r1 / r2 = the 16-byte state records {arc begin, arc count, final bits, noeps} of s1 in fst1 / s2 in fst2
   const uint32_t b1 = r1.x, b2 = r2.x;
   const uint32_t n1 = r1.y, n2 = r2.y;
   const float fin1 = __uint_as_float(r1.z), fin2 = __uint_as_float(r2.z);
-  const uint32_t ne1 = r1.w;
   // compute_final_weight :420-449 (final1 (x) final2; None when either is None / the product is zero)
   if (lane == 0) ar.fin[q] = (fin1 != INF && fin2 != INF) ? wtimes(fin1, fin2) : INF;
-  // SequenceComposeFilter::set_state :134-148
-  const bool alleps1 = (n1 == ne1) && !(fin1 != INF);
-  const bool noeps1 = ne1 == 0;
+  // set_state of the filters (sequence_compose_filter.rs:134-148, alt_sequence_compose_filter.rs:143-158,
+  // match_compose_filter.rs:126-147): fst1 looks at its OUTPUT epsilons, fst2 at its INPUT epsilons; the state
+  // record carries the four facts as bits (SREC_*)
+  const bool alleps1 = (r1.w & SREC_ALL_OEPS) && !(fin1 != INF);
+  const bool noeps1 = (r1.w & SREC_NO_OEPS) != 0;
+  const bool alleps2 = (r2.w & SREC_ALL_IEPS) && !(fin2 != INF);
+  const bool noeps2 = (r2.w & SREC_NO_IEPS) != 0;
   // match_input :199-219 (SortedMatcher::priority = num_trs)
   const bool mi = mode == MODE_BOTH ? (n1 <= n2) : (mode == MODE_INPUT);
   const wfst_tr* it_arcs = mi ? f1.arcs + b1 : f2.arcs + b2;
@@ -338,10 +350,39 @@ __device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode,
   const uint32_t n_se = mi ? n2 : n1;
   const uint32_t sa = mi ? s2 : s1;
   const uint32_t sb = mi ? s1 : s2;
-  // filter_tr outcomes :150-171, constant per composed state:
-  //   X: the fst1-side arc has olabel NO_LABEL (fst2 moves alone)    Y: the fst2-side arc has ilabel NO_LABEL
-  const uint32_t fsX = alleps1 ? REJECT : (noeps1 ? 0u : 1u);
-  const uint32_t fsY = fs != 0 ? REJECT : 0u;
+  // filter_tr outcomes, constant per composed state; the four classes of (arc1, arc2) pairs a matcher can produce:
+  //   X: arc1.olabel == NO_LABEL (fst1 stands still, fst2 takes an input-epsilon arc)
+  //   Y: arc2.ilabel == NO_LABEL (fst2 stands still, fst1 takes an output-epsilon arc)
+  //   Z: both real, arc1.olabel == 0 == arc2.ilabel                 M: both real, matching non-epsilon label
+  uint32_t fsX, fsY, fsZ, fsM = 0u;
+  switch (filter) {
+    case 1:  // NullComposeFilter :122-129
+      fsX = fsY = REJECT;
+      fsZ = 0u;
+      break;
+    case 2:  // TrivialComposeFilter :122-124
+      fsX = fsY = fsZ = 0u;
+      break;
+    case 4:  // AltSequenceComposeFilter :160-181
+      fsY = alleps2 ? REJECT : (noeps2 ? 0u : 1u);
+      fsX = fs == 1u ? REJECT : 0u;
+      fsZ = REJECT;
+      break;
+    case 5:  // MatchComposeFilter :149-205
+      fsY = fs == 0u ? (noeps2 ? 0u : (alleps2 ? REJECT : 1u)) : (fs == 1u ? 1u : REJECT);
+      fsX = fs == 0u ? (noeps1 ? 0u : (alleps1 ? REJECT : 2u)) : (fs == 2u ? 2u : REJECT);
+      fsZ = fs == 0u ? 0u : REJECT;
+      break;
+    case 6:  // NoMatchComposeFilter :122-126
+      fsX = fsY = 0u;
+      fsZ = REJECT;
+      break;
+    default:  // Auto / SequenceComposeFilter :150-171
+      fsX = alleps1 ? REJECT : (noeps1 ? 0u : 1u);
+      fsY = fs != 0u ? REJECT : 0u;
+      fsZ = REJECT;
+      break;
+  }
   const uint32_t fs_nolabel = mi ? fsX : fsY;  // iterated arc labelled NO_LABEL (the loop pseudo-arc)
   const uint32_t fs_eps = mi ? fsY : fsX;      // iterated arc labelled 0 paired with the matcher's EpsLoop
 
@@ -384,21 +425,25 @@ __device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode,
     } else if (have) {
       equal_range_global(se_arcs, n_se, mi, skey, &lo, &cnt);
     }
-    uint32_t fsn;  // filter state of the emitted arcs of this item
+    uint32_t fsn;  // filter state of the emitted arcs of this item (of its real pairs when eps_item)
     bool eps_item = false;
+    uint32_t loop1 = 0;  // 1: the first pair of an eps_item is the matcher's EpsLoop (accepted by the filter)
     if (!have) {
       cnt = 0;
       fsn = REJECT;
     } else if (label == NO_LABEL) {
       fsn = fs_nolabel;  // real arcs with key 0, no EpsLoop (sorted_matcher.rs:127-139)
     } else if (label == 0u) {
-      fsn = fs_eps;  // EpsLoop first; the real epsilon arcs that follow are all rejected (:167-168)
+      // the matcher yields EpsLoop first, then the real epsilon arcs (:124-184); the filter sees the loop as class
+      // X/Y and the real ones as class Z (rejected by the sequence filters, accepted by Null/Trivial/Match)
       eps_item = true;
-      cnt = 1;
+      loop1 = fs_eps != REJECT ? 1u : 0u;
+      fsn = fsZ;
+      cnt = loop1 + (fsZ != REJECT ? cnt : 0u);
     } else {
-      fsn = 0u;
+      fsn = fsM;
     }
-    if (fsn == REJECT) cnt = 0;
+    if (!eps_item && fsn == REJECT) cnt = 0;
     uint32_t total, pos, maxcnt;
     if (__ballot(cnt > 1u) == 0) {  // every item emits 0 or 1 arc (the usual case): two ballots replace the scans
       const uint64_t em = __ballot(cnt == 1u);
@@ -421,19 +466,21 @@ __device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode,
     }
     for (uint32_t m = 0; m < maxcnt; ++m) {
       ArcReg aa;
+      const bool is_loop = loop1 != 0u && m == 0u;  // (loop1 is only ever set on eps items)
       if (small) {
-        aa = shfl_arc(se, (lo + m) & 63u);
+        aa = shfl_arc(se, (lo + m - loop1) & 63u);
       } else {
         aa = ArcReg{0, 0, 0.0f, 0};
-        if (m < cnt && !eps_item) aa = load_arc(se_arcs + lo + m);
+        if (m < cnt && !is_loop) aa = load_arc(se_arcs + lo + m - loop1);
       }
       if (m < cnt) {
-        if (eps_item) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, sa} : ArcReg{0u, NO_LABEL, 0.0f, sa};  // eps_loop, mod.rs:98-105
+        const uint32_t fsn_m = is_loop ? fs_eps : fsn;
+        if (is_loop) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, sa} : ArcReg{0u, NO_LABEL, 0.0f, sa};  // eps_loop, mod.rs:98-105
         // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319); selected field by field so that the
         // structs stay in registers (a reference select would push them to scratch)
         const ArcReg a1{mi ? ab.il : aa.il, mi ? ab.ol : aa.ol, mi ? ab.w : aa.w, mi ? ab.ns : aa.ns};
         const ArcReg a2{mi ? aa.il : ab.il, mi ? aa.ol : ab.ol, mi ? aa.w : ab.w, mi ? aa.ns : ab.ns};
-        const uint64_t key = pack_tuple(fsn, a1.ns, a2.ns);
+        const uint64_t key = pack_tuple(fsn_m, a1.ns, a2.ns);
         const float wsum = wtimes(a1.w, a2.w);  // add_tr :267-285
         if (FAST) {
           const uint32_t e = level_cnt + pos + m;
@@ -523,6 +570,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
   const ProblemDesc desc = descs[p];
   const FstView f1 = desc.f1;
   const uint32_t mode = desc.mode;
+  const uint32_t filter = desc.filter;
   const Arena ar = carve_arena(arena_base + (size_t)p * arena_stride, caps);
   Result res;
   res.status = ST_OK;
@@ -583,7 +631,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
           const uint64_t tk = rl64(f_key, q - lo);
           const uint64_t ssk = rl64(f_sk, q - lo);
           if (lane == 0) ar.off[q] = n_arcs + level_cnt;
-          rc = expand_state<true>(f1, f2, mode, ar, caps, q, tk, rl128(f_r1, q - lo), rl128(f_r2, q - lo), ssk, lv,
+          rc = expand_state<true>(f1, f2, mode, filter, ar, caps, q, tk, rl128(f_r1, q - lo), rl128(f_r2, q - lo), ssk, lv,
                                   &n_arcs, &stg, &level_cnt, &res.status);
           if (rc != EXP_OK) break;
         }
@@ -610,7 +658,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
           // removes one dependent trip to HBM from the next level
           uint4 pr1 = make_uint4(0, 0, 0, 0), pr2 = make_uint4(0, 0, 0, 0);
           if (have) {
-            pr1 = f1.srec[(uint32_t)(key >> 32) & 0x7FFFFFFFu];
+            pr1 = f1.srec[tuple_s1(key)];
             pr2 = f2.srec[(uint32_t)key];
           }
           // first occurrence of each destination tuple inside the level + min candidate of its group
@@ -684,7 +732,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       for (uint32_t q = lo; q < hi; ++q) {
         if (lane == 0) ar.off[q] = n_arcs;
         const uint64_t tk = ar.tuples[q];
-        if (expand_state<false>(f1, f2, mode, ar, caps, q, tk, f1.srec[(uint32_t)(tk >> 32) & 0x7FFFFFFFu],
+        if (expand_state<false>(f1, f2, mode, filter, ar, caps, q, tk, f1.srec[tuple_s1(tk)],
                                 f2.srec[(uint32_t)tk], KEY_INF, lv, &n_arcs, nullptr, nullptr, &res.status) != EXP_OK) {
           ok = false;
           break;
@@ -742,7 +790,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
         f_key = lane < n_new ? ar.tuples[lo + lane] : 0ull;
         f_sk = ((FLAGS & FLAG_SP) && lane < n_new) ? ld_l2(&ar.skey[lo + lane]) : KEY_INF;
         if (lane < n_new) {
-          f_r1 = f1.srec[(uint32_t)(f_key >> 32) & 0x7FFFFFFFu];
+          f_r1 = f1.srec[tuple_s1(f_key)];
           f_r2 = f2.srec[(uint32_t)f_key];
         }
       }
@@ -1122,7 +1170,8 @@ const char* status_name(uint32_t s) {
 
 }  // namespace
 
-wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect) {
+wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect, uint32_t filter) {
+  if (f1->n_states > TUPLE_S1_MASK) throw Error("compose: the 1st FST has more than 2^30 states");
   const uint32_t mode = decide_match_mode(f1->props, f2->props);
   ensure_device(const_cast<wfst_fst*>(f1));
   ensure_device(const_cast<wfst_fst*>(f2));
@@ -1136,7 +1185,7 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
   std::vector<ProblemDesc> descs(1);
   descs[0].f1 = view_of(f1);
   descs[0].mode = mode;
-  descs[0].pad = 0;
+  descs[0].filter = filter;
   const FstView v2 = view_of(f2);
   uint64_t est_s = 4ull * std::max<uint64_t>(f1->n_states, 64) + 1024;
   uint64_t est_a = 4ull * est_s;
@@ -1189,7 +1238,8 @@ struct wfst_batch_job {
 
 namespace wfst {
 
-wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t) {
+wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t,
+                                                  uint32_t filter) {
   auto job = std::make_unique<wfst_batch_job>();
   job->ctx = ctx;
   job->n = n;
@@ -1201,10 +1251,11 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   uint64_t max_states = 64;
   for (size_t i = 0; i < n; ++i) {
     if (!accs[i]) throw Error("null acceptor in batch");
+    if (accs[i]->n_states > TUPLE_S1_MASK) throw Error("compose: a 1st FST has more than 2^30 states");
     job->descs[i].mode = decide_match_mode(accs[i]->props, t->props);
     ensure_device(const_cast<wfst_fst*>(accs[i]));
     job->descs[i].f1 = view_of(accs[i]);
-    job->descs[i].pad = 0;
+    job->descs[i].filter = filter;
     job->todo[i] = i;
     max_states = std::max<uint64_t>(max_states, accs[i]->n_states);
   }
@@ -1280,8 +1331,8 @@ void compose_shortest_path_batch_abandon(wfst_batch_job* job) {
 }
 
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool /*connect*/,
-                                 wfst_fst** outs, uint64_t* composed_arcs) {
-  compose_shortest_path_batch_end(compose_shortest_path_batch_begin(ctx, accs, n, t), outs, composed_arcs);
+                                 wfst_fst** outs, uint64_t* composed_arcs, uint32_t filter) {
+  compose_shortest_path_batch_end(compose_shortest_path_batch_begin(ctx, accs, n, t, filter), outs, composed_arcs);
 }
 
 }  // namespace wfst

@@ -85,10 +85,15 @@ __global__ void derive_noeps_kernel(const uint32_t* __restrict__ offsets, const 
     srec[s] = make_uint4(b, 0u, __float_as_uint(finals[s]), 0u);
     return;
   }
-  uint32_t c = 0;
-  for (uint32_t i = b; i < e; ++i) c += arcs[i].olabel == WFST_EPS_LABEL;
+  uint32_t c = 0, ci = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    c += arcs[i].olabel == WFST_EPS_LABEL;
+    ci += arcs[i].ilabel == WFST_EPS_LABEL;
+  }
   noeps[s] = c;
-  srec[s] = make_uint4(b, e - b, __float_as_uint(finals[s]), c);
+  const uint32_t facts = (c == 0 ? SREC_NO_OEPS : 0u) | (c == e - b ? SREC_ALL_OEPS : 0u) | (ci == 0 ? SREC_NO_IEPS : 0u) |
+                         (ci == e - b ? SREC_ALL_IEPS : 0u);
+  srec[s] = make_uint4(b, e - b, __float_as_uint(finals[s]), facts);
 }
 
 struct Layout {

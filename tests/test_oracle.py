@@ -315,3 +315,27 @@ def test_shortest_distance_and_reverse(oracle):
     assert r["offsets"][1] == n_final and len(r["arcs"]) == len(flat["arcs"]) + n_final
     rr = f.reverse().reverse().to_flat()  # reversing twice gives the language back (two extra states)
     assert rr["n_states"] == flat["n_states"] + 2
+
+
+# ---------------------------------------------------------------- §8(f) N4: the six compose filters of ComposeFilterEnum
+# Unpinned by reference output (the reference's filter goldens are produced by OpenFST at CI time); checked through
+# what every epsilon filter must preserve: the weighted relation.  All filters except Null (which drops epsilon-only
+# moves by design) accept exactly the same (input, output) strings; the sequencing filters merely remove redundant
+# epsilon paths, so the best weight agrees with Trivial's (which keeps every path).
+@pytest.mark.parametrize("seed", range(10))
+def test_compose_filters_preserve_the_best_path(oracle, seed):
+    rng = np.random.default_rng(6000 + seed)
+    a = random_fst_flat(rng, int(rng.integers(3, 9)), 3, 2, p_eps_o=0.4, p_final=0.4, sort="olabel", min_fanout=1)
+    b = random_fst_flat(rng, int(rng.integers(3, 9)), 3, 2, p_eps_i=0.4, p_final=0.4, sort="ilabel", min_fanout=1)
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    best = {}
+    for flt in (0, 2, 3, 4, 5, 6):
+        c = oa.compose(ob, compose_filter=flt)
+        best[flt] = float(c.shortest_path_canonical().total_weight)
+    assert oa.compose(ob, compose_filter=0) == oa.compose(ob, compose_filter=3)  # Auto is the sequence filter
+    ref = best[2]
+    for flt, w in best.items():
+        assert (np.isinf(w) and np.isinf(ref)) or w == pytest.approx(ref, abs=1e-5), (flt, best)
+    # Null: a sub-relation (no lone epsilon moves) — never better than the others
+    wn = float(oa.compose(ob, compose_filter=1).shortest_path_canonical().total_weight)
+    assert wn >= ref - 1e-5
