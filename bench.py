@@ -49,6 +49,9 @@ def parse_args():
                     help="run S1 then S2 of a step on ONE stream.  Default: S2's batch is enqueued asynchronously on a "
                          "second context / HIP stream (wfst_compose_shortest_path_batch_begin), S1 runs on the first, "
                          "then the batch is collected — the two independent requests overlap on the GPU.")
+    ap.add_argument("--batch-cus", type=int, default=64,
+                    help="compute units reserved for the batch context when the two requests overlap (the other "
+                         "context gets the rest; hipExtStreamCreateWithCUMask).  0 = no partitioning.")
     args = ap.parse_args()
     args.overlap = not args.serial
     return args
@@ -78,11 +81,26 @@ def main():
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     stream = torch.cuda.Stream(device=device)
-    ctx = rustfst_amd.Context(local_rank, stream=stream.cuda_stream)
+    if args.overlap and args.batch_cus > 0:
+        # Two contexts on DISJOINT compute units: the batch kernel is 64 lone waves chasing dependent loads, and a
+        # load issued from a CU that also hosts streaming relaxation waves waits 2-4x longer in that CU's memory
+        # queue (tools/cu_mask_test.py: 1.08 -> 0.90 ms per step).  CU i = bit i%32 of word i//32.
+        n_cus = torch.cuda.get_device_properties(device).multi_processor_count
+        k = min(args.batch_cus, n_cus - 1)
+        small = np.zeros((n_cus + 31) // 32, dtype=np.uint32)
+        for cu in range(k):
+            small[cu // 32] |= np.uint32(1 << (cu % 32))
+        big = np.zeros_like(small)
+        for cu in range(k, n_cus):
+            big[cu // 32] |= np.uint32(1 << (cu % 32))
+        ctx = rustfst_amd.Context(local_rank, cu_mask=big)
+        ctx2 = rustfst_amd.Context(local_rank, cu_mask=small)
+    else:
+        ctx = rustfst_amd.Context(local_rank, stream=stream.cuda_stream)
+        # second context (own HIP stream + pools) for the batch pipeline: S1 and S2 are independent requests
+        stream2 = torch.cuda.Stream(device=device, priority=-1)
+        ctx2 = ctx if (not args.overlap) else rustfst_amd.Context(local_rank, stream=stream2.cuda_stream)
     rustfst_amd.set_default_context(ctx)
-    # second context (own HIP stream + pools) for the batch pipeline: S1 and S2 are independent requests
-    stream2 = torch.cuda.Stream(device=device, priority=-1)
-    ctx2 = ctx if (not args.overlap) else rustfst_amd.Context(local_rank, stream=stream2.cuda_stream)
 
     # ------------------------------------------------------------------ synthetic workload (identical on all ranks)
     t0 = time.time()
@@ -143,16 +161,18 @@ def main():
             arcs = int(ta.item())
 
         # ------------------------------------------------------------------ per-part times (untimed extra pass)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record(stream)
-        sp = dt.shortest_path()
-        ev[1].record(stream)
-        ctx.synchronize()
-        outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt2)
-        ev[2].record(stream)
-        torch.cuda.synchronize(device)
-        ms_sp_t = ev[0].elapsed_time(ev[1])
-        ms_batch = ev[1].elapsed_time(ev[2])
+        # each request ALONE on its own context, host clock around the synchronous call (3 repetitions, best)
+        def alone(fn):
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize(device)
+                c0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(device)
+                best = min(best, time.perf_counter() - c0)
+            return 1e3 * best
+        ms_sp_t = alone(lambda: dt.shortest_path())
+        ms_batch = alone(lambda: rustfst_amd.compose_shortest_path_batch(daccs, dt2, ctx=ctx2))
         sweeps = ctx.stats()["sweeps"]
 
         # ------------------------------------------------------------------ roofline of the relaxation kernel
@@ -227,7 +247,8 @@ def main():
             "metric": "arcs relaxed/sec (compose -> shortest_path, 1M-state / 10M-arc FST)",
             "value": round(value, 1), "unit": "arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread)",
+            "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread); "
+                             + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"configs[2]+[3]: shortest_path(T) + fused compose->shortest_path of {args.batch_per_gpu} "

@@ -63,6 +63,11 @@ uint32_t wfst_abi_version(void);
 wfst_status wfst_ctx_create(int device, wfst_ctx** out);
 /* use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); not owned */
 wfst_status wfst_ctx_create_on_stream(int device, void* hip_stream, wfst_ctx** out);
+/* context whose (own) stream may only use the compute units set in cu_mask (bit i of word i/32 = CU i;
+ * hipExtStreamCreateWithCUMask).  For serving several request classes on one GPU: the fused batch is a handful of
+ * long single-wave workgroups whose dependent loads slow down ~40 % when bandwidth-hungry kernels of another context
+ * share their CUs; giving each context disjoint CUs removes that interference. */
+wfst_status wfst_ctx_create_with_cu_mask(int device, const uint32_t* cu_mask, uint32_t mask_words, wfst_ctx** out);
 wfst_status wfst_ctx_destroy(wfst_ctx* ctx);
 wfst_status wfst_ctx_synchronize(wfst_ctx* ctx);
 wfst_status wfst_ctx_stream(wfst_ctx* ctx, void** hip_stream);

@@ -38,6 +38,7 @@ SYMBOLS = [
     ("wfst_abi_version", _u32, []),
     ("wfst_ctx_create", C.c_int, [C.c_int, _P(_vp)]),
     ("wfst_ctx_create_on_stream", C.c_int, [C.c_int, _vp, _P(_vp)]),
+    ("wfst_ctx_create_with_cu_mask", C.c_int, [C.c_int, _vp, _u32, _P(_vp)]),
     ("wfst_ctx_destroy", C.c_int, [_vp]),
     ("wfst_ctx_synchronize", C.c_int, [_vp]),
     ("wfst_ctx_stream", C.c_int, [_vp, _P(_vp)]),

@@ -79,7 +79,7 @@ DeviceArena::~DeviceArena() {
 
 using namespace wfst;
 
-static wfst_ctx* ctx_create(int device, void* stream, bool own) {
+static wfst_ctx* ctx_create(int device, void* stream, bool own, const uint32_t* cu_mask = nullptr, uint32_t mask_words = 0) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0)
@@ -88,7 +88,10 @@ static wfst_ctx* ctx_create(int device, void* stream, bool own) {
   HIP_CHECK(hipSetDevice(device));
   auto ctx = std::make_unique<wfst_ctx>();
   ctx->device = device;
-  if (own) {
+  if (own && cu_mask && mask_words) {
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->stream, mask_words, cu_mask));
+    ctx->owns_stream = true;
+  } else if (own) {
     HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->owns_stream = true;
   } else {
@@ -100,6 +103,12 @@ static wfst_ctx* ctx_create(int device, void* stream, bool own) {
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (cu_mask && mask_words) {  // grids are sized for the CUs this context's stream may use
+    int bits = 0;
+    for (uint32_t w = 0; w < mask_words; ++w) bits += __builtin_popcount(cu_mask[w]);
+    if (bits <= 0) throw Error("empty CU mask");
+    ctx->n_cus = std::min(ctx->n_cus, bits);
+  }
   return ctx.release();
 }
 
@@ -137,6 +146,12 @@ wfst_status wfst_ctx_create_on_stream(int device, void* hip_stream, wfst_ctx** o
   return wrap([&] {
     if (!out) throw Error("null out pointer");
     *out = ctx_create(device, hip_stream, false);
+  });
+}
+wfst_status wfst_ctx_create_with_cu_mask(int device, const uint32_t* cu_mask, uint32_t mask_words, wfst_ctx** out) {
+  return wrap([&] {
+    if (!out || !cu_mask || !mask_words) throw Error("null pointer");
+    *out = ctx_create(device, nullptr, true, cu_mask, mask_words);
   });
 }
 wfst_status wfst_ctx_destroy(wfst_ctx* ctx) {

@@ -13,6 +13,9 @@
 // No MFMA: this is sparse DP; the bound is HBM / L2-atomic traffic (20 B per arc relaxed by the
 // SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
 #include <cstdlib>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 #include "fst_props.h"
@@ -274,13 +277,15 @@ __global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const ui
 }
 
 // f_parent = argmin over final states of (d[s] (x) rho(s), s)      (shortest_path.rs:214-220)
-__global__ void sssp_final_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key, uint32_t n,
-                                  Ctl* __restrict__ ctl) {
+__global__ void __launch_bounds__(256) sssp_final_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key,
+                                                        uint32_t n, Ctl* __restrict__ ctl) {
+  __shared__ unsigned long long s_best[4];
   unsigned long long best = KEY_INF;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const float f = finals[s];
+    if (!(f < INF)) continue;  // most states are not final: their key is never fetched
     const uint64_t k = key[s];
-    if (k == KEY_INF || !(f < INF)) continue;
+    if (k == KEY_INF) continue;
     const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;
     if (!(tot < INF)) continue;
     const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | s;
@@ -290,9 +295,14 @@ __global__ void sssp_final_kernel(const float* __restrict__ finals, const uint64
     const unsigned long long o = __shfl_xor(best, d);
     best = o < best ? o : best;
   }
-  // few atomics on the single result word: only waves that can still lower it try (same-address atomics cost ~12 ns each)
-  if ((threadIdx.x & 63) == 0 && best != KEY_INF && best < __hip_atomic_load(&ctl->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMin(&ctl->best, best);
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) best = s_best[w] < best ? s_best[w] : best;
+    // one atomic per workgroup at most, and only if it can still lower the result (same-address atomics cost ~12 ns each)
+    if (best != KEY_INF && best < __hip_atomic_load(&ctl->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(&ctl->best, best);
+  }
 }
 
 // parent[t] = min (s,pos) over arcs with (d[s]+w, hops[s]+1) == (d[t], hops[t])
@@ -358,36 +368,6 @@ __global__ void sssp_backtrace_kernel(const uint32_t* __restrict__ offsets, cons
 __global__ void __launch_bounds__(256) rev_count_kernel(const uint2* __restrict__ wn, uint64_t n_arcs, uint32_t* __restrict__ indeg) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_arcs; i += (uint64_t)gridDim.x * blockDim.x)
     atomicAdd(&indeg[wn[i].y], 1u);
-}
-// exclusive scan of n counters by ONE workgroup (n is a few million at most; runs once per FST)
-__global__ void __launch_bounds__(1024) rev_scan_kernel(const uint32_t* __restrict__ indeg, uint32_t* __restrict__ rev_off,
-                                                       uint32_t* __restrict__ cursor, uint32_t n) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  for (uint32_t base = 0; base < n; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < n ? indeg[i] : 0u;
-    uint32_t incl = v;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d);
-      if ((int)lane >= d) incl += o;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    uint32_t before = carry;
-    for (uint32_t w = 0; w < wv; ++w) before += wave_tot[w];
-    if (i < n) {
-      rev_off[i] = before + incl - v;
-      cursor[i] = before + incl - v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = before + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) rev_off[n] = carry;
 }
 __global__ void __launch_bounds__(256) rev_fill_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                       uint32_t n, uint32_t* __restrict__ cursor, uint2* __restrict__ rev_arc) {
@@ -680,11 +660,19 @@ const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
   auto r = std::make_shared<RevCsr>();
   r->off = DBuf<uint32_t>(*ctx->pool, (size_t)n + 1);
   r->arc = DBuf<uint2>(*ctx->pool, f->n_arcs);
-  DBuf<uint32_t> indeg(*ctx->pool, n), cursor(*ctx->pool, n);
+  DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
   HIP_CHECK(hipMemsetAsync(indeg.p, 0, (size_t)n * sizeof(uint32_t), st));
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
   rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, indeg.p);
-  rev_scan_kernel<<<1, 1024, 0, st>>>(indeg.p, r->off.p, cursor.p, n);
+  {  // rev_off = exclusive scan of the in-degrees (n + 1 outputs: the extra zero input makes rev_off[n] the total)
+    HIP_CHECK(hipMemsetAsync(indeg.p + n, 0, sizeof(uint32_t), st));
+    size_t temp_bytes = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, indeg.p, r->off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+    DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, indeg.p, r->off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+    HIP_CHECK(hipMemcpyAsync(cursor.p, r->off.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // temp is released here
+  }
   const uint32_t fblocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
   rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, cursor.p, r->arc.p);
   HIP_CHECK(hipGetLastError());
@@ -700,7 +688,7 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   hipStream_t st = ctx->stream;
   Solve sv;
   run_relaxation(ctx, f, sv);
-  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 8), 256, 0, st>>>(f->dev.finals, sv.key.p,
+  sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p,
                                                                                                           n, sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
   constexpr uint32_t PATH_PINNED = 4096;  // arcs of the path written straight into pinned memory by the backtrace

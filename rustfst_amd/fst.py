@@ -43,10 +43,16 @@ class Tr:
 class Context:
     """One engine context per (host thread, GPU): a HIP stream + device memory pools."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, cu_mask: Optional[Sequence[int]] = None):
+        """stream: an existing HIP stream handle to run on; cu_mask: list of 32-bit words, bit i of word i//32 =
+        compute unit i — the context then owns a stream restricted to those CUs."""
         L = _lib.lib()
         h = C.c_void_p()
-        if stream is None:
+        if cu_mask is not None:
+            words = np.asarray(list(cu_mask), dtype=np.uint32)
+            check(L.wfst_ctx_create_with_cu_mask(device, words.ctypes.data, len(words), C.byref(h)),
+                  "wfst_ctx_create_with_cu_mask")
+        elif stream is None:
             check(L.wfst_ctx_create(device, C.byref(h)), "wfst_ctx_create")
         else:
             check(L.wfst_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)), "wfst_ctx_create_on_stream")
