@@ -58,7 +58,7 @@ constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, ind
 
 struct Ctl {
   uint32_t base;          // first sweep index of the batch being replayed (graph nodes add their static offset)
-  uint32_t pad0;
+  float tau0;             // threshold of sweep 0 (a multiple of delta)
   uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
   // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
   uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
@@ -78,7 +78,7 @@ struct Ctl {
 __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
                                            uint32_t* streak) {
   *streak = 0;
-  if (sweep == 0) return delta;
+  if (sweep == 0) return ctl->tau0;
   const uint32_t p = (sweep - 1) % RING;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t mine = 0;
@@ -97,7 +97,7 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
   return prev + delta * (float)(1u << (st - 1u));
 }
 
-__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start) {
+__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start, float tau0) {
   key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
   flags0[start] = 1;
   for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
@@ -107,6 +107,7 @@ __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint3
   for (uint32_t i = threadIdx.x; i < NEAR_RING * NEAR_SHARDS * NEAR_STRIDE; i += blockDim.x) (&ctl->near[0][0])[i] = 0;
   if (threadIdx.x) return;
   ctl->base = 0;
+  ctl->tau0 = tau0;
   ctl->arcs = 0;
   ctl->states = 0;
   ctl->best = KEY_INF;
@@ -460,7 +461,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
   HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
   uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n_pad};
-  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start);
+
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
   // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
@@ -470,6 +471,9 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (!(delta > 0.0f)) delta = INF;
   uint32_t near_low = 4096;  // activations below which a sweep is launch-latency bound anyway
   if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) near_low = (uint32_t)std::atol(e);
+  float tau0_mult = 1.0f;  // first band = tau0_mult x delta
+  if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
+  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start, delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
   const uint64_t sweep_cap = 4ull * n + 64;
   ctx->stats.sweeps = 0;
 
