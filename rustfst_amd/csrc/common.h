@@ -119,7 +119,7 @@ struct wfst_ctx {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  } sweep_graph[2];  // [0]: 8 sweeps per replay, [1]: 64
+  } sweep_graph[3];  // [0]: first batch of a solve (predicted length), [1]: 8 sweeps per replay, [2]: 64
   wfst::PinnedBuf pinned_flags;  // host mirror of the per-sweep activity flags (its address is baked into the graphs)
   int n_cus = 256;
 };
@@ -182,6 +182,7 @@ struct wfst_fst {
   // shortest_path query of a large FST (sssp.hip reverse_csr)
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
   mutable uint32_t sp_queries = 0;
+  mutable uint32_t last_sweeps = 0;  // sweeps the last relaxation of this FST needed (sizes the first graph replay)
 };
 
 namespace wfst {
