@@ -104,6 +104,8 @@ wfst_status wfst_fst_info(const wfst_fst* fst, uint32_t* n_states, uint64_t* n_a
 /* copy out: offsets[n_states+1], arcs[n_arcs], finals[n_states] (any pointer may be NULL) */
 wfst_status wfst_fst_download(const wfst_fst* fst, uint32_t* offsets, wfst_tr* arcs, float* finals);
 wfst_status wfst_fst_destroy(wfst_fst* fst);
+/* destroys fsts[0..n) (NULL entries are skipped): the outs[] of a fused batch in one call */
+wfst_status wfst_fst_destroy_many(wfst_fst* const* fsts, size_t n);
 
 /* ---- compose: fst_compose / fst_compose_with_config (rustfst-ffi/src/algorithms/compose.rs:308-372)
  *      = rustfst::algorithms::compose::{compose, compose_with_config}

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("wfst_fst_info", C.c_int, [_vp, _P(_u32), _P(_u64), _P(_i64), _P(_u64)]),
     ("wfst_fst_download", C.c_int, [_vp, _vp, _vp, _vp]),
     ("wfst_fst_destroy", C.c_int, [_vp]),
+    ("wfst_fst_destroy_many", C.c_int, [_P(_vp), _sz]),
     ("wfst_compose", C.c_int, [_vp, _vp, _vp, _P(ComposeConfig), _P(_vp)]),
     ("wfst_shortest_path", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_distance", C.c_int, [_vp, _vp, _vp, _vp]),

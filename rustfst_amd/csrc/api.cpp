@@ -263,6 +263,13 @@ wfst_status wfst_fst_destroy(wfst_fst* fst) {
   });
 }
 
+wfst_status wfst_fst_destroy_many(wfst_fst* const* fsts, size_t n) {
+  return wrap([&] {
+    if (n && !fsts) throw Error("null pointer");
+    for (size_t i = 0; i < n; ++i) delete fsts[i];
+  });
+}
+
 wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fst2, const wfst_compose_config* cfg,
                          wfst_fst** out) {
   return wrap([&] {

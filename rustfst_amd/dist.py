@@ -42,7 +42,10 @@ def pack_device_paths(paths, max_arcs: int) -> np.ndarray:
     from . import _lib
     n = len(paths)
     out = np.zeros((n, 4 + 4 * max_arcs), dtype=np.uint32)
-    arr = (C.c_void_p * n)(*[p._h.value if isinstance(p._h, C.c_void_p) else p._h for p in paths])
+    if hasattr(paths, "_arr"):  # a PathList: its handle array goes to the library as it is
+        arr = paths._arr
+    else:
+        arr = (C.c_void_p * n)(*[p._h.value if isinstance(p._h, C.c_void_p) else p._h for p in paths])
     _lib.check(_lib.lib().wfst_fst_pack_paths(arr, n, max_arcs, out.ctypes.data), "wfst_fst_pack_paths")
     return out
 

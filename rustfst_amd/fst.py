@@ -119,18 +119,19 @@ def set_default_context(ctx: Context):
 class DeviceFst:
     """Owning wrapper of a wfst_fst handle: an FST resident in HBM as CSR."""
 
-    def __init__(self, handle, ctx: Context):
+    def __init__(self, handle, ctx: Context, owner=None):
         self._h = handle
         self.ctx = ctx
+        self._owner = owner  # a PathList that owns the handle (this object is then a view)
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and getattr(self, "_owner", None) is None:
             try:
                 _lib.lib().wfst_fst_destroy(h)
             except Exception:
                 pass
-            self._h = None
+        self._h = None
 
     @classmethod
     def from_arrays(cls, n_states: int, start: Optional[int], offsets, arcs, finals, props: int,
@@ -264,6 +265,35 @@ class DeviceFst:
         return (dist, hops) if want_hops else dist
 
 
+class PathList(Sequence):
+    """The outs[] of a fused batch: owns the n result handles (released with ONE wfst_fst_destroy_many call) and
+    hands out DeviceFst views on demand — a step that only forwards the results pays no per-path Python work."""
+
+    def __init__(self, handles, n: int, ctx: Context):
+        self._arr, self._n, self.ctx = handles, n, ctx
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return DeviceFst(C.c_void_p(self._arr[i]), self.ctx, owner=self)
+
+    def __del__(self):
+        arr = getattr(self, "_arr", None)
+        if arr is not None:
+            try:
+                _lib.lib().wfst_fst_destroy_many(arr, self._n)
+            except Exception:
+                pass
+            self._arr = None
+
+
 class BatchJob:
     """A fused batch in flight (wfst_compose_shortest_path_batch_begin); finish() = ..._end."""
 
@@ -279,7 +309,7 @@ class BatchJob:
         check(_lib.lib().wfst_compose_shortest_path_batch_end(job, outs, C.byref(na)),
               "wfst_compose_shortest_path_batch_end")
         self._keep = None
-        return [DeviceFst(C.c_void_p(outs[i]), self._ctx) for i in range(self._n)], na.value
+        return PathList(outs, self._n, self._ctx), na.value
 
     def __del__(self):
         if getattr(self, "_job", None) is not None:  # abandoned: wait for the kernel and free the job
@@ -319,7 +349,7 @@ def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
         ctx._h, arr, n, t._h, compose_config._c() if compose_config else None,
         shortest_path_config._c() if shortest_path_config else None, outs, C.byref(na)),
         "wfst_compose_shortest_path_batch")
-    return [DeviceFst(C.c_void_p(outs[i]), ctx) for i in range(n)], na.value
+    return PathList(outs, n, ctx), na.value
 
 
 # ------------------------------------------------------------------ configs
