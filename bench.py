@@ -7,7 +7,8 @@ One "step" on every rank =
   (S1) shortest_path(T)                      — the 10M-arc frontier relaxation (the roofline kernel)
   (S2) for each of this rank's B linear acceptors (random walks of length 200 in T):
        shortest_path(compose(A_i, T))        — the fused wave-per-problem pipeline
-  (N > 1 only) all-gather of the B result paths over RCCL.
+  (N > 1 only) all-gather of the B result paths over RCCL, queued asynchronously and collected one step later
+  (the last one before the closing barrier), so it overlaps with the next step's compute.
 S1 and S2 are independent requests: S2 is enqueued first, asynchronously, on a second context / HIP stream
 (its single long kernel uses one wave per acceptor), S1 then runs on the first stream and overlaps with it,
 and S2's results are collected last (--serial runs them back to back on one stream instead).
@@ -116,6 +117,19 @@ def main():
 
     last = {}
 
+    def exchange():
+        # RCCL all-gather of this step's result paths: queued asynchronously on the torch stream at the end of the
+        # step and collected one step later, so the communication overlaps with the next step's compute; the last
+        # one is drained before the closing barrier, inside the timed region.  (Issuing it earlier in the step,
+        # between the batch kernel and shortest_path(T), stalls the step by ~0.4 ms: its kernels then queue between
+        # the two compute streams.)
+        if last.get("pending") is not None:
+            last["gathered"] = last["pending"].result()
+            last["pending"] = None
+        if last.get("to_send") is not None:
+            last["pending"] = wdist.gather_paths_async(last["to_send"], world, device)
+            last["to_send"] = None
+
     def step():
         if not args.overlap:
             sp = dt.shortest_path()
@@ -129,9 +143,13 @@ def main():
             outs, n_arcs = job.finish()
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
         if world > 1 or force_dist:
-            packed = wdist.pack_device_paths(outs, args.acc_len + 8)
-            last["gathered"] = wdist.gather_paths(packed, world, device)
+            last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
+            exchange()
         return e_t + 2 * n_arcs
+
+    def drain():
+        if world > 1 or force_dist:
+            exchange()  # collects the last step's results
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -143,11 +161,13 @@ def main():
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
+        drain()
         barrier()
         t_start = time.perf_counter()
         arcs = 0
         for _ in range(args.steps):
             arcs += step()
+        drain()
         barrier()
         elapsed = time.perf_counter() - t_start
 

@@ -67,20 +67,83 @@ def unpack_paths(packed: np.ndarray) -> List[dict]:
     return res
 
 
+_gather_bufs = {}
+
+
 def gather_paths(local_packed: np.ndarray, world: int, device=None):
     """All-gather equally shaped per-rank result blocks. Returns [world, n_local, rec] uint32 (numpy).
     Uses torch.distributed's default group: backend "nccl" (= RCCL over xGMI) when `device` is a GPU,
-    gloo on CPU."""
+    gloo on CPU.  On a GPU the staging buffers (pinned host in/out, device in/out) are allocated once per shape,
+    so a call is: memcpy into pinned, async H2D, all-gather, async D2H, one stream synchronisation."""
     import torch
     import torch.distributed as dist
 
-    t = torch.from_numpy(local_packed.view(np.int32))
-    if device is not None:
-        t = t.to(device, non_blocking=True)
-    # concatenation layout along dim 0 (accepted by both the gloo and the nccl/RCCL backends)
-    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy().view(np.uint32).reshape((world,) + tuple(t.shape))
+    shape = tuple(local_packed.shape)
+    if device is None:
+        t = torch.from_numpy(local_packed.view(np.int32))
+        # concatenation layout along dim 0 (accepted by both the gloo and the nccl/RCCL backends)
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t)
+        return out.numpy().view(np.uint32).reshape((world,) + shape)
+    key = (shape, world, str(device))
+    bufs = _gather_bufs.get(key)
+    if bufs is None:
+        h_in = torch.empty(shape, dtype=torch.int32).pin_memory()
+        h_out = torch.empty((world * shape[0],) + shape[1:], dtype=torch.int32).pin_memory()
+        d_in = torch.empty(shape, dtype=torch.int32, device=device)
+        d_out = torch.empty((world * shape[0],) + shape[1:], dtype=torch.int32, device=device)
+        bufs = _gather_bufs[key] = (h_in, h_out, d_in, d_out)
+    h_in, h_out, d_in, d_out = bufs
+    h_in.numpy()[...] = local_packed.view(np.int32)
+    d_in.copy_(h_in, non_blocking=True)
+    dist.all_gather_into_tensor(d_out, d_in)
+    h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return h_out.numpy().view(np.uint32).reshape((world,) + shape).copy()
+
+
+class PendingGather:
+    """An all-gather of packed result records in flight on the current torch stream (gather_paths_async)."""
+
+    def __init__(self, h_out, event, world, shape):
+        self._h_out, self._event, self._world, self._shape = h_out, event, world, shape
+
+    def result(self) -> np.ndarray:
+        """Waits for the exchange; returns [world, n_local, rec] uint32."""
+        self._event.synchronize()
+        return self._h_out.numpy().view(np.uint32).reshape((self._world,) + self._shape).copy()
+
+
+_async_bufs = {}
+
+
+def gather_paths_async(local_packed: np.ndarray, world: int, device) -> PendingGather:
+    """gather_paths without the final wait: H2D, all-gather and D2H are queued on the current torch stream and the
+    call returns; the exchange then overlaps with whatever the caller does next (the next decoding step) and
+    `.result()` collects it.  Two buffer sets alternate, so one exchange may be in flight while the next is prepared."""
+    import torch
+    import torch.distributed as dist
+
+    shape = tuple(local_packed.shape)
+    key = (shape, world, str(device))
+    st = _async_bufs.get(key)
+    if st is None:
+        sets = []
+        for _ in range(2):
+            sets.append((torch.empty(shape, dtype=torch.int32).pin_memory(),
+                         torch.empty((world * shape[0],) + shape[1:], dtype=torch.int32).pin_memory(),
+                         torch.empty(shape, dtype=torch.int32, device=device),
+                         torch.empty((world * shape[0],) + shape[1:], dtype=torch.int32, device=device)))
+        st = _async_bufs[key] = {"sets": sets, "next": 0}
+    h_in, h_out, d_in, d_out = st["sets"][st["next"]]
+    st["next"] ^= 1
+    h_in.numpy()[...] = local_packed.view(np.int32)
+    d_in.copy_(h_in, non_blocking=True)
+    dist.all_gather_into_tensor(d_out, d_in)
+    h_out.copy_(d_out, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return PendingGather(h_out, ev, world, shape)
 
 
 def interleave(gathered: np.ndarray, n_total: int) -> np.ndarray:
