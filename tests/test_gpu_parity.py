@@ -686,3 +686,56 @@ def test_compose_filters_wide_states_and_batch(gpu_ctx, oracle, flt):
     for x, out in zip(accs, outs):
         want = to_oracle(oracle, x).compose(ot, compose_filter=flt.value).shortest_path_canonical().to_flat()
         assert_flat_identical(out.to_flat(), want, f"{flt.name} fused batch")
+
+
+# ------------------------------------------------------------------ robustness of the boundary
+def test_loader_rejects_damaged_files(gpu_ctx, oracle):
+    """Truncated or corrupted vector / const files come back as KO with a message — never a crash, never garbage."""
+    for name in ("fst_014_hcl.fst", "fst_014_g.fst"):
+        data = open(os.path.join(GOLDEN, name), "rb").read()
+        for cut in (0, 3, 17, 40, 66, len(data) // 2, len(data) - 1):
+            with pytest.raises(rustfst_amd.WfstError):
+                rustfst_amd.DeviceFst.from_bytes(data[:cut])
+            with pytest.raises(oracle.OracleError):
+                oracle.OracleFst.load(data[:cut])
+        bad_magic = b"\x00\x00\x00\x00" + data[4:]
+        with pytest.raises(rustfst_amd.WfstError):
+            rustfst_amd.DeviceFst.from_bytes(bad_magic)
+        wrong_type = data.replace(b"standard", b"log\x00\x00\x00\x00\x00", 1)
+        with pytest.raises(rustfst_amd.WfstError):
+            rustfst_amd.DeviceFst.from_bytes(wrong_type)
+    # a const file whose state records point outside the arc array
+    data = bytearray(open(os.path.join(GOLDEN, "fst_014_hcl.fst"), "rb").read())
+    states_at = 80  # 65 header bytes, aligned to 16 (version 1)
+    assert int.from_bytes(data[states_at + 4:states_at + 8], "little") == 0  # pos of state 0
+    data[states_at + 4:states_at + 8] = (10 ** 6).to_bytes(4, "little")
+    with pytest.raises(rustfst_amd.WfstError):
+        rustfst_amd.DeviceFst.from_bytes(bytes(data))
+
+
+def test_degenerate_fsts_through_every_entry_point(gpu_ctx, oracle):
+    """no states / states without arcs / no start / no final state"""
+    empty = dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=np.zeros(0, rustfst_amd.TR_DTYPE),
+                 finals=np.zeros(0, np.float32), props=synth.I_LABEL_SORTED | synth.O_LABEL_SORTED)
+    lonely = dict(n_states=3, start=1, offsets=np.zeros(4, np.uint32), arcs=np.zeros(0, rustfst_amd.TR_DTYPE),
+                  finals=np.array([np.inf, 0.5, np.inf], np.float32), props=synth.I_LABEL_SORTED | synth.O_LABEL_SORTED)
+    nostart = dict(lonely, start=None)
+    nofinal = dict(lonely, finals=np.full(3, np.inf, np.float32))
+    t = random_fst_flat(np.random.default_rng(3), 12, 3, 3, p_final=0.3, sort="ilabel")
+    for name, f in (("empty", empty), ("lonely", lonely), ("nostart", nostart), ("nofinal", nofinal)):
+        d, o = to_device(f), to_oracle(oracle, f)
+        assert_flat_identical(d.shortest_path().to_flat(), o.shortest_path_canonical().to_flat(), name + " shortest_path")
+        d.tr_sort(False)
+        o.tr_sort(by_olabel=True)
+        assert_flat_identical(d.to_flat(), o.to_flat(), name + " tr_sort")
+        for flt in (ComposeFilter.AUTOFILTER, ComposeFilter.MATCHFILTER):
+            got = d.compose(to_device(t), ComposeConfig(flt))
+            assert_flat_identical(got.to_flat(), o.compose(to_oracle(oracle, t), compose_filter=flt.value).to_flat(),
+                                  name + " compose " + flt.name)
+        outs, _ = rustfst_amd.compose_shortest_path_batch([d, d], to_device(t))
+        want = o.compose(to_oracle(oracle, t)).shortest_path_canonical().to_flat()
+        for x in outs:
+            assert_flat_identical(x.to_flat(), want, name + " fused")
+        assert rustfst_amd.DeviceFst.from_bytes(d.to_bytes("const")).to_bytes() == o.store()
+    outs, n = rustfst_amd.compose_shortest_path_batch([], to_device(t))
+    assert len(outs) == 0 and n == 0
