@@ -739,3 +739,23 @@ def test_degenerate_fsts_through_every_entry_point(gpu_ctx, oracle):
         assert rustfst_amd.DeviceFst.from_bytes(d.to_bytes("const")).to_bytes() == o.store()
     outs, n = rustfst_amd.compose_shortest_path_batch([], to_device(t))
     assert len(outs) == 0 and n == 0
+
+
+def test_c_example_runs(gpu_ctx, tmp_path):
+    """examples/decode_batch.c: the C-ABI driven from plain C, end to end on the GPU (exit status 0 = expected paths)."""
+    import shutil
+    import subprocess
+    from rustfst_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "decode_batch"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "decode_batch.c"),
+                    "-L", libdir, "-lwfst_amd", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)],
+                   check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "acceptor 0: path of 3 arcs, weight 1.500, output labels: 11 12 11" in r.stdout
+    assert "acceptor 1: path of 2 arcs, weight 1.000, output labels: 12 12" in r.stdout

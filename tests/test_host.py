@@ -146,3 +146,23 @@ def test_acceptor_matches_reference_utils(oracle, wfst_lib):
     np.testing.assert_array_equal(fo["offsets"], flat["offsets"])
     np.testing.assert_array_equal(fo["arcs"], flat["arcs"])
     np.testing.assert_array_equal(fo["finals"], flat["finals"])
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path, wfst_lib):
+    """include/wfst.h is a self-contained C99 header (no C++, no HIP, no torch types) and examples/decode_batch.c —
+    the drop-in boundary used from plain C — compiles and links against the library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "wfst.h"\nint main(void) { wfst_tr t = {1, 2, 0.5f, 3}; (void)t; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)],
+                   check=True)
+    exe = tmp_path / "decode_batch"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", inc, os.path.join(ROOT, "examples", "decode_batch.c"),
+                    "-L", libdir, "-lwfst_amd", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)],
+                   check=True)
+    assert exe.exists()
