@@ -759,3 +759,15 @@ def test_c_example_runs(gpu_ctx, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "acceptor 0: path of 3 arcs, weight 1.500, output labels: 11 12 11" in r.stdout
     assert "acceptor 1: path of 2 arcs, weight 1.000, output labels: 12 12" in r.stdout
+
+
+def test_config5_scale_properties():
+    """BASELINE configs[4] scale (5M states / 50M arcs, 5 % epsilon arcs): n=1 and n=10 shortest paths, distances
+    (Bellman condition on 2M sampled arcs, best final = path weight), a fused batch of 64 acceptors (paths read the
+    acceptors' labels) and a 50M-arc tr_sort — tools/config5_scale_check.py, size-independent properties only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5_scale_check.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
