@@ -144,6 +144,20 @@ struct DeviceCsr {
 };
 
 namespace wfst {
+// reverse(fst) (reverse.rs:33-87) for the n-best search: state 0 = super-initial (one eps arc per final state of fst, in
+// state order, kept on the host), state t+1 = the in-arcs of t in reverse()'s order.  The in-arc segments live on the
+// host for small FSTs; for large ones they STAY in HBM and the host search fetches the few segments it visits.
+struct RevFst {
+  uint32_t n = 0;                 // states of the original FST
+  std::vector<wfst_tr> super;     // arcs of state 0
+  std::vector<float> finals;      // [n+1] final weights of rfst (+inf = none)
+  bool on_host = true;
+  std::vector<uint32_t> h_roff;   // [n+1] segment offsets (on_host)
+  std::vector<wfst_tr> h_arcs;    // [E]
+  DBuf<uint32_t> d_roff;          // same on the device (!on_host)
+  DBuf<wfst_tr> d_arcs;
+  uint64_t fetched_segments = 0;  // statistics
+};
 struct RevCsr {
   DBuf<uint32_t> off;  // [n+1]
   DBuf<uint2> arc;     // [E] {source state, position of the arc in the source's arc list}
@@ -177,7 +191,7 @@ struct wfst_fst {
   HostCsr host;
   DeviceCsr dev;
   // reverse(fst) (reverse.rs:33-87) as host CSR: built on the GPU on first use by the n>1 shortest-path search
-  mutable std::shared_ptr<HostCsr> rev_host;
+  mutable std::shared_ptr<wfst::RevFst> rev_host;
   // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second
   // shortest_path query of a large FST (sssp.hip reverse_csr)
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;

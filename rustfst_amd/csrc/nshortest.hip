@@ -11,6 +11,12 @@
 // they decide heap order and must not deviate.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include <cstdlib>
 
 #include "common.h"
 #include "fst_props.h"
@@ -61,58 +67,108 @@ __global__ void rev_emit_kernel(const wfst_tr* __restrict__ arcs, const uint32_t
   }
 }
 
-std::shared_ptr<HostCsr> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
+// one in-arc segment (state t of the original FST) -> pinned host memory: {count, arcs[min(count, cap)]}
+__global__ void rev_fetch_kernel(const uint32_t* __restrict__ roff, const wfst_tr* __restrict__ rarcs, uint32_t t,
+                                 uint32_t* __restrict__ out_count, wfst_tr* __restrict__ out_arcs, uint32_t cap) {
+  const uint32_t b = roff[t], c = roff[t + 1] - b;
+  if (threadIdx.x == 0) *out_count = c;
+  for (uint32_t i = threadIdx.x; i < c && i < cap; i += blockDim.x) out_arcs[i] = rarcs[b + i];
+}
+
+std::shared_ptr<RevFst> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
   ensure_device(const_cast<wfst_fst*>(f));
   const uint32_t n = f->n_states;
   const uint64_t E = f->n_arcs;
   hipStream_t st = ctx->stream;
   DevicePool& pool = *ctx->pool;
-  auto rev = std::make_shared<HostCsr>();
-  std::vector<uint32_t> counts(n + 1, 0);
+  auto rev = std::make_shared<RevFst>();
+  rev->n = n;
+  // the in-arc segments of large FSTs stay in HBM: the search visits a few hundred of them, downloading all (16 B per
+  // arc) would dominate (0.42 s for 50M arcs)
+  rev->on_host = E < (1ull << 22);
+  if (const char* e = std::getenv("WFST_NBEST_LAZY")) rev->on_host = std::atoi(e) == 0;
   std::vector<float> finals(n);
   DBuf<uint32_t> d_counts(pool, (size_t)n + 1);
   HIP_CHECK(hipMemsetAsync(d_counts.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
   const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((E + 255) / 256, (uint64_t)ctx->n_cus * 8));
   if (E) rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.arcs, E, d_counts.p);
-  HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   if (n) HIP_CHECK(hipMemcpyAsync(finals.data(), f->dev.finals, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  // device-side offsets of the in-arc segments (targets 0..n-1), exclusive scan on the host
-  std::vector<uint32_t> roff(n + 1);
-  uint64_t acc = 0;
-  for (uint32_t t = 0; t < n; ++t) {
-    roff[t] = (uint32_t)acc;
-    acc += counts[t];
+  // offsets of the in-arc segments (targets 0..n-1): exclusive scan of the in-degrees on the device
+  rev->d_roff = DBuf<uint32_t>(pool, (size_t)n + 1);
+  rev->d_arcs = DBuf<wfst_tr>(pool, E);
+  {
+    size_t temp_bytes = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, d_counts.p, rev->d_roff.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+    DBuf<uint8_t> temp(pool, temp_bytes);
+    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, d_counts.p, rev->d_roff.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, rev->d_roff.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (total != E) throw Error("reverse: inconsistent arc count");
   }
-  roff[n] = (uint32_t)acc;
-  if (acc != E) throw Error("reverse: inconsistent arc count");
-  std::vector<wfst_tr> in_arcs(E);
+  std::vector<uint32_t> roff;
+  if (rev->on_host) {
+    roff.resize((size_t)n + 1);
+    HIP_CHECK(hipMemcpyAsync(roff.data(), rev->d_roff.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
   if (E) {
-    DBuf<uint32_t> d_roff(pool, (size_t)n + 1), d_cursor(pool, n);
+    DBuf<uint32_t> d_cursor(pool, n);
     DBuf<uint2> d_tmp(pool, E);
-    DBuf<wfst_tr> d_rarcs(pool, E);
-    HIP_CHECK(hipMemcpyAsync(d_roff.p, roff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, (size_t)n * sizeof(uint32_t), st));
-    rev_place_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.arcs, n, d_roff.p, d_cursor.p, d_tmp.p);
-    rev_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.arcs, d_roff.p, d_tmp.p, n, d_rarcs.p);
+    rev_place_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.arcs, n, rev->d_roff.p, d_cursor.p, d_tmp.p);
+    rev_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.arcs, rev->d_roff.p, d_tmp.p, n, rev->d_arcs.p);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(in_arcs.data(), d_rarcs.p, E * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+    if (rev->on_host) {
+      rev->h_arcs.resize(E);
+      HIP_CHECK(hipMemcpyAsync(rev->h_arcs.data(), rev->d_arcs.p, E * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));  // d_cursor / d_tmp are released here
+  } else {
     HIP_CHECK(hipStreamSynchronize(st));
   }
-  // assemble rfst: state 0 = super-initial with one eps:eps arc per final state, in state order (reverse.rs:56-60)
-  std::vector<wfst_tr> super;
+  if (rev->on_host) {
+    rev->h_roff = std::move(roff);
+    rev->d_roff.reset();
+    rev->d_arcs.reset();
+  }
+  // state 0 = super-initial with one eps:eps arc per final state, in state order (reverse.rs:56-60)
   for (uint32_t s = 0; s < n; ++s)
-    if (finals[s] != INF) super.push_back(wfst_tr{0u, 0u, finals[s], s + 1});
-  rev->offsets.resize((size_t)n + 2);
-  rev->offsets[0] = 0;
-  rev->offsets[1] = (uint32_t)super.size();
-  for (uint32_t t = 0; t < n; ++t) rev->offsets[t + 2] = rev->offsets[1] + roff[t + 1];
-  rev->arcs.reserve(super.size() + E);
-  rev->arcs.insert(rev->arcs.end(), super.begin(), super.end());
-  rev->arcs.insert(rev->arcs.end(), in_arcs.begin(), in_arcs.end());
+    if (finals[s] != INF) rev->super.push_back(wfst_tr{0u, 0u, finals[s], s + 1});
   rev->finals.assign((size_t)n + 1, INF);
   if (f->start >= 0) rev->finals[(size_t)f->start + 1] = 0.0f;  // reverse.rs:53-55
   return rev;
+}
+
+// arcs of state `rs` of the reversed FST (a pointer valid until the next call)
+const wfst_tr* rev_arcs_of(wfst_ctx* ctx, RevFst& r, uint32_t rs, uint32_t* count, std::vector<wfst_tr>& scratch) {
+  if (rs == 0) {
+    *count = (uint32_t)r.super.size();
+    return r.super.data();
+  }
+  const uint32_t t = rs - 1;
+  if (r.on_host) {
+    *count = r.h_roff[t + 1] - r.h_roff[t];
+    return r.h_arcs.data() + r.h_roff[t];
+  }
+  constexpr uint32_t CAP = 1024;  // arcs per fetch through the small pinned buffer (in-degrees are ~fan-out)
+  char* pin = (char*)ctx->pinned.get(64 + CAP * sizeof(wfst_tr));
+  uint32_t* h_cnt = (uint32_t*)pin;
+  wfst_tr* h_arcs = (wfst_tr*)(pin + 64);
+  rev_fetch_kernel<<<1, 64, 0, ctx->stream>>>(r.d_roff.p, r.d_arcs.p, t, h_cnt, h_arcs, CAP);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  r.fetched_segments += 1;
+  const uint32_t c = *h_cnt;
+  *count = c;
+  if (c <= CAP) return h_arcs;
+  // a hub state: copy its whole segment
+  scratch.resize(c);
+  uint32_t b = 0;
+  HIP_CHECK(hipMemcpyAsync(&b, r.d_roff.p + t, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(scratch.data(), r.d_arcs.p + b, (size_t)c * sizeof(wfst_tr), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return scratch.data();
 }
 
 // ---------------------------------------------------------------- TropicalWeight with the reference's semantics
@@ -289,17 +345,23 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
   const uint32_t n = f->n_states;
   if (f->start < 0 || n == 0) return finish();  // shortest_distance -> [] ; istart check fails -> FO::new()
   // 1. forward distances (GPU relaxation; exact fixed point == the reference's on grid weights)
+  const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_0 = tnow();
   std::vector<float> distance(n);
   shortest_distance(ctx, f, distance.data(), nullptr);
+  auto t_1 = tnow();
   // 2. reversed FST (GPU transpose, cached on the handle)
   wfst_fst* mf = const_cast<wfst_fst*>(f);
   if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
-  const HostCsr& r = *mf->rev_host;
+  RevFst& r = *mf->rev_host;
+  std::vector<wfst_tr> scratch;
+  auto t_2 = tnow();
   // 3. distance of the super-initial state (shortest_path.rs:143-153)
   float d = INF;
-  for (uint32_t i = r.offsets[0]; i < r.offsets[1]; ++i) {
-    const uint32_t state = r.arcs[i].nextstate - 1;
-    if (state < distance.size()) d = wplus(d, wtimes(r.arcs[i].weight, distance[state]));
+  for (const wfst_tr& a : r.super) {
+    const uint32_t state = a.nextstate - 1;
+    if (state < distance.size()) d = wplus(d, wtimes(a.weight, distance[state]));
   }
   std::vector<float> distance_2;
   distance_2.reserve((size_t)n + 1);
@@ -333,8 +395,10 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
     if (!p.some && rcount[(size_t)p_first_real] == nshortest) break;
     if (rcount[(size_t)p_first_real] > nshortest) continue;
     if (!p.some) continue;
-    for (uint32_t i = r.offsets[p.state]; i < r.offsets[p.state + 1]; ++i) {
-      wfst_tr tr = r.arcs[i];
+    uint32_t n_in = 0;
+    const wfst_tr* in = rev_arcs_of(ctx, r, p.state, &n_in, scratch);
+    for (uint32_t i = 0; i < n_in; ++i) {
+      wfst_tr tr = in[i];
       const float weight = wtimes(p.w, tr.weight);
       const uint32_t next = ofst.add_state();
       pairs.push_back(Pair{true, tr.nextstate, weight});
@@ -350,6 +414,12 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
       ofst.add_tr(next, wfst_tr{0u, 0u, fw, state});
       heap.push(next);
     }
+  }
+  auto t_3 = tnow();
+  if (timing) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "[nbest] distances %.0f us | reverse %.0f us | search %.0f us (%llu segments fetched, %zu states)\n",
+                 us(t_0, t_1), us(t_1, t_2), us(t_2, t_3), (unsigned long long)r.fetched_segments, ofst.states.size());
   }
   // 5. connect + property word (shortest_path.rs:512-517)
   ofst.connect();

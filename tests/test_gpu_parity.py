@@ -449,8 +449,12 @@ def test_nshortest_known_graph(gpu_ctx, oracle):
         assert_flat_identical(got, o.shortest_path_n(n).to_flat(), f"K2 graph n={n}")
 
 
+@pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
 @pytest.mark.parametrize("seed", range(10))
-def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed):
+def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
+    # lazy = 1: the reversed FST stays on the device and the host search fetches the segments it visits (the path
+    # large FSTs take); forced here on small ones, where the oracle can check the result
+    monkeypatch.setenv("WFST_NBEST_LAZY", lazy)
     rng = np.random.default_rng(700 + seed)
     flat = random_fst_flat(rng, int(rng.integers(3, 60)), 4, 5, p_eps_i=0.1, p_final=0.2, min_fanout=1,
                            acyclic=bool(seed % 2))
@@ -460,7 +464,9 @@ def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed):
         assert_flat_identical(got, exp, f"seed {seed} n={n}")
 
 
-def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle):
+@pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
+def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle, lazy, monkeypatch):
+    monkeypatch.setenv("WFST_NBEST_LAZY", lazy)
     t = synth.make_transducer(20_000, 8, 64, 0.02, seed=5)
     accs = synth.make_acceptors(t, 2, 40, seed0=1000)
     dt, ot = to_device(t), to_oracle(oracle, t)
