@@ -110,7 +110,7 @@ def main():
     accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
     mine = wdist.shard_indices(n_total, rank, world)
     dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
-    daccs = rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx2)
+    daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx2))
     dt2 = dt  # T is read-only for both pipelines: one HBM copy serves both contexts
     e_t = int(t["offsets"][-1])
     gen_s = time.time() - t0

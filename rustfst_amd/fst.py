@@ -265,6 +265,19 @@ class DeviceFst:
         return (dist, hops) if want_hops else dist
 
 
+class HandleArray:
+    """A batch of DeviceFst handles marshalled once for the C-ABI (`const wfst_fst* const*`): callers that submit the
+    same acceptors repeatedly build it once instead of paying the ctypes marshalling on every call."""
+
+    def __init__(self, fsts: Sequence["DeviceFst"]):
+        self._keep = list(fsts)
+        n = len(self._keep)
+        self._arr = (C.c_void_p * n)(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in self._keep])
+
+    def __len__(self):
+        return len(self._keep)
+
+
 class PathList(Sequence):
     """The outs[] of a fused batch: owns the n result handles (released with ONE wfst_fst_destroy_many call) and
     hands out DeviceFst views on demand — a step that only forwards the results pays no per-path Python work."""
@@ -325,13 +338,13 @@ def compose_shortest_path_batch_begin(acceptors: Sequence[DeviceFst], t: DeviceF
     afterwards on ANOTHER context (e.g. shortest_path of a large FST) overlaps with it on the GPU."""
     n = len(acceptors)
     ctx = ctx or t.ctx
-    arr = (C.c_void_p * n)(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in acceptors])
+    arr = acceptors._arr if isinstance(acceptors, HandleArray) else HandleArray(acceptors)._arr
     job = C.c_void_p()
     check(_lib.lib().wfst_compose_shortest_path_batch_begin(
         ctx._h, arr, n, t._h, compose_config._c() if compose_config else None,
         shortest_path_config._c() if shortest_path_config else None, C.byref(job)),
         "wfst_compose_shortest_path_batch_begin")
-    return BatchJob(job, n, ctx, (list(acceptors), t, arr))
+    return BatchJob(job, n, ctx, (acceptors, t, arr))
 
 
 def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
@@ -342,7 +355,7 @@ def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
     Returns (list of DeviceFst paths, total composed arcs before trimming)."""
     n = len(acceptors)
     ctx = ctx or t.ctx
-    arr = (C.c_void_p * n)(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in acceptors])
+    arr = acceptors._arr if isinstance(acceptors, HandleArray) else HandleArray(acceptors)._arr
     outs = (C.c_void_p * n)()
     na = C.c_uint64()
     check(_lib.lib().wfst_compose_shortest_path_batch(

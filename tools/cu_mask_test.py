@@ -29,12 +29,6 @@ def run(name, ctx, ctx2):
         if it >= 5: acc += [b - a, c - b, d - c, d - a]
     print("%-44s begin %.1f | shortest_path(T) %.1f | finish %.1f | step %.1f us" % ((name,) + tuple(acc / N * 1e6)))
 
+s_, big = masks(range(64))
+run("S2 on CUs 0..63 (bench default)", rustfst_amd.Context(0, cu_mask=big), rustfst_amd.Context(0, cu_mask=s_))
 run("no masks", rustfst_amd.Context(0), rustfst_amd.Context(0))
-pats = [("S2 on CUs 0..31", range(32)), ("S2 on CUs 0..47", range(48)), ("S2 on CUs 0..63", range(64)),
-        ("S2 on CUs 0..23", range(24)), ("S2 on CUs 224..255", range(224, 256)), ("S2 on CUs 0..15 + 128..143", list(range(16)) + list(range(128, 144))),
-        ("S2 on CUs 0..7 of each 32", [c for c in range(256) if c % 32 < 8])]
-for name, pat in pats:
-    s_, big = masks(pat)
-    run(name, rustfst_amd.Context(0, cu_mask=big), rustfst_amd.Context(0, cu_mask=s_))
-s_, big = masks(range(32))
-run("S2 on CUs 0..31, S1 unmasked", rustfst_amd.Context(0), rustfst_amd.Context(0, cu_mask=s_))
