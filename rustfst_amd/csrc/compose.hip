@@ -244,8 +244,20 @@ struct ArcReg {
   float w;
   uint32_t ns;
 };
+// Pointers that reach the kernel through a descriptor in memory (fst1 of every problem) are generic to the compiler,
+// which then emits FLAT loads: slower, and they tie the LDS and the vector-memory wait counters together.  Everything an
+// FstView points to is device memory, so say so.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const u32x4_t __attribute__((address_space(1)))* global_u4_ptr;
+__device__ __forceinline__ uint4 ld_global16(const void* p) {
+  // (the integer round trip is what makes the compiler drop "generic")
+  const u32x4_t v = *(global_u4_ptr)(unsigned long long)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+__device__ __forceinline__ uint32_t ld_global4(const void* p) { return *(global_u32_ptr)(unsigned long long)p; }
 __device__ __forceinline__ ArcReg load_arc(const wfst_tr* p) {
-  const uint4 v = *reinterpret_cast<const uint4*>(p);  // one 16-B load
+  const uint4 v = ld_global16(p);  // one 16-B load
   return ArcReg{v.x, v.y, __uint_as_float(v.z), v.w};
 }
 __device__ __forceinline__ void store_arc(wfst_tr* p, uint32_t il, uint32_t ol, float w, uint32_t ns) {
@@ -262,14 +274,14 @@ __device__ inline void equal_range_global(const wfst_tr* arcs, uint32_t n, bool 
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
     uint32_t mid = lo + ((hi - lo) >> 1);
-    uint32_t k = by_ilabel ? arcs[mid].ilabel : arcs[mid].olabel;
+    uint32_t k = ld_global4(by_ilabel ? &arcs[mid].ilabel : &arcs[mid].olabel);
     if (k < key) lo = mid + 1; else hi = mid;
   }
   uint32_t first = lo;
   hi = n;
   while (lo < hi) {
     uint32_t mid = lo + ((hi - lo) >> 1);
-    uint32_t k = by_ilabel ? arcs[mid].ilabel : arcs[mid].olabel;
+    uint32_t k = ld_global4(by_ilabel ? &arcs[mid].ilabel : &arcs[mid].olabel);
     if (k <= key) lo = mid + 1; else hi = mid;
   }
   *lo_out = first;
@@ -614,8 +626,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
     uint64_t f_sk = lane == 0 ? ((uint64_t)enc_f32(0.0f) << 32) : KEY_INF;
     uint4 f_r1 = make_uint4(0, 0, 0, 0), f_r2 = make_uint4(0, 0, 0, 0);
     if (lane == 0) {
-      f_r1 = f1.srec[f1.start];
-      f_r2 = f2.srec[f2.start];
+      f_r1 = ld_global16(f1.srec + f1.start);
+      f_r2 = ld_global16(f2.srec + f2.start);
     }
     // LazyFst::compute :235-259 — FIFO BFS; level k = ids [lo, hi)
     while (lo < hi && ok) {
@@ -658,8 +670,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
           // removes one dependent trip to HBM from the next level
           uint4 pr1 = make_uint4(0, 0, 0, 0), pr2 = make_uint4(0, 0, 0, 0);
           if (have) {
-            pr1 = f1.srec[tuple_s1(key)];
-            pr2 = f2.srec[(uint32_t)key];
+            pr1 = ld_global16(f1.srec + tuple_s1(key));
+            pr2 = ld_global16(f2.srec + (uint32_t)key);
           }
           // first occurrence of each destination tuple inside the level + min candidate of its group
           uint64_t mymin = cand;
@@ -732,8 +744,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       for (uint32_t q = lo; q < hi; ++q) {
         if (lane == 0) ar.off[q] = n_arcs;
         const uint64_t tk = ar.tuples[q];
-        if (expand_state<false>(f1, f2, mode, filter, ar, caps, q, tk, f1.srec[tuple_s1(tk)],
-                                f2.srec[(uint32_t)tk], KEY_INF, lv, &n_arcs, nullptr, nullptr, &res.status) != EXP_OK) {
+        if (expand_state<false>(f1, f2, mode, filter, ar, caps, q, tk, ld_global16(f1.srec + tuple_s1(tk)),
+                                ld_global16(f2.srec + (uint32_t)tk), KEY_INF, lv, &n_arcs, nullptr, nullptr, &res.status) != EXP_OK) {
           ok = false;
           break;
         }
@@ -790,8 +802,8 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
         f_key = lane < n_new ? ar.tuples[lo + lane] : 0ull;
         f_sk = ((FLAGS & FLAG_SP) && lane < n_new) ? ld_l2(&ar.skey[lo + lane]) : KEY_INF;
         if (lane < n_new) {
-          f_r1 = f1.srec[tuple_s1(f_key)];
-          f_r2 = f2.srec[(uint32_t)f_key];
+          f_r1 = ld_global16(f1.srec + tuple_s1(f_key));
+          f_r2 = ld_global16(f2.srec + (uint32_t)f_key);
         }
       }
     }
