@@ -159,6 +159,17 @@ def main():
         torch.cuda.synchronize(device)
 
     with torch.cuda.stream(stream):
+        # Setup, part 2 (untimed, like the upload of T): three priming steps.  The engine keeps derived data per
+        # resident FST that it only builds once an FST is queried AGAIN (the transpose used by the backtrace on the
+        # 2nd query, the sweep graph sized to the previous solve on the 3rd); a serving process reaches that state
+        # within its first requests, and the --warmup steps that follow are then warm-up only.
+        PRIMING_STEPS = 3
+        t1 = time.time()
+        for _ in range(PRIMING_STEPS):
+            step()
+        drain()
+        barrier()
+        gen_s += time.time() - t1
         for _ in range(args.warmup):
             step()
         drain()
@@ -288,7 +299,7 @@ def main():
             "ms_shortest_path_T": round(ms_sp_t, 4), "ms_compose_shortest_path_batch": round(ms_batch, 4),
             "ms_per_compose_shortest_path": round(ms_batch / max(1, len(mine)), 5),
             "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(last["n_arcs"]),
-            "setup_seconds": round(gen_s, 2),
+            "setup_seconds": round(gen_s, 2), "priming_steps": 3,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
