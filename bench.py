@@ -246,6 +246,31 @@ def main():
                     roofline["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / algo_bytes, 2)
                     roofline["traffic_source"] = pmc["source"] + "; " + pmc["correction"]
 
+        # the other kernel of the step, for completeness: the fused batch kernel is LATENCY bound (one wave per
+        # problem walking ~200 dependent BFS levels), so its fraction of the HBM peak is tiny by construction;
+        # algorithmic bytes per expanded state = 24 + 16 f1 + 4 f1 ceil(log2(f2 + 1)) + 48 m  
+        batch_kernel = None
+        if rank == 0:
+            import math
+            ctx2.reset_stats()
+            ctx2.set_profiling(True)
+            rustfst_amd.compose_shortest_path_batch(daccs, dt2, ctx=ctx2)
+            ctx2.set_profiling(False)
+            st2 = ctx2.stats()
+            if st2["compose_ms"] > 0 and st2["compose_states"] > 0:
+                f1, f2 = 1.0, float(args.fanout)
+                m = st2["compose_arcs"] / st2["compose_states"]
+                per_state = 24 + 16 * f1 + 4 * f1 * math.ceil(math.log2(f2 + 1)) + 48 * m
+                ab = per_state * st2["compose_states"]
+                batch_kernel = {
+                    "kernel": "compose_wave_kernel<FLAG_SP>", "bound": "latency (dependent round trips per BFS level)",
+                    "kernel_ms": round(st2["compose_ms"], 4), "problems": len(mine),
+                    "composed_states": int(st2["compose_states"]), "composed_arcs": int(st2["compose_arcs"]),
+                    "algorithmic_bytes": round(ab), "achieved_GBps": round(ab / (st2["compose_ms"] * 1e-3) / 1e9, 3),
+                    "frac_of_hbm_peak": round(ab / (st2["compose_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                    "us_per_bfs_level": round(1e3 * st2["compose_ms"] / (args.acc_len + 1), 3),
+                }
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1): the oracle
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -300,7 +325,7 @@ def main():
             "ms_per_compose_shortest_path": round(ms_batch / max(1, len(mine)), 5),
             "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(last["n_arcs"]),
             "setup_seconds": round(gen_s, 2), "priming_steps": 3,
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
     if world > 1 or force_dist:
