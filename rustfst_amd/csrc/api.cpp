@@ -24,6 +24,7 @@ size_t DevicePool::bucket(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 void* DevicePool::alloc(size_t bytes) {
+  std::lock_guard<std::mutex> lk(mu_);
   size_t b = bucket(bytes);
   auto it = free_.find(b);
   if (it != free_.end()) {
@@ -35,7 +36,7 @@ void* DevicePool::alloc(size_t bytes) {
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, b);
   if (e != hipSuccess) {
-    trim();
+    trim_locked();
     HIP_CHECK(hipMalloc(&p, b));
   }
   live_[p] = b;
@@ -43,14 +44,19 @@ void* DevicePool::alloc(size_t bytes) {
 }
 void DevicePool::free(void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lk(mu_);
   auto it = live_.find(p);
   if (it == live_.end()) return;
   free_.emplace(it->second, p);
   live_.erase(it);
 }
-void DevicePool::trim() {
+void DevicePool::trim_locked() {
   for (auto& kv : free_) (void)hipFree(kv.second);
   free_.clear();
+}
+void DevicePool::trim() {
+  std::lock_guard<std::mutex> lk(mu_);
+  trim_locked();
 }
 DevicePool::~DevicePool() {
   trim();

@@ -5,8 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -46,7 +48,8 @@ wfst_status wrap(F&& f) noexcept {  // rustfst-ffi/src/lib.rs:43-56 `wrap`
 }
 
 // ---------------------------------------------------------------- device memory pool
-// Size-bucketed caching allocator: hot paths never call hipMalloc/hipFree after warm-up.
+// Size-bucketed caching allocator: hot paths never call hipMalloc/hipFree after warm-up.  Thread-safe: an FST shared
+// by several contexts (threads) may grow its cached derived data from any of them.
 class DevicePool {
  public:
   explicit DevicePool(int device) { (void)device; }
@@ -57,6 +60,8 @@ class DevicePool {
 
  private:
   static size_t bucket(size_t bytes);
+  void trim_locked();
+  std::mutex mu_;
   std::multimap<size_t, void*> free_;
   std::map<void*, size_t> live_;
 };
@@ -195,8 +200,11 @@ struct wfst_fst {
   // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second
   // shortest_path query of a large FST (sssp.hip reverse_csr)
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
-  mutable uint32_t sp_queries = 0;
-  mutable uint32_t last_sweeps = 0;  // sweeps the last relaxation of this FST needed (sizes the first graph replay)
+  mutable std::atomic<uint32_t> sp_queries{0};
+  mutable std::atomic<uint32_t> last_sweeps{0};  // sweeps the last relaxation of this FST needed (sizes the first graph replay)
+  // the lazily built caches above may be requested from several contexts (threads) at once: built under this lock,
+  // with buffers taken from the OWNER context's pool (this->ctx), which outlives the handle
+  mutable std::mutex cache_mu;
 };
 
 namespace wfst {

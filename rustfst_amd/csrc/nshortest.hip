@@ -94,8 +94,9 @@ std::shared_ptr<RevFst> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
   if (E) rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.arcs, E, d_counts.p);
   if (n) HIP_CHECK(hipMemcpyAsync(finals.data(), f->dev.finals, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   // offsets of the in-arc segments (targets 0..n-1): exclusive scan of the in-degrees on the device
-  rev->d_roff = DBuf<uint32_t>(pool, (size_t)n + 1);
-  rev->d_arcs = DBuf<wfst_tr>(pool, E);
+  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;  // cached with the handle: the owner's pool outlives it
+  rev->d_roff = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
+  rev->d_arcs = DBuf<wfst_tr>(owner_pool, E);
   {
     size_t temp_bytes = 0;
     HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, d_counts.p, rev->d_roff.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
@@ -353,8 +354,13 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
   auto t_1 = tnow();
   // 2. reversed FST (GPU transpose, cached on the handle)
   wfst_fst* mf = const_cast<wfst_fst*>(f);
-  if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
-  RevFst& r = *mf->rev_host;
+  std::shared_ptr<RevFst> rev_keep;
+  {
+    std::lock_guard<std::mutex> lk(f->cache_mu);
+    if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
+    rev_keep = mf->rev_host;
+  }
+  RevFst& r = *rev_keep;
   std::vector<wfst_tr> scratch;
   auto t_2 = tnow();
   // 3. distance of the super-initial state (shortest_path.rs:143-153)

@@ -579,8 +579,9 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     // batch of a solve is sized to what the previous solve of this FST needed (+1 sweep to see the quiet one, rounded
     // up to a multiple of 4; batch sizes stay even because the flag parity of a graph node is static).
     uint32_t first_count = 8;
-    if (f->last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (f->last_sweeps + 1 + 3) & ~3u);
-    const bool predicted = f->last_sweeps != 0 && f->last_sweeps < first_count;
+    const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 3) & ~3u);
+    const bool predicted = last_sweeps != 0 && last_sweeps < first_count;
     auto enqueue_batch = [&](hipEvent_t ev) {
       // after the first batch: constant small batches while the solve is shallow, larger ones for deep lattices
       Batch b{next_sweep, 8u, 1};
@@ -622,7 +623,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   }
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
-  f->last_sweeps = sweeps_done;
+  f->last_sweeps.store(sweeps_done, std::memory_order_relaxed);
 }
 
 // Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
@@ -671,15 +672,16 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
 // Transpose of f (in-arcs as {source, position}); built the SECOND time shortest_path sees the same large FST —
 // a one-shot query keeps the parent pass, a resident transducer that is queried again pays ~1 ms once.
 const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
   if (f->rev_dev) return f->rev_dev.get();
-  f->sp_queries += 1;
-  if (f->sp_queries < 2 || f->n_arcs < (1u << 18) || f->n_arcs >= 0xFFFFFFFFull) return nullptr;
+  if (f->sp_queries.fetch_add(1) + 1 < 2 || f->n_arcs < (1u << 18) || f->n_arcs >= 0xFFFFFFFFull) return nullptr;
   if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return nullptr;
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   auto r = std::make_shared<RevCsr>();
-  r->off = DBuf<uint32_t>(*ctx->pool, (size_t)n + 1);
-  r->arc = DBuf<uint2>(*ctx->pool, f->n_arcs);
+  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;  // cached with the handle: the owner's pool outlives it
+  r->off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
+  r->arc = DBuf<uint2>(owner_pool, f->n_arcs);
   DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
   HIP_CHECK(hipMemsetAsync(indeg.p, 0, (size_t)n * sizeof(uint32_t), st));
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);

@@ -777,3 +777,39 @@ def test_config5_scale_properties():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5_scale_check.py")], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_one_fst_queried_from_two_contexts_concurrently(gpu_ctx, oracle):
+    """A resident FST is read by several contexts (host threads) at once; its lazily built caches (transpose for the
+    backtrace, reverse for n-best) are built under the handle's lock.  Every result equals the oracle's."""
+    import threading
+    t = synth.make_transducer(60000, 8, 64, 0.02, seed=21)
+    assert t["offsets"][-1] >= 1 << 18
+    d = to_device(t)
+    o = to_oracle(oracle, t)
+    ref1 = o.shortest_path_canonical().to_flat()
+    ref5 = o.shortest_path_n(5).to_flat()
+    errors = []
+
+    def work(k):
+        try:
+            ctx = rustfst_amd.Context(0)
+            for q in range(6):
+                # the handle belongs to another context: calls run on the handle's own context unless told otherwise,
+                # so drive the C-ABI with this thread's context explicitly
+                import ctypes as C
+                from rustfst_amd import _lib
+                out = C.c_void_p()
+                cfg = ShortestPathConfig(nshortest=1 if (q + k) % 2 else 5)._c()
+                _lib.check(_lib.lib().wfst_shortest_path(ctx._h, d._h, cfg, C.byref(out)), "wfst_shortest_path")
+                got = rustfst_amd.DeviceFst(out, ctx).to_flat()
+                assert_flat_identical(got, ref1 if (q + k) % 2 else ref5, f"thread {k} query {q}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
