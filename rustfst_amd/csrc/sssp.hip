@@ -97,8 +97,9 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
   return prev + delta * (float)(1u << (st - 1u));
 }
 
-__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start, float tau0) {
+__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start, float tau0, uint32_t* shadow) {
   key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
+  shadow[start] = enc_f32(0.0f);
   flags0[start] = 1;
   for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
     ctl->tau[i] = 0;
@@ -124,7 +125,8 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          uint8_t* __restrict__ flags_cur,
                                                          uint8_t* __restrict__ flags_next, uint32_t n,
                                                          uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
-                                                         uint32_t sweep_offset, float delta, uint32_t near_low) {
+                                                         uint32_t sweep_offset, float delta, uint32_t near_low,
+                                                         uint32_t* __restrict__ shadow) {
   // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
   const uint32_t sweep = ctl->base + sweep_offset;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
@@ -204,20 +206,29 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
         const float cb = (db + __uint_as_float(ab.x)) + 0.0f;
         const bool fa = va && ca < INF, fb = vb && cb < INF;  // +inf never improves (shortest_path.rs:226)
         const uint64_t cka = ((uint64_t)enc_f32(ca) << 32) | ha, ckb = ((uint64_t)enc_f32(cb) << 32) | hb;
-        // plain pre-check: keys only decrease, a stale read can only cost an extra atomic
-        uint64_t ka = 0, kb = 0;
-        if (fa) ka = key[aa.y];
-        if (fb) kb = key[ab.y];
-        const bool ta = fa && cka < ka, tb = fb && ckb < kb;
+        // Plain pre-check against a 4-byte SHADOW of the distance half of the key (4 MB for 1M states: half the bytes
+        // per gather and a far better L2 hit rate than the 8-byte keys).  shadow[t] is only ever written with values
+        // that an atomicMin has installed in key[t], and keys only decrease, so shadow[t] >= enc(d[t]) at all times:
+        // a candidate above it cannot improve; a stale (too high) shadow only costs an extra atomic; on equal
+        // distance the hop half decides and the real key is read.
+        const uint32_t eca = (uint32_t)(cka >> 32), ecb = (uint32_t)(ckb >> 32);
+        uint32_t sa = 0, sb = 0;
+        if (fa) sa = shadow[aa.y];
+        if (fb) sb = shadow[ab.y];
+        bool ta = fa && eca <= sa, tb = fb && ecb <= sb;
+        if (ta && eca == sa) ta = cka < key[aa.y];
+        if (tb && ecb == sb) tb = ckb < key[ab.y];
         uint64_t olda = 0, oldb = 0;
         if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
         if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
         if (ta && cka < olda) {
+          shadow[aa.y] = eca;
           flags_next[aa.y] = 1;
           any = true;
           near_cnt += ca <= tau ? 1u : 0u;
         }
         if (tb && ckb < oldb) {
+          shadow[ab.y] = ecb;
           flags_next[ab.y] = 1;
           any = true;
           near_cnt += cb <= tau ? 1u : 0u;
@@ -436,6 +447,7 @@ __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __re
 
 struct Solve {
   DBuf<uint64_t> key;
+  DBuf<uint32_t> shadow;  // enc(d) half of the keys, for the pre-check gathers
   DBuf<uint8_t> flags;  // two frontiers of n bytes
   DBuf<uint32_t> improved;
   DBuf<Ctl> ctl;
@@ -452,12 +464,14 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   const uint32_t n = f->n_states;
   DevicePool& pool = *ctx->pool;
   sv.key = DBuf<uint64_t>(pool, n);
+  sv.shadow = DBuf<uint32_t>(pool, n);
   const size_t n_pad = ((size_t)n + 15) & ~(size_t)15;
   sv.flags = DBuf<uint8_t>(pool, 2 * n_pad);
   sv.improved = DBuf<uint32_t>(pool, IMP_RING);
   sv.ctl = DBuf<Ctl>(pool, 1);
   hipStream_t st = ctx->stream;
   HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
+  HIP_CHECK(hipMemsetAsync(sv.shadow.p, 0xFF, (size_t)n * sizeof(uint32_t), st));
   HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
   HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
   uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n_pad};
@@ -473,7 +487,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) near_low = (uint32_t)std::atol(e);
   float tau0_mult = 1.0f;  // first band = tau0_mult x delta
   if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
-  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start, delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start, delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.shadow.p);
   const uint64_t sweep_cap = 4ull * n + 64;
   ctx->stats.sweeps = 0;
 
@@ -489,7 +503,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta, near_low);
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
       sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
-                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low);
+                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low, sv.shadow.p);
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u, nullptr);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -521,7 +535,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
       const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn ^ ((uint64_t)count << 56), (uint64_t)sv.key.p,
                                (uint64_t)sv.flags.p,
-                               (uint64_t)sv.improved.p, (uint64_t)sv.ctl.p, ((uint64_t)n << 32) | __float_as_uint_host(delta),
+                               (uint64_t)sv.improved.p ^ ((uint64_t)sv.shadow.p << 1), (uint64_t)sv.ctl.p,
+                               ((uint64_t)n << 32) | __float_as_uint_host(delta),
                                (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
       if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
       if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
@@ -538,11 +553,12 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       Ctl* a_ctl = sv.ctl.p;
       float a_delta = delta;
       uint32_t a_low = near_low;
+      uint32_t* a_shadow = sv.shadow.p;
       for (uint32_t j = 0; j < count; ++j) {  // batches start at multiples of their size: flag parity is static
         uint8_t* a_fc = fl[j & 1u];
         uint8_t* a_fn = fl[(j & 1u) ^ 1u];
         uint32_t a_off = j;
-        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low};
+        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low, &a_shadow};
         hipKernelNodeParams kp{};
         kp.func = (void*)sssp_relax_kernel;
         kp.gridDim = dim3(blocks);
