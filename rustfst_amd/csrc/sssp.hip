@@ -590,6 +590,8 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       uint32_t first, count;
       int which;
     };
+    bool use_graphs = false;
+    if (const char* e = std::getenv("WFST_SSSP_GRAPH")) use_graphs = std::atoi(e) != 0;
     uint32_t next_sweep = 0;
     // A replay boundary costs ~14 us of idle GPU (measured: profiles/r01d) and the first replay ~34 us, so the FIRST
     // batch of a solve is sized to what the previous solve of this FST needed (+1 sweep to see the quiet one, rounded
@@ -603,7 +605,17 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       Batch b{next_sweep, 8u, 1};
       if (next_sweep == 0) b = Batch{0u, first_count, 0};
       else if (next_sweep >= 64) b = Batch{next_sweep, MAX_BATCH, 2};
-      HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
+      if (use_graphs) {
+        HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
+      } else {
+        // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
+        // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
+        for (uint32_t j = 0; j < b.count; ++j)
+          sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[j & 1u], fl[(j & 1u) ^ 1u], n,
+                                                    sv.improved.p, sv.ctl.p, j, delta, near_low, sv.shadow.p);
+        sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, b.count, h_imp + b.which * IMP_RING);
+        HIP_CHECK(hipGetLastError());
+      }
       HIP_CHECK(hipEventRecord(ev, st));
       next_sweep += b.count;
       return b;
