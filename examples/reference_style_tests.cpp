@@ -1,0 +1,151 @@
+// reference_style_tests.cpp — the reference's own known-answer tests for this path, written against wfst.hpp so that they
+// read like the originals:
+//   K1  rustfst-python/tests/algorithms/test_compose.py:13-81          test_compose_fst
+//   K2  rustfst-python/tests/algorithms/test_shortest_path.py:5-51     test_shortest_path
+//   K3  rustfst/src/algorithms/compose/compose_static.rs:282-289       doctest of compose (fst![1,2 => 2,3] o fst![2,3 => 3,4])
+//   error behaviour of compose on unsorted operands (compose_fst_op.rs:169-197) and of missing states (mutable_fst.rs)
+//
+//   g++ -std=c++17 -I include examples/reference_style_tests.cpp -L rustfst_amd/lib -lwfst_amd -Wl,-rpath,$PWD/rustfst_amd/lib -o ref_tests
+#include <cstdio>
+#include <cstring>
+
+#include "wfst.hpp"
+
+using namespace wfst_amd;
+
+static int failures = 0;
+#define ASSERT(cond)                                                      \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::printf("ASSERT FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                         \
+    }                                                                     \
+  } while (0)
+
+static Tr tr(Label il, Label ol, float w, StateId ns) { return Tr{il, ol, w, ns}; }
+
+static void test_compose_fst() {  // K1
+  VectorFst fst1;
+  StateId s1 = fst1.add_state(), s2 = fst1.add_state(), s3 = fst1.add_state();
+  fst1.set_start(s1);
+  fst1.set_final(s2);
+  fst1.set_final(s3);
+  fst1.add_tr(s1, tr(1, 2, 1.0f, s2));
+  fst1.add_tr(s1, tr(1, 4, 2.0f, s3));
+  fst1.add_tr(s2, tr(3, 5, 2.0f, s2));
+
+  VectorFst fst2;
+  s1 = fst2.add_state(), s2 = fst2.add_state(), s3 = fst2.add_state();
+  fst2.set_start(s1);
+  fst2.set_final(s3);
+  fst2.add_tr(s1, tr(2, 6, 1.0f, s2));
+  fst2.add_tr(s2, tr(5, 7, 2.5f, s3));
+  fst2.add_tr(s3, tr(5, 8, 1.5f, s3));
+  fst2.add_tr(s1, tr(4, 9, 3.0f, s3));
+
+  VectorFst expected_fst;
+  s1 = expected_fst.add_state(), s2 = expected_fst.add_state(), s3 = expected_fst.add_state();
+  StateId s4 = expected_fst.add_state();
+  expected_fst.set_start(s1);
+  expected_fst.set_final(s3);
+  expected_fst.set_final(s4);
+  expected_fst.add_tr(s1, tr(1, 6, 2.0f, s2));
+  expected_fst.add_tr(s1, tr(1, 9, 5.0f, s3));
+  expected_fst.add_tr(s2, tr(3, 7, 4.5f, s4));
+  expected_fst.add_tr(s4, tr(3, 8, 3.5f, s4));
+
+  VectorFst fst3 = compose(fst1, fst2);
+  ASSERT(fst3 == expected_fst);
+  for (ComposeFilterEnum f : {ComposeFilterEnum::SequenceFilter, ComposeFilterEnum::AltSequenceFilter,
+                              ComposeFilterEnum::MatchFilter, ComposeFilterEnum::NoMatchFilter,
+                              ComposeFilterEnum::TrivialFilter, ComposeFilterEnum::NullFilter})
+    ASSERT(compose_with_config(fst1, fst2, ComposeConfig{f, true}) == expected_fst);  // no epsilons: all filters agree
+}
+
+static void test_shortest_path() {  // K2
+  VectorFst fst1;
+  StateId s1 = fst1.add_state(), s2 = fst1.add_state(), s3 = fst1.add_state(), s4 = fst1.add_state();
+  fst1.set_start(s1);
+  fst1.set_final(s4, 2.0f);
+  fst1.add_tr(s1, tr(1, 1, 3.0f, s2));
+  fst1.add_tr(s2, tr(2, 2, 2.0f, s2));
+  fst1.add_tr(s2, tr(3, 3, 4.0f, s4));
+  fst1.add_tr(s1, tr(4, 4, 5.0f, s3));
+  fst1.add_tr(s3, tr(5, 5, 4.0f, s4));
+
+  VectorFst expected_fst;
+  s1 = expected_fst.add_state(), s2 = expected_fst.add_state(), s3 = expected_fst.add_state();
+  expected_fst.set_start(s3);
+  expected_fst.set_final(s1, 2.0f);
+  expected_fst.add_tr(s3, tr(1, 1, 3.0f, s2));
+  expected_fst.add_tr(s2, tr(3, 3, 4.0f, s1));
+
+  const ShortestPathConfig config = ShortestPathConfig{}.with_nshortest(1).with_unique(true);  // ShortestPathConfig(1, True)
+  VectorFst shortest = shortest_path_with_config(fst1, config);
+  ASSERT(shortest == expected_fst);
+  ASSERT(shortest_path(fst1) == expected_fst);
+
+  // two best paths (weights 9 and 11): a tree rooted at a fresh start state, one branch per path (shortest_path.rs:409-518)
+  VectorFst two = shortest_path_with_config(fst1, ShortestPathConfig{}.with_nshortest(2));
+  ASSERT(two.start().has_value() && two.num_trs(*two.start()) == 2);
+}
+
+static void test_compose_doctest() {  // K3: transducer(labels 1,2 -> 2,3) o transducer(2,3 -> 3,4) == transducer(1,2 -> 3,4)
+  auto transducer = [](std::vector<Label> in, std::vector<Label> out) {  // utils::transducer (labels_to_fst.rs:40-109), one()
+    VectorFst f;
+    StateId cur = f.add_state();
+    f.set_start(cur);
+    for (size_t i = 0; i < in.size(); ++i) {
+      StateId nxt = f.add_state();
+      f.add_tr(cur, Tr{in[i], out[i], 0.0f, nxt});
+      cur = nxt;
+    }
+    f.set_final(cur);
+    return f;
+  };
+  ASSERT(compose(transducer({1, 2}, {2, 3}), transducer({2, 3}, {3, 4})) == transducer({1, 2}, {3, 4}));
+}
+
+static void test_errors() {
+  VectorFst a;  // olabels 7 then 2 out of state 0: not O_LABEL_SORTED
+  a.add_states(2);
+  a.set_start(0);
+  a.set_final(1);
+  a.add_tr(0, tr(1, 7, 0.0f, 1));
+  a.add_tr(0, tr(1, 2, 0.0f, 1));
+  VectorFst b;  // ilabels 7 then 2: not I_LABEL_SORTED
+  b.add_states(2);
+  b.set_start(0);
+  b.set_final(1);
+  b.add_tr(0, tr(7, 1, 0.0f, 1));
+  b.add_tr(0, tr(2, 1, 0.0f, 1));
+  bool threw = false;
+  try {
+    compose(a, b);
+  } catch (const Error& e) {
+    threw = std::strstr(e.what(), "(sort?)") != nullptr;  // compose_fst_op.rs:194
+  }
+  ASSERT(threw);
+  tr_sort(a, OLabelCompare{});
+  tr_sort(b, ILabelCompare{});
+  VectorFst ab = compose(a, b);
+  ASSERT(ab.num_states() == 2 && ab.num_trs(0) == 2);  // 0 --1:1--> 1 twice over (labels 2 and 7 both match)
+  threw = false;
+  try {
+    VectorFst c;
+    c.set_start(3);
+  } catch (const Error& e) {
+    threw = std::strstr(e.what(), "doesn't exist") != nullptr;
+  }
+  ASSERT(threw);
+  ASSERT(shortest_path(VectorFst()).num_states() == 0);  // no start state -> empty result (shortest_path.rs:185-187)
+}
+
+int main() {
+  test_compose_fst();
+  test_shortest_path();
+  test_compose_doctest();
+  test_errors();
+  std::printf(failures ? "%d assertion(s) FAILED\n" : "all reference-style tests passed\n", failures);
+  return failures != 0;
+}

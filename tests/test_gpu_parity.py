@@ -813,3 +813,21 @@ def test_one_fst_queried_from_two_contexts_concurrently(gpu_ctx, oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_cpp_reference_style_tests_run(gpu_ctx, tmp_path):
+    """examples/reference_style_tests.cpp: the reference's K1 / K2 / K3 known-answer tests and its error behaviour, written
+    against the C++ mirror include/wfst.hpp, end to end on the GPU."""
+    import shutil
+    import subprocess
+    from rustfst_amd import _lib
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "ref_tests"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "reference_style_tests.cpp"),
+                    "-L", libdir, "-lwfst_amd", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-o", str(exe)], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all reference-style tests passed" in r.stdout, r.stdout + r.stderr

@@ -166,3 +166,18 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path, wfst_lib):
                     "-L", libdir, "-lwfst_amd", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)],
                    check=True)
     assert exe.exists()
+
+
+def test_cpp_mirror_header_compiles_and_links(tmp_path, wfst_lib):
+    """include/wfst.hpp (the C++17 mirror of the reference's Rust interface for this path) and the reference-style test
+    program built on it compile warning-free and link against the library."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "ref_tests"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "reference_style_tests.cpp"), "-L", libdir, "-lwfst_amd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-o", str(exe)], check=True)
+    assert exe.exists()
