@@ -155,6 +155,12 @@ wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst
                                                    const wfst_shortest_path_config* scfg, wfst_batch_job** job);
 wfst_status wfst_compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs);
 
+/* ---- reverse (rustfst/src/algorithms/reverse.rs:33-87; FFI fst_reverse): state 0 of the result is a new super-initial
+ *      state with one eps:eps arc per final state of fst (weight = its final weight), state s + 1 holds the arcs INTO s
+ *      turned around, in (source state, arc position) order; start + 1 is final with weight one.  The transpose is built
+ *      on the GPU and cached on the handle (the n > 1 shortest-path search uses the same one). ---- */
+wfst_status wfst_reverse(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out);
+
 /* ---- tr_sort (rustfst/src/algorithms/tr_sort.rs:13-62; FFI fst_tr_sort, rustfst-ffi/src/algorithms/tr_sort.rs:15):
  *      in-place, stable, per-state sort of the device-resident arcs by ilabel (ilabel_cmp != 0, ILabelCompare)
  *      or olabel (OLabelCompare), followed by the reference's property update.  This is what makes an FST

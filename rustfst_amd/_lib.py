@@ -63,6 +63,7 @@ SYMBOLS = [
     ("wfst_compose_shortest_path_batch_end", C.c_int, [_vp, _P(_vp), _P(_u64)]),
     ("wfst_fst_pack_paths", C.c_int, [_P(_vp), _sz, _u32, _vp]),
     ("wfst_fst_tr_sort", C.c_int, [_vp, _vp, C.c_int]),
+    ("wfst_reverse", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_vec_fst_new", C.c_int, [_P(_vp)]),
     ("wfst_vec_fst_destroy", C.c_int, [_vp]),
     ("wfst_vec_fst_copy", C.c_int, [_vp, _P(_vp)]),

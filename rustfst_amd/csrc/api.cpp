@@ -318,6 +318,14 @@ wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* di
   });
 }
 
+wfst_status wfst_reverse(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !fst || !out) throw Error("null pointer");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = reverse_fst(ctx, fst);
+  });
+}
+
 wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp) {
   return wrap([&] {
     if (!ctx || !fst) throw Error("null pointer");

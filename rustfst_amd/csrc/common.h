@@ -230,6 +230,7 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
 // nshortest.hip
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
+wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f);
 // tr_sort.hip
 void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
 // compose.hip

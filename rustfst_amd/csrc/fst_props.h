@@ -101,6 +101,33 @@ inline uint64_t add_tr(uint64_t in, uint32_t state, const wfst_tr& tr, const wfs
   if (out & TOP_SORTED) out |= ACYCLIC | INITIAL_ACYCLIC;
   return out;
 }
+// add_tr over a whole SET of arcs at once.  Every effect of add_tr is a sticky set/clear decided by one fact about the arc,
+// followed by a mask that is the same for every arc, so folding add_tr over any number of arcs (in any order) equals one
+// application with the union of their facts.  facts: 1 il != ol | 2 il == 0 | 4 il == 0 && ol == 0 | 8 ol == 0 |
+// 16 ilabel below its predecessor's | 32 olabel below its predecessor's | 64 weight neither zero nor one | 128 nextstate <= state
+inline uint64_t add_trs_by_facts(uint64_t in, uint32_t facts) {
+  uint64_t out = in;
+  if (facts & 1u) out = (out | NOT_ACCEPTOR) & ~ACCEPTOR;
+  if (facts & 2u) out = (out | I_EPSILONS) & ~NO_I_EPSILONS;
+  if (facts & 4u) out = (out | EPSILONS) & ~NO_EPSILONS;
+  if (facts & 8u) out = (out | O_EPSILONS) & ~NO_O_EPSILONS;
+  if (facts & 16u) out = (out | NOT_I_LABEL_SORTED) & ~I_LABEL_SORTED;
+  if (facts & 32u) out = (out | NOT_O_LABEL_SORTED) & ~O_LABEL_SORTED;
+  if (facts & 64u) out = (out | WEIGHTED) & ~UNWEIGHTED;
+  if (facts & 128u) out = (out | NOT_TOP_SORTED) & ~TOP_SORTED;
+  out &= ADD_ARC_MASK | ACCEPTOR | NO_EPSILONS | NO_I_EPSILONS | NO_O_EPSILONS | I_LABEL_SORTED | O_LABEL_SORTED |
+         UNWEIGHTED | TOP_SORTED;
+  if (out & TOP_SORTED) out |= ACYCLIC | INITIAL_ACYCLIC;
+  return out;
+}
+// reverse_properties (mutate_properties.rs:622-638)
+inline uint64_t reverse(uint64_t inprops, bool has_superinitial) {
+  uint64_t out = (ACCEPTOR | NOT_ACCEPTOR | EPSILONS | I_EPSILONS | O_EPSILONS | UNWEIGHTED | CYCLIC | ACYCLIC |
+                  WEIGHTED_CYCLES | UNWEIGHTED_CYCLES) & inprops;
+  if (has_superinitial) out |= WEIGHTED & inprops;
+  return out;
+}
+
 inline uint64_t delete_states(uint64_t in) { return in & DELETE_STATES_MASK; }  // :102-104
 inline uint64_t compose(uint64_t p1, uint64_t p2) {                             // :151-184
   uint64_t out = 0;

@@ -140,6 +140,38 @@ std::shared_ptr<RevFst> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
   return rev;
 }
 
+// ---------------------------------------------------------------- reverse() as a public operation (wfst_reverse)
+// union of add_tr's facts (fst_props.h add_trs_by_facts) over the arcs of reversed states 1..n
+__global__ void __launch_bounds__(256) rev_facts_kernel(const uint32_t* __restrict__ roff, const wfst_tr* __restrict__ rarcs,
+                                                       uint32_t n, uint32_t* __restrict__ facts_out) {
+  uint32_t facts = 0;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const uint32_t b = roff[t], e = roff[t + 1];
+    uint32_t pil = 0, pol = 0;
+    for (uint32_t i = b; i < e; ++i) {
+      const wfst_tr a = rarcs[i];
+      facts |= (a.ilabel != a.olabel ? 1u : 0u) | (a.ilabel == 0u ? 2u : 0u) | (a.ilabel == 0u && a.olabel == 0u ? 4u : 0u) |
+               (a.olabel == 0u ? 8u : 0u) | (i > b && pil > a.ilabel ? 16u : 0u) | (i > b && pol > a.olabel ? 32u : 0u) |
+               (a.nextstate <= t + 1u ? 128u : 0u);
+      const float w = a.weight;
+      const bool is_zero = INF <= w + props::KDELTA;                                  // approx == +inf (semiring.rs:159-168)
+      const bool is_one = w <= props::KDELTA && 0.0f <= w + props::KDELTA;            // approx == 0
+      if (!is_zero && !is_one) facts |= 64u;
+      pil = a.ilabel;
+      pol = a.olabel;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) facts |= __shfl_xor(facts, d);
+  if ((threadIdx.x & 63) == 0 && facts) atomicOr(facts_out, facts);
+}
+// offsets of the output: [0, F, F + roff[1], ..., F + roff[n]]; finals: one() at start + 1
+__global__ void rev_assemble_kernel(const uint32_t* __restrict__ roff, uint32_t n, uint32_t n_super, int64_t start,
+                                    uint32_t* __restrict__ off_out, float* __restrict__ fin_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= n + 1) off_out[k] = k == 0 ? 0u : n_super + roff[k - 1];
+  if (k <= n) fin_out[k] = (k >= 1 && (int64_t)(k - 1) == start) ? 0.0f : INF;
+}
+
 // arcs of state `rs` of the reversed FST (a pointer valid until the next call)
 const wfst_tr* rev_arcs_of(wfst_ctx* ctx, RevFst& r, uint32_t rs, uint32_t* count, std::vector<wfst_tr>& scratch) {
   if (rs == 0) {
@@ -330,6 +362,68 @@ struct OutFst {
 };
 
 }  // namespace
+
+// reverse (reverse.rs:33-87): state 0 = super-initial with one eps:eps arc per final state (weight = its final weight),
+// state s + 1 = the arcs INTO s, turned around, in (source state, arc position) order; start + 1 is final with one().
+wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f) {
+  wfst_fst* mf = const_cast<wfst_fst*>(f);
+  std::shared_ptr<RevFst> rev;
+  {
+    std::lock_guard<std::mutex> lk(f->cache_mu);
+    if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
+    rev = mf->rev_host;
+  }
+  const RevFst& r = *rev;
+  const uint32_t n = r.n;
+  const uint32_t n_super = (uint32_t)r.super.size();
+  const uint64_t E = f->n_arcs;
+  hipStream_t st = ctx->stream;
+  DevicePool& pool = *ctx->pool;
+  // the in-arc segments on the device (small FSTs keep them on the host only)
+  DBuf<uint32_t> tmp_roff;
+  DBuf<wfst_tr> tmp_arcs;
+  const uint32_t* d_roff = r.d_roff.p;
+  const wfst_tr* d_arcs = r.d_arcs.p;
+  if (r.on_host) {
+    tmp_roff = DBuf<uint32_t>(pool, (size_t)n + 1);
+    tmp_arcs = DBuf<wfst_tr>(pool, E);
+    HIP_CHECK(hipMemcpyAsync(tmp_roff.p, r.h_roff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (E) HIP_CHECK(hipMemcpyAsync(tmp_arcs.p, r.h_arcs.data(), E * sizeof(wfst_tr), hipMemcpyHostToDevice, st));
+    d_roff = tmp_roff.p;
+    d_arcs = tmp_arcs.p;
+  }
+  DBuf<uint32_t> off_out(pool, (size_t)n + 2), d_facts(pool, 1);
+  DBuf<float> fin_out(pool, (size_t)n + 1);
+  DBuf<wfst_tr> arcs_out(pool, (size_t)n_super + E);
+  HIP_CHECK(hipMemsetAsync(d_facts.p, 0, sizeof(uint32_t), st));
+  if (n_super) HIP_CHECK(hipMemcpyAsync(arcs_out.p, r.super.data(), (size_t)n_super * sizeof(wfst_tr), hipMemcpyHostToDevice, st));
+  if (E) HIP_CHECK(hipMemcpyAsync(arcs_out.p + n_super, d_arcs, E * sizeof(wfst_tr), hipMemcpyDeviceToDevice, st));
+  rev_assemble_kernel<<<(n + 2 + 255) / 256, 256, 0, st>>>(d_roff, n, n_super, f->start, off_out.p, fin_out.p);
+  if (n && E) {
+    const uint32_t blocks = std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 8);
+    rev_facts_kernel<<<blocks, 256, 0, st>>>(d_roff, d_arcs, n, d_facts.p);
+  }
+  HIP_CHECK(hipGetLastError());
+  uint32_t facts = 0;
+  HIP_CHECK(hipMemcpyAsync(&facts, d_facts.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  // property word: the mutations reverse() performs, in its order (add_state x (n+1), set_final(start+1, one), the arcs
+  // state by state, set_start(0)), then reverse_properties(iprops, true) | oprops
+  uint64_t p = props::NULL_PROPS;
+  for (uint32_t k = 0; k < std::min<uint32_t>(n + 1, 2u); ++k) p = props::add_state(p);  // (idempotent after the first)
+  if (f->start >= 0) {
+    const float one = 0.0f;
+    p = props::set_final(p, nullptr, &one);
+  }
+  for (const wfst_tr& a : r.super) {  // state 0: eps:eps arcs into states >= 1
+    if (!props::is_zero(a.weight) && !props::is_one(a.weight)) facts |= 64u;
+    facts |= 2u | 4u | 8u;
+  }
+  if (n_super + E) p = props::add_trs_by_facts(p, facts);
+  p = props::set_start(p);
+  p = (props::reverse(f->props, true) | p) & props::ALL;
+  return adopt_device(ctx, n + 1, (uint64_t)n_super + E, 0, p, off_out.p, arcs_out.p, fin_out.p);
+}
 
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta) {
   OutFst ofst;

@@ -249,6 +249,12 @@ class DeviceFst:
         check(_lib.lib().wfst_shortest_path(self.ctx._h, self._h, cfg, C.byref(out)), "Error computing shortest path")
         return DeviceFst(out, self.ctx)
 
+    def reverse(self) -> "DeviceFst":
+        """algorithms::reverse (reverse.rs:33-87): new FST with a super-initial state 0."""
+        out = C.c_void_p()
+        check(_lib.lib().wfst_reverse(self.ctx._h, self._h, C.byref(out)), "Error during reverse")
+        return DeviceFst(out, self.ctx)
+
     def tr_sort(self, ilabel_cmp: bool = True) -> "DeviceFst":
         """In-place stable per-state arc sort on the device by ilabel (ILabelCompare) or olabel
         (OLabelCompare) + the reference's property update: algorithms/tr_sort.rs:13-62,

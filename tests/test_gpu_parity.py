@@ -831,3 +831,26 @@ def test_cpp_reference_style_tests_run(gpu_ctx, tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "all reference-style tests passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
+@pytest.mark.parametrize("seed", range(8))
+def test_reverse_matches_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
+    """algorithms::reverse (reverse.rs:33-87) as a public operation: states, arc order, weights, finals, start and the
+    property word (the reference's mutation bookkeeping + reverse_properties) are the oracle's."""
+    monkeypatch.setenv("WFST_NBEST_LAZY", lazy)
+    rng = np.random.default_rng(8100 + seed)
+    if seed == 0:
+        flat = dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=np.zeros(0, rustfst_amd.TR_DTYPE),
+                    finals=np.zeros(0, np.float32), props=0)
+    elif seed == 1:  # acceptor, unweighted, acyclic: the positive property bits must survive
+        flat = synth.linear_acceptor_flat([3, 1, 2])
+    else:
+        flat = random_fst_flat(rng, int(rng.integers(1, 300)), int(rng.integers(1, 9)), 6, p_eps_i=0.2 * (seed % 2),
+                               p_eps_o=0.2 * (seed % 3 == 0), p_final=rng.random() * 0.5, sort=["ilabel", "olabel", "none"][seed % 3],
+                               acyclic=bool(seed % 2), weight_grid=512 if seed % 4 else 1)
+        if seed == 5:
+            flat["start"] = None
+    d, o = to_device(flat), to_oracle(oracle, flat)
+    assert_flat_identical(d.reverse().to_flat(), o.reverse().to_flat(), f"reverse seed {seed}")
+    assert_flat_identical(d.reverse().reverse().to_flat(), o.reverse().reverse().to_flat(), f"reverse twice seed {seed}")

@@ -65,6 +65,7 @@ while time.time() < t_end:
             by_o = bool(rng.integers(0, 2))
             d.tr_sort(not by_o); o.tr_sort(by_olabel=by_o)
             assert_flat_identical(d.to_flat(), o.to_flat(), "tr_sort")
+            assert_flat_identical(d.reverse().to_flat(), o.reverse().to_flat(), "reverse")
             n["nbest"] += 1; n["sort"] += 1
         else:
             t = random_fst_flat(rng, int(rng.integers(5, 400)), int(rng.integers(1, 6)), 4, p_eps_i=rng.random() * 0.3, p_final=0.3, sort="ilabel", min_fanout=1)
