@@ -50,9 +50,11 @@ def parse_args():
                     help="run S1 then S2 of a step on ONE stream.  Default: S2's batch is enqueued asynchronously on a "
                          "second context / HIP stream (wfst_compose_shortest_path_batch_begin), S1 runs on the first, "
                          "then the batch is collected — the two independent requests overlap on the GPU.")
-    ap.add_argument("--batch-cus", type=int, default=64,
+    ap.add_argument("--batch-cus", type=int, default=0,
                     help="compute units reserved for the batch context when the two requests overlap (the other "
-                         "context gets the rest; hipExtStreamCreateWithCUMask).  0 = no partitioning.")
+                         "context gets the rest; hipExtStreamCreateWithCUMask).  0 = no partitioning (default: with the "
+                         "string o T kernel the batch is 0.19 ms and partitioning only takes CUs from shortest_path; it "
+                         "paid, 1.04 -> 0.88 ms, while the batch ran on the general 0.7 ms kernel).")
     args = ap.parse_args()
     args.overlap = not args.serial
     return args
@@ -263,7 +265,8 @@ def main():
                 per_state = 24 + 16 * f1 + 4 * f1 * math.ceil(math.log2(f2 + 1)) + 48 * m
                 ab = per_state * st2["compose_states"]
                 batch_kernel = {
-                    "kernel": "compose_wave_kernel<FLAG_SP>", "bound": "latency (dependent round trips per BFS level)",
+                    "kernel": "string_compose_sp_kernel" if st2["string_problems"] == len(mine) else "compose_wave_kernel<FLAG_SP>",
+                    "string_problems": int(st2["string_problems"]), "bound": "latency (dependent round trips per BFS level)",
                     "kernel_ms": round(st2["compose_ms"], 4), "problems": len(mine),
                     "composed_states": int(st2["compose_states"]), "composed_arcs": int(st2["compose_arcs"]),
                     "algorithmic_bytes": round(ab), "achieved_GBps": round(ab / (st2["compose_ms"] * 1e-3) / 1e9, 3),

@@ -225,6 +225,8 @@ typedef struct {
   uint64_t compose_arcs;   /* composed arcs emitted (pre-trim), last call */
   uint64_t compose_retries; /* arena-overflow retries, cumulative */
   double compose_ms;       /* device time of the last compose / fused-batch kernel */
+  uint64_t string_problems; /* problems of the last fused batch that took the string o T kernel (fst1 a linear,
+                               epsilon-free acceptor, fst2 without input epsilons) */
 } wfst_stats;
 /* profiling on: relaxation launches are bracketed by HIP events (adds sync; never on in timed runs) */
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on);

@@ -200,6 +200,13 @@ struct wfst_fst {
   // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second
   // shortest_path query of a large FST (sssp.hip reverse_csr)
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
+  // a linear, epsilon-free, single-final acceptor ("string": utils::acceptor, labels_to_fst.rs:111-132), detected at
+  // upload from the host arrays; such an fst1 takes the specialised string o T kernel of the fused batch
+  bool is_string = false;
+  // per-arc {arc begin, arc count} of the destination state (8 B per arc) and whether any arc has ilabel 0: derived
+  // lazily when the FST first serves as fst2 of the string o T kernel (compose.hip), cached under cache_mu
+  mutable std::shared_ptr<wfst::DBuf<uint2>> anext;
+  mutable int ieps_state = 0;  // 0 unknown, 1 no input epsilons, 2 has input epsilons
   mutable std::atomic<uint32_t> sp_queries{0};
   mutable std::atomic<uint32_t> last_sweeps{0};  // sweeps the last relaxation of this FST needed (sizes the first graph replay)
   // the lazily built caches above may be requested from several contexts (threads) at once: built under this lock,
@@ -231,6 +238,10 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
 // nshortest.hip
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
 wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f);
+// per-arc destination ranges / input-epsilon check of an FST used as fst2 of the string o T kernel (cached on the handle)
+const uint2* ensure_anext(wfst_ctx* ctx, const wfst_fst* f);
+bool has_input_epsilons(wfst_ctx* ctx, const wfst_fst* f);
+bool detect_string(uint32_t n_states, int64_t start, const uint32_t* offsets, const wfst_tr* arcs, const float* finals);
 // tr_sort.hip
 void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
 // compose.hip

@@ -45,7 +45,10 @@ constexpr uint32_t HV_PEND = 0x80000000u;
 constexpr uint64_t KEY_INF = ~0ull;
 
 enum : uint32_t { MODE_BOTH = 0, MODE_INPUT = 1, MODE_OUTPUT = 2 };  // MatchType after match_type()
-enum : uint32_t { ST_OK = 0, ST_OVERFLOW_STATES = 1, ST_OVERFLOW_ARCS = 2, ST_OVERFLOW_HASH = 3, ST_OVERFLOW_PATH = 4 };
+enum : uint32_t {
+  ST_OK = 0, ST_OVERFLOW_STATES = 1, ST_OVERFLOW_ARCS = 2, ST_OVERFLOW_HASH = 3, ST_OVERFLOW_PATH = 4,
+  ST_NOT_A_STRING_CASE = 5  // the string o T kernel met a case it does not cover: redo on the general kernel
+};
 enum : uint32_t { FLAG_TRIM = 1, FLAG_SP = 2 };
 
 struct FstView {
@@ -53,7 +56,8 @@ struct FstView {
   const wfst_tr* arcs;
   const float* finals;
   const uint32_t* noeps;
-  const uint4* srec;  // {arc begin, arc count, final bits, noeps}
+  const uint4* srec;   // {arc begin, arc count, final bits, SREC_* epsilon facts}
+  const uint2* anext;  // per arc {arc begin, arc count} of its destination state (string o T kernel only), or null
   uint32_t n_states;
   int32_t start;  // -1 = None
 };
@@ -997,6 +1001,187 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
   if (lane == 0) results[p] = res;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// string o T  ->  shortest path, one wave per problem: the decoding case of the fused batch, where fst1 is a linear,
+// epsilon-free, single-final acceptor (utils::acceptor, labels_to_fst.rs:111-132) and fst2 has no input-epsilon arcs.
+// The composition is then a layered lattice — BFS level i = the composed states (i, q) — so the general machinery above
+// collapses:
+//   * a tuple first seen in level i + 1 cannot have been seen before: first-occurrence ranking inside the level (ballots over
+//     the new states, which live in lane registers) IS StateTable::find_id; no hash table, no CAS round trip;
+//   * ids are handed out level by level in emission order, arcs of a state in fst2's arc order (the label-equal run of a
+//     sorted block): the numbering LazyFst::compute produces (lazy/lazy_fst.rs:226-269), hence the same canonical parent
+//     (smallest (source id, arc position) among the tight arcs == the first strict improvement in emission order);
+//   * every arc goes from level i to level i + 1: one forward pass is the exact (min,+) fixed point, hops == level;
+//   * the arc block of a destination is named by the matched arc itself (FstView::anext), so a level costs ONE dependent
+//     trip to memory (the arc blocks of the frontier) instead of three (state record -> arc block -> hash).
+// Composed states / arcs are only counted (the fused batch returns paths); parents live in LDS.  Anything outside the
+// covered case (more than 64 states in a level, more than STR_MAXS states in all) reports ST_NOT_A_STRING_CASE and the
+// host re-runs that problem on compose_wave_kernel.  Results are bit-identical to the general kernel's by construction and
+// by test (tests/test_gpu_parity.py: both kernels against the oracle).
+constexpr uint32_t STR_MAXS = 2048;
+constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(64) string_compose_sp_kernel(const ProblemDesc* __restrict__ descs, FstView f2,
+                                                               Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
+                                                               uint32_t path_cap, uint32_t* __restrict__ path_cursor) {
+  __shared__ uint32_t s_par[STR_MAXS];  // predecessor state on the best path into this state (STR_NONE: unreached)
+  __shared__ uint32_t s_ol[STR_MAXS];   // olabel of the arc taken from it
+  __shared__ float s_w[STR_MAXS];       // weight of that arc (w1 (x) w2)
+  __shared__ uint32_t s_pth[STR_MAXS];  // states of the best path, from the final one backwards
+  const uint32_t p = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const FstView f1 = descs[p].f1;
+  Result res;
+  res.status = ST_OK;
+  res.n_states = res.n_arcs = res.t_states = res.t_arcs = 0;
+  res.t_start = -1;
+  res.has_path = res.hops = 0;
+  res.final_weight = res.total = INF;
+  res.path_off = 0;
+  res.n_levels = 0;
+  if (f1.start < 0 || f2.start < 0) {  // compute_start -> None
+    if (lane == 0) results[p] = res;
+    return;
+  }
+  const uint32_t L = f1.n_states - 1u;  // number of arcs of the string
+  // frontier of the current level in registers: lane k < F holds composed state lo + k = (pos, q)
+  uint32_t q = 0, nb = 0, nc = 0;
+  float d = INF;
+  if (lane == 0) {
+    q = (uint32_t)f2.start;
+    d = 0.0f;  // Weight::one()
+    const uint4 r = ld_global16(f2.srec + q);
+    nb = r.x;
+    nc = r.y;
+  }
+  uint32_t lo = 0, hi = 1, F = 1, n_arcs = 0, level = 0;  // level = position of the current frontier in the string
+  if (lane == 0) s_par[0] = STR_NONE;
+  uint4 a_cur = make_uint4(0, 0, 0, 0);
+  if (L) a_cur = ld_global16(f1.arcs);  // the same address in every lane: one broadcast load
+  bool ok = true;
+  for (uint32_t pos = 0; pos < L && F && ok; ++pos) {
+    const uint32_t label = a_cur.x;
+    const float w1 = __uint_as_float(a_cur.z);
+    if (pos + 1 < L) a_cur = ld_global16(f1.arcs + pos + 1);  // next label: off the critical chain
+    uint32_t nq = 0, nnb = 0, nnc = 0, n_new = 0;  // new states of the next level: lane k holds state hi + k
+    float nd = INF;
+    for (uint32_t f = 0; f < F && ok; ++f) {
+      const uint32_t fb = rl(nb, f), fc = rl(nc, f);
+      const float fd = __uint_as_float(rl(__float_as_uint(d), f));
+      for (uint32_t base = 0; base < fc && ok; base += 64) {
+        const bool have = base + lane < fc;
+        uint4 a = make_uint4(0, 0, 0, 0);
+        uint2 nx = make_uint2(0, 0);
+        if (have) {
+          a = ld_global16(f2.arcs + fb + base + lane);
+          nx = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(f2.anext) + 8ull * (fb + base + lane));
+        }
+        uint64_t m = __ballot(have && a.x == label);  // the label-equal run of fst2's (sorted) block, in arc order
+        n_arcs += (uint32_t)__popcll(m);
+        while (m) {
+          const uint32_t l = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+          m &= m - 1;
+          const uint32_t qd = rl(a.w, l), ol = rl(a.y, l), xb = rl(nx.x, l), xc = rl(nx.y, l);
+          const float w2 = __uint_as_float(rl(a.z, l));
+          const float wsum = wtimes(w1, w2);  // add_tr, compose_fst_op.rs:267-285
+          float c = INF;
+          if (fd < INF) c = (fd + wsum) + 0.0f;  // candidate distance; +inf never relaxes (shortest_path.rs:226)
+          const uint64_t ex = __ballot(lane < n_new && nq == qd);  // StateTable::find_id inside the level
+          uint32_t idx;
+          if (ex == 0) {
+            idx = n_new;
+            if (idx >= 64u || hi + idx >= STR_MAXS) {
+              ok = false;
+              break;
+            }
+            if (lane == idx) {
+              nq = qd;
+              nnb = xb;
+              nnc = xc;
+              nd = INF;
+            }
+            if (lane == 0) s_par[hi + idx] = STR_NONE;
+            n_new += 1;
+          } else {
+            idx = (uint32_t)__ffsll((unsigned long long)ex) - 1u;
+          }
+          const float cur = __uint_as_float(rl(__float_as_uint(nd), idx));
+          if (c < cur) {  // strict: on ties the earlier (source id, arc position) stays
+            if (lane == idx) nd = c;
+            if (lane == 0) {
+              s_par[hi + idx] = lo + f;
+              s_ol[hi + idx] = ol;
+              s_w[hi + idx] = wsum;
+            }
+          }
+        }
+      }
+    }
+    lo = hi;
+    hi += n_new;
+    F = n_new;
+    q = nq;
+    nb = nnb;
+    nc = nnc;
+    d = nd;
+    if (F) level = pos + 1;
+  }
+  if (!ok) {
+    res.status = ST_NOT_A_STRING_CASE;
+    if (lane == 0) results[p] = res;
+    return;
+  }
+  res.n_states = hi;
+  res.n_arcs = n_arcs;
+  res.n_levels = level + 1u;
+  // final states: only level L can be final (fst1's single final state); rho = rho1 (x) rho2 (compose_fst_op.rs:420-449)
+  lds_handoff();
+  unsigned long long best = KEY_INF;
+  float my_fin = INF;
+  if (F && level == L) {  // the whole string was consumed
+    const float fin1 = __uint_as_float(ld_global16(f1.srec + L).z);
+    if (lane < F) {
+      const float fin2 = __uint_as_float(ld_global16(f2.srec + q).z);
+      if (fin1 != INF && fin2 != INF) my_fin = wtimes(fin1, fin2);
+      if (d < INF && my_fin < INF) {
+        const float tot = (d + my_fin) + 0.0f;
+        if (tot < INF) best = ((unsigned long long)enc_f32(tot) << 32) | (lo + lane);
+      }
+    }
+  }
+  best = wave_min_u64(best);
+  if (best != KEY_INF) {
+    const uint32_t fp = (uint32_t)best;
+    res.has_path = 1;
+    res.hops = L;
+    res.final_weight = __uint_as_float(rl(__float_as_uint(my_fin), fp - lo));
+    res.total = dec_f32((uint32_t)(best >> 32));
+    if (lane == 0) {  // walk the parents back (LDS); state k of the walk is in level L - k
+      uint32_t cur = fp;
+      for (uint32_t k = 0; k < L; ++k) {
+        s_pth[k] = cur;
+        cur = s_par[cur];
+      }
+    }
+    lds_handoff();
+    uint32_t poff = 0;
+    if (lane == 0) poff = atomicAdd(path_cursor, L);
+    poff = __shfl(poff, 0);
+    if ((uint64_t)poff + L > path_cap) {
+      res.status = ST_OVERFLOW_PATH;
+    } else {
+      res.path_off = poff;
+      for (uint32_t k = lane; k < L; k += 64) {  // arc k enters the k-th state created by the backtrace (shortest_path.rs:257-272)
+        const uint32_t st = s_pth[k];
+        const uint32_t il = ld_global16(f1.arcs + (L - 1u - k)).x;
+        store_arc(path_buf + poff + k, il, s_ol[st], s_w[st], k);
+      }
+    }
+  }
+  if (lane == 0) results[p] = res;
+}
+
 // ---------------------------------------------------------------- host side
 // ComposeFstOp::match_type (compose_fst_op.rs:169-197) with SortedMatcher::match_type
 // (matchers/sorted_matcher.rs:56-85): decided from the property bits only.
@@ -1021,6 +1206,7 @@ FstView view_of(const wfst_fst* f) {
   v.finals = f->dev.finals;
   v.noeps = f->dev.noeps;
   v.srec = f->dev.srec;
+  v.anext = nullptr;
   v.n_states = f->n_states;
   v.start = (int32_t)f->start;
   return v;
@@ -1065,20 +1251,28 @@ struct BatchRun {
   wfst_tr* h_eager = nullptr;
   uint32_t eager = 0;
   const wfst_tr* host_paths = nullptr;
+  bool string_kernel = false;  // this run went through string_compose_sp_kernel
 };
 
+inline size_t run_pinned_bytes(size_t n, uint32_t eager) {
+  return ((n * (sizeof(ProblemDesc) + sizeof(Result)) + 64 + (size_t)eager * sizeof(wfst_tr)) + 255) & ~(size_t)255;
+}
+
 // Enqueues descriptors, the kernel and the result copies on ctx's stream and returns without waiting.
+// `pinned` (optional): where this run's staging lives inside ctx->pinned_big (two runs of one job share the buffer);
+// `string_kernel`: launch string_compose_sp_kernel (no arena) instead of compose_wave_kernel.
 template <uint32_t FLAGS>
 void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
-                  bool want_paths, uint32_t eager_paths = 0) {
+                  bool want_paths, uint32_t eager_paths = 0, char* pinned = nullptr, bool string_kernel = false) {
   const size_t n = descs.size();
   DevicePool& pool = *ctx->pool;
   hipStream_t st = ctx->stream;
   run.n = n;
   run.want_paths = want_paths;
   run.caps = caps;
-  run.stride = arena_bytes(caps);
-  run.arena = DBuf<char>(pool, run.stride * n);
+  run.string_kernel = string_kernel;
+  run.stride = string_kernel ? 0 : arena_bytes(caps);
+  run.arena = DBuf<char>(pool, string_kernel ? 256 : run.stride * n);
   run.d_desc = DBuf<ProblemDesc>(pool, n);
   run.d_res = DBuf<Result>(pool, n);
   run.d_cursor = DBuf<uint32_t>(pool, 1);
@@ -1086,14 +1280,16 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   run.path_cap = path_cap;
   run.paths = DBuf<wfst_tr>(pool, path_cap);
   run.eager = want_paths ? std::min(eager_paths, path_cap) : 0u;
-  ProblemDesc* h_desc = (ProblemDesc*)ctx->pinned_big.get(n * sizeof(ProblemDesc) + n * sizeof(Result) + 64 +
-                                                          (size_t)run.eager * sizeof(wfst_tr));
+  ProblemDesc* h_desc = (ProblemDesc*)(pinned ? pinned : (char*)ctx->pinned_big.get(run_pinned_bytes(n, run.eager)));
   std::memcpy(h_desc, descs.data(), n * sizeof(ProblemDesc));
   HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(run.d_cursor.p, 0, sizeof(uint32_t), st));
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, caps, run.arena.p, run.stride, run.d_res.p,
-                                                          run.paths.p, path_cap, run.d_cursor.p);
+  if (string_kernel)
+    string_compose_sp_kernel<<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, run.d_res.p, run.paths.p, path_cap, run.d_cursor.p);
+  else
+    compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, caps, run.arena.p, run.stride, run.d_res.p,
+                                                            run.paths.p, path_cap, run.d_cursor.p);
   HIP_CHECK(hipGetLastError());
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
   run.h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
@@ -1121,7 +1317,7 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
   }
   run.results.assign(h_res, h_res + n);
 #ifdef WFST_PHASE_TIMING
-  {
+  if (!run.string_kernel) {
     unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; ++i)
       for (int k = 0; k < 8; ++k) tot[k] += h_res[i].dbg[k];
@@ -1246,6 +1442,10 @@ struct wfst_batch_job {
   std::vector<size_t> todo;
   uint64_t est_s = 0, est_a = 0;
   wfst::BatchRun run;
+  // problems that took the string o T kernel (fst1 a linear epsilon-free acceptor, fst2 without input epsilons)
+  std::vector<size_t> todo_s;
+  wfst::BatchRun run_s;
+  wfst::FstView v2_s{};  // fst2 with its per-arc destination ranges
 };
 
 namespace wfst {
@@ -1273,10 +1473,42 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   }
   job->est_s = 4ull * max_states + 256;
   job->est_a = 2ull * job->est_s;
-  uint64_t eager = 0;  // a path through A_i o T has at most |A_i| - 1 arcs unless T loops on input epsilons
-  for (size_t i = 0; i < n; ++i) eager += accs[i]->n_states;
-  launch_begin<FLAG_SP>(ctx, job->descs, job->v2, make_caps(job->est_s, job->est_a), job->run, true,
-                        (uint32_t)std::min<uint64_t>(eager, 1u << 22));
+  // which problems are "string o T" (the decoding case)?
+  bool string_ok = (filter == 0 || filter == 3) && t->n_arcs > 0 && t->n_arcs < 0xFFFFFFFFull;
+  if (const char* e = std::getenv("WFST_STRING_KERNEL")) string_ok = string_ok && std::atoi(e) != 0;
+  if (string_ok) {
+    bool any = false;
+    for (size_t i = 0; i < n && !any; ++i) any = accs[i]->is_string && accs[i]->n_states <= STR_MAXS;
+    string_ok = any && !has_input_epsilons(ctx, t);
+  }
+  std::vector<ProblemDesc> d_str, d_gen;
+  std::vector<size_t> todo_gen;
+  uint64_t eager_s = 0, eager_g = 0;  // a path through A_i o T has at most |A_i| - 1 arcs unless T loops on input epsilons
+  if (string_ok) {
+    job->v2_s = job->v2;
+    job->v2_s.anext = ensure_anext(ctx, t);
+    string_ok = job->v2_s.anext != nullptr;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    if (string_ok && accs[i]->is_string && accs[i]->n_states <= STR_MAXS) {
+      job->todo_s.push_back(i);
+      d_str.push_back(job->descs[i]);
+      eager_s += accs[i]->n_states;
+    } else {
+      todo_gen.push_back(i);
+      d_gen.push_back(job->descs[i]);
+      eager_g += accs[i]->n_states;
+    }
+  }
+  job->todo.swap(todo_gen);
+  const uint32_t e_s = (uint32_t)std::min<uint64_t>(eager_s, 1u << 22), e_g = (uint32_t)std::min<uint64_t>(eager_g, 1u << 22);
+  const size_t pin_s = d_str.empty() ? 0 : run_pinned_bytes(d_str.size(), e_s);
+  const size_t pin_g = d_gen.empty() ? 0 : run_pinned_bytes(d_gen.size(), e_g);
+  char* pin = (char*)ctx->pinned_big.get(pin_s + pin_g + 256);
+  if (!d_str.empty())
+    launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true);
+  if (!d_gen.empty())
+    launch_begin<FLAG_SP>(ctx, d_gen, job->v2, make_caps(job->est_s, job->est_a), job->run, true, e_g, pin + pin_s, false);
   return job.release();
 }
 
@@ -1287,13 +1519,51 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
   if (composed_arcs) *composed_arcs = 0;
   if (n == 0) return;
   for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
-  uint64_t tot_arcs = 0, tot_states = 0;
+  uint64_t tot_arcs = 0, tot_states = 0, n_string_ok = 0;
   double ms = 0;
   const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   try {
-    for (int attempt = 0;; ++attempt) {
+    if (!job->todo_s.empty()) {  // results of the string o T kernel; what it did not cover joins the general list
+      launch_end(ctx, job->run_s);
+      ms += ctx->stats.compose_ms;
+      std::vector<size_t> more;
+      for (size_t k = 0; k < job->todo_s.size(); ++k) {
+        const Result& r = job->run_s.results[k];
+        if (r.status != ST_OK) {
+          more.push_back(job->todo_s[k]);
+          continue;
+        }
+        tot_arcs += r.n_arcs;
+        tot_states += r.n_states;
+        n_string_ok += 1;
+        outs[job->todo_s[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run_s.host_paths + r.path_off : nullptr);
+      }
+      if (!more.empty()) {
+        if (!job->todo.empty()) {  // the general run of this job is still in flight: collect it first
+          launch_end(ctx, job->run);
+          std::vector<size_t> again;
+          for (size_t k = 0; k < job->todo.size(); ++k) {
+            const Result& r = job->run.results[k];
+            if (r.status != ST_OK) {
+              again.push_back(job->todo[k]);
+              continue;
+            }
+            tot_arcs += r.n_arcs;
+            tot_states += r.n_states;
+            outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
+          }
+          more.insert(more.end(), again.begin(), again.end());
+        }
+        job->todo.swap(more);
+        std::vector<ProblemDesc> cur(job->todo.size());
+        for (size_t k = 0; k < job->todo.size(); ++k) cur[k] = job->descs[job->todo[k]];
+        job->run = BatchRun{};
+        launch_begin<FLAG_SP>(ctx, cur, job->v2, make_caps(job->est_s, job->est_a), job->run, true);
+      }
+    }
+    for (int attempt = 0; !job->todo.empty(); ++attempt) {
       launch_end(ctx, job->run);
       auto t_b = tnow();
       if (timing) std::fprintf(stderr, "[batch_end] wait+copy %.1f us\n", std::chrono::duration<double, std::micro>(t_b - t_a).count());
@@ -1331,6 +1601,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
   ctx->stats.compose_states = tot_states;
   ctx->stats.compose_arcs = tot_arcs;
   ctx->stats.compose_ms = ms;
+  ctx->stats.string_problems = n_string_ok;
   if (composed_arcs) *composed_arcs = tot_arcs;
 }
 

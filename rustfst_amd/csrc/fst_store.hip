@@ -71,6 +71,27 @@ __global__ void derive_wn_kernel(const wfst_tr* __restrict__ arcs, uint2* __rest
   }
 }
 
+// one thread per arc: {arc begin, arc count} of the destination state
+__global__ void derive_anext_kernel(const wfst_tr* __restrict__ arcs, const uint32_t* __restrict__ offsets,
+                                    uint2* __restrict__ anext, uint64_t n_arcs, uint32_t n_states) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_arcs; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t ns = arcs[i].nextstate;
+    uint2 r = make_uint2(0u, 0u);
+    if (ns < n_states) {
+      const uint32_t b = offsets[ns];
+      r = make_uint2(b, offsets[ns + 1] - b);
+    }
+    anext[i] = r;
+  }
+}
+// does any state have an arc with ilabel 0?  (the state records already carry the fact)
+__global__ void any_ieps_kernel(const uint4* __restrict__ srec, uint32_t n_states, uint32_t* __restrict__ flag) {
+  bool any = false;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_states; s += gridDim.x * blockDim.x)
+    any |= srec[s].y != 0u && (srec[s].w & SREC_NO_IEPS) == 0u;
+  if (__any(any) && (threadIdx.x & 63) == 0) *flag = 1u;
+}
+
 // one thread per state (of the concatenation): count olabel == 0 arcs; validate offsets.
 // seg_* describe the FSTs packed in the arena so that nextstate bounds are per FST.
 __global__ void derive_noeps_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
@@ -130,6 +151,65 @@ void check_header(uint32_t n_states, int64_t start) {
   if (n_states >= 0x7FFFFFFFu) throw Error("FST too large: state ids must fit in 31 bits");
   if (start < -1 || (start >= 0 && (uint64_t)start >= n_states)) throw Error("start state out of range");
 }
+
+}  // namespace
+
+const uint2* ensure_anext(wfst_ctx* ctx, const wfst_fst* f) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
+  if (f->anext) return f->anext->p;
+  if (!f->has_dev || f->n_arcs == 0) return nullptr;
+  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
+  auto buf = std::make_shared<DBuf<uint2>>(owner_pool, f->n_arcs);
+  int blocks = (int)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
+  derive_anext_kernel<<<blocks, 256, 0, ctx->stream>>>(f->dev.arcs, f->dev.offsets, buf->p, f->n_arcs, f->n_states);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  f->anext = buf;
+  return buf->p;
+}
+
+bool has_input_epsilons(wfst_ctx* ctx, const wfst_fst* f) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
+  if (f->ieps_state == 0) {
+    if (f->props & props::NO_I_EPSILONS) {
+      f->ieps_state = 1;
+    } else if (f->props & props::I_EPSILONS) {
+      f->ieps_state = 2;
+    } else if (!f->has_dev || f->n_states == 0) {
+      f->ieps_state = 1;
+      if (f->has_host)
+        for (const wfst_tr& a : f->host.arcs)
+          if (a.ilabel == WFST_EPS_LABEL) f->ieps_state = 2;
+    } else {
+      DBuf<uint32_t> flag(*ctx->pool, 1);
+      HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), ctx->stream));
+      const uint32_t blocks = std::min<uint32_t>((f->n_states + 255) / 256, (uint32_t)ctx->n_cus * 8);
+      any_ieps_kernel<<<blocks, 256, 0, ctx->stream>>>(f->dev.srec, f->n_states, flag.p);
+      uint32_t h = 0;
+      HIP_CHECK(hipMemcpyAsync(&h, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      f->ieps_state = h ? 2 : 1;
+    }
+  }
+  return f->ieps_state == 2;
+}
+
+// utils::acceptor shape (labels_to_fst.rs:111-132): states 0..L in a chain, state s < L has exactly one arc, to s + 1,
+// ilabel == olabel != 0; only state L is final; start = 0
+bool detect_string(uint32_t n_states, int64_t start, const uint32_t* offsets, const wfst_tr* arcs, const float* finals) {
+  if (n_states == 0 || start != 0) return false;
+  const uint32_t L = n_states - 1;
+  if (offsets[n_states] != L) return false;
+  for (uint32_t s = 0; s < L; ++s) {
+    if (offsets[s] != s) return false;
+    const wfst_tr& a = arcs[s];
+    if (a.nextstate != s + 1 || a.ilabel != a.olabel || a.ilabel == WFST_EPS_LABEL) return false;
+    if (finals[s] != INF) return false;
+  }
+  return offsets[L] == L && finals[L] != INF;
+}
+
+namespace {
 
 // Runs the derive kernels for a single FST laid out at `l` in `arena` and validates it.
 void derive_single(wfst_ctx* ctx, const DeviceCsr& d, uint32_t n_states, uint64_t n_arcs, float* mean_weight,
@@ -223,7 +303,9 @@ wfst_fst* upload_from_host(wfst_ctx* ctx, uint32_t n_states, int64_t start, cons
   uint64_t n_arcs = n_states ? offsets[n_states] : 0;
   if (n_states && offsets[0] != 0) throw Error("invalid FST: offsets[0] must be 0");
   if (n_arcs && !arcs) throw Error("null arcs array");
-  return upload_generic(ctx, n_states, start, offsets, arcs, finals, props, hipMemcpyHostToDevice, n_arcs);
+  wfst_fst* f = upload_generic(ctx, n_states, start, offsets, arcs, finals, props, hipMemcpyHostToDevice, n_arcs);
+  f->is_string = n_states <= 65536 && detect_string(n_states, start, offsets, arcs, finals);
+  return f;
 }
 
 wfst_fst* upload_from_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* d_offsets,
@@ -310,6 +392,8 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
     f->dev.wn = all.wn + arc_base[i];
     f->dev.srec = all.srec + state_base[i];
     f->has_dev = true;
+    f->is_string = n_states[i] <= 65536 && detect_string(n_states[i], starts[i], offsets_cat + state_base[i] + i,
+                                                         arcs_cat + arc_base[i], finals_cat + state_base[i]);
     outs[i] = f.release();
   }
 }

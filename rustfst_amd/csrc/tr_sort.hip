@@ -175,6 +175,7 @@ void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp) {
     }
     f->rev_host.reset();
     f->rev_dev.reset();  // arc positions changed
+    f->anext.reset();
   }
   f->props = tr_sort_props(f->props, ilabel_cmp);
 }

@@ -854,3 +854,87 @@ def test_reverse_matches_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
     d, o = to_device(flat), to_oracle(oracle, flat)
     assert_flat_identical(d.reverse().to_flat(), o.reverse().to_flat(), f"reverse seed {seed}")
     assert_flat_identical(d.reverse().reverse().to_flat(), o.reverse().reverse().to_flat(), f"reverse twice seed {seed}")
+
+
+# ------------------------------------------------------------------ the string o T kernel of the fused batch
+@pytest.mark.parametrize("kernel", ["1", "0"], ids=["string_kernel", "general_kernel"])
+@pytest.mark.parametrize("seed", range(10))
+def test_string_batch_both_kernels_match_oracle(gpu_ctx, oracle, seed, kernel, monkeypatch):
+    """Linear epsilon-free acceptors against an input-epsilon-free T: the specialised string o T kernel and the general
+    kernel must both return the oracle's canonical path (ids of the untrimmed composition decide ties: small alphabets
+    and integer weights make ties and wide levels frequent), the same composed-arc count, and identical property words."""
+    monkeypatch.setenv("WFST_STRING_KERNEL", kernel)
+    rng = np.random.default_rng(12_000 + seed)
+    ties = seed % 2 == 0
+    n_t, fan, sigma = int(rng.integers(2, 60)), int(rng.integers(1, 7)), int(rng.integers(1, 4))
+    t = random_fst_flat(rng, n_t, fan, sigma, p_final=0.4, sort="ilabel", min_fanout=1, weight_grid=1 if ties else 512,
+                        max_w=3 if ties else 2560)
+    accs = []
+    for k in range(6):
+        length = int(rng.integers(0, 40))
+        a = synth.linear_acceptor_flat(rng.integers(1, sigma + 1, length).astype(np.uint32), final_weight=0.5 * (k % 2))
+        if k % 3 == 0 and length:
+            a["arcs"]["weight"] = (rng.integers(0, 4, length)).astype(np.float32)  # weighted string
+            a["props"] = 0x0000_0000_0001_0000 | synth.I_LABEL_SORTED | synth.O_LABEL_SORTED  # ACCEPTOR + sorted, rest unknown
+        accs.append(a)
+    ctx = rustfst_amd.default_context()
+    dacc = rustfst_amd.DeviceFst.upload_many(accs, ctx)
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch(dacc, to_device(t))
+    used = ctx.stats()["string_problems"]
+    assert used == (len(accs) if kernel == "1" else 0)
+    ot = to_oracle(oracle, t)
+    want_arcs = 0
+    for a, out in zip(accs, outs):
+        oc = to_oracle(oracle, a).compose(ot, connect=False)
+        want_arcs += oc.num_arcs
+        assert_flat_identical(out.to_flat(), oc.shortest_path_canonical().to_flat(), f"seed {seed} kernel {kernel}")
+    assert n_arcs == want_arcs
+
+
+def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
+    """Levels wider than one wave, input epsilons in T, epsilons or branching in fst1, explicit non-sequence filters: the
+    batch silently takes the general kernel (per problem) and still matches the oracle."""
+    rng = np.random.default_rng(5)
+    ctx = rustfst_amd.default_context()
+    # 1. a level wider than 64 states: T fans one label out to 100 distinct states
+    n = 103
+    rows, offsets = [], [0]
+    for s in range(n):
+        if s == 0:
+            rows += [(1, 1, float(k % 5), 1 + k) for k in range(100)]
+        elif s <= 100:
+            rows += [(1, 2, 1.0, 101)]
+        elif s == 101:
+            rows += [(1, 3, 0.5, 102)]
+        offsets.append(len(rows))
+    arcs = np.array(rows, dtype=rustfst_amd.TR_DTYPE)
+    finals = np.full(n, np.inf, np.float32)
+    finals[102] = 0.0
+    t = dict(n_states=n, start=0, offsets=np.array(offsets, np.uint32), arcs=arcs, finals=finals,
+             props=synth.I_LABEL_SORTED)
+    a = synth.linear_acceptor_flat(np.array([1, 1, 1], np.uint32))
+    outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many([a, a], ctx), to_device(t))
+    assert ctx.stats()["string_problems"] == 0  # both problems overflowed the 64-state level and were redone
+    want = to_oracle(oracle, a).compose(to_oracle(oracle, t)).shortest_path_canonical().to_flat()
+    for o in outs:
+        assert_flat_identical(o.to_flat(), want, "wide level")
+    # 2. T with input epsilons -> general kernel for everybody
+    t2 = random_fst_flat(rng, 30, 4, 3, p_eps_i=0.3, p_final=0.3, sort="ilabel", min_fanout=1)
+    b = synth.linear_acceptor_flat(np.array([1, 2, 3, 1], np.uint32))
+    outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many([b], ctx), to_device(t2))
+    assert ctx.stats()["string_problems"] == 0
+    assert_flat_identical(outs[0].to_flat(), to_oracle(oracle, b).compose(to_oracle(oracle, t2)).shortest_path_canonical().to_flat(), "T with eps")
+    # 3. mixed batch: a string, a branching acceptor, a string with an epsilon label; explicit Match filter for all
+    t3 = random_fst_flat(rng, 40, 4, 3, p_final=0.3, sort="ilabel", min_fanout=1)
+    branching = random_fst_flat(rng, 6, 2, 3, p_final=0.5, sort="olabel", acyclic=True, min_fanout=1)
+    eps_string = synth.linear_acceptor_flat(np.array([1, 2], np.uint32))
+    eps_string["arcs"]["ilabel"][1] = 0
+    eps_string["arcs"]["olabel"][1] = 0
+    eps_string["props"] = 0x0000_0000_0001_0000 | synth.I_LABEL_SORTED | synth.O_LABEL_SORTED
+    batch = [b, branching, eps_string]
+    for flt, expect in ((ComposeFilter.AUTOFILTER, 1), (ComposeFilter.SEQUENCEFILTER, 1), (ComposeFilter.MATCHFILTER, 0)):
+        outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(batch, ctx), to_device(t3), ComposeConfig(flt))
+        assert ctx.stats()["string_problems"] == expect
+        for x, out in zip(batch, outs):
+            want = to_oracle(oracle, x).compose(to_oracle(oracle, t3), compose_filter=flt.value).shortest_path_canonical().to_flat()
+            assert_flat_identical(out.to_flat(), want, f"mixed batch {flt.name}")

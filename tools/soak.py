@@ -71,6 +71,11 @@ while time.time() < t_end:
             t = random_fst_flat(rng, int(rng.integers(5, 400)), int(rng.integers(1, 6)), 4, p_eps_i=rng.random() * 0.3, p_final=0.3, sort="ilabel", min_fanout=1)
             accs = [random_fst_flat(rng, int(rng.integers(1, 25)), 2, 4, p_eps_o=rng.random() * 0.3, p_final=0.4, sort="olabel", acyclic=bool(rng.integers(0, 2)))
                     for _ in range(int(rng.integers(1, 9)))]
+            # ... and linear acceptors (the string o T kernel when t has no input epsilons), small alphabet => ties
+            from rustfst_amd import synth as _synth
+            accs += [_synth.linear_acceptor_flat(rng.integers(1, 3 if seed % 3 else 5, int(rng.integers(0, 30))).astype(np.uint32),
+                                                 final_weight=float(rng.integers(0, 3))) for _ in range(int(rng.integers(0, 5)))]
+            os.environ["WFST_STRING_KERNEL"] = str(int(rng.integers(0, 2)))
             flt = FILTERS[int(rng.integers(0, len(FILTERS)))]
             outs, _ = rustfst_amd.compose_shortest_path_batch([to_device(x) for x in accs], to_device(t), ComposeConfig(flt))
             ot = to_oracle(O, t)
