@@ -141,8 +141,10 @@ def main():
             # GPU-wide relaxation sweeps is queued, or the hardware runs the chain to its end first
             # (tools/ubench_concurrency.hip: 623 us overlapped vs 904 us serialised).
             job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
-            sp = dt.shortest_path()
+            # S1 asynchronously too: the host builds the batch's 64 result FSTs while the sweeps are still running
+            sp_job = dt.shortest_path_begin()
             outs, n_arcs = job.finish()
+            sp = sp_job.finish()
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
         if world > 1 or force_dist:
             last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)

@@ -145,6 +145,17 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* asynchronous form of wfst_shortest_path for nshortest == 1: _begin queues the relaxation (and, from the second
+ * query of an FST on, the final-state search, backtrace and read-back behind it) on ctx's stream and returns; _end
+ * waits, continues the relaxation if it needed more sweeps than the previous query, and returns the same FST the
+ * synchronous call returns, freeing the job (also on error; out == NULL abandons it).  One job in flight per context
+ * and no other call on that context between _begin and _end; fst must stay alive until _end.  cfg as in
+ * wfst_shortest_path; nshortest != 1 -> KO "unsupported". */
+typedef struct wfst_sp_job wfst_sp_job;
+wfst_status wfst_shortest_path_begin(wfst_ctx* ctx, const wfst_fst* fst, const wfst_shortest_path_config* cfg,
+                                     wfst_sp_job** job);
+wfst_status wfst_shortest_path_end(wfst_sp_job* job, wfst_fst** out);
+
 /* asynchronous form of the fused batch: _begin enqueues the whole pipeline on ctx's stream and returns at once
  * (so that the caller can issue other work, e.g. wfst_shortest_path on ANOTHER context, which then overlaps on
  * the GPU); _end waits, fills outs[0..n) / composed_arcs exactly like the synchronous call and frees the job

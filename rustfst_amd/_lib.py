@@ -56,6 +56,8 @@ SYMBOLS = [
     ("wfst_fst_destroy_many", C.c_int, [_P(_vp), _sz]),
     ("wfst_compose", C.c_int, [_vp, _vp, _vp, _P(ComposeConfig), _P(_vp)]),
     ("wfst_shortest_path", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
+    ("wfst_shortest_path_begin", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
+    ("wfst_shortest_path_end", C.c_int, [_vp, _P(_vp)]),
     ("wfst_shortest_distance", C.c_int, [_vp, _vp, _vp, _vp]),
     ("wfst_compose_shortest_path_batch", C.c_int,
      [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _P(_vp), _P(_u64)]),

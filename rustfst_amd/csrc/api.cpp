@@ -348,6 +348,35 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
   });
 }
 
+wfst_status wfst_shortest_path_begin(wfst_ctx* ctx, const wfst_fst* fst, const wfst_shortest_path_config* cfg,
+                                     wfst_sp_job** job) {
+  return wrap([&] {
+    if (!ctx || !fst || !job) throw Error("null pointer");
+    *job = nullptr;
+    wfst_shortest_path_config c = cfg ? *cfg : wfst_shortest_path_config{1e-6f, 1, 0};
+    if (c.nshortest != 1) throw Error("unsupported: nshortest != 1 in the asynchronous shortest_path");
+    if (ctx->sp_in_flight) throw Error("a shortest_path job is already in flight on this context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *job = shortest_path_n1_begin(ctx, fst);
+    ctx->sp_in_flight = true;
+  });
+}
+
+wfst_status wfst_shortest_path_end(wfst_sp_job* job, wfst_fst** out) {
+  return wrap([&] {
+    if (!job) throw Error("null job");
+    wfst_ctx* ctx = sp_job_ctx(job);
+    ctx->sp_in_flight = false;
+    if (!out) {
+      shortest_path_n1_abandon(job);
+      throw Error("null pointer");
+    }
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = shortest_path_n1_end(job);
+  });
+}
+
 wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
                                                    const wfst_fst* t, const wfst_compose_config* ccfg,
                                                    const wfst_shortest_path_config* scfg, wfst_batch_job** job) {

@@ -112,6 +112,7 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
   bool batch_in_flight = false;  // wfst_compose_shortest_path_batch_begin .. _end
+  bool sp_in_flight = false;     // wfst_shortest_path_begin .. _end
   wfst_stats stats{};
   struct SweepSample {
     double ms;
@@ -234,6 +235,10 @@ void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
 void fst_to_openfst_const_bytes(const wfst_fst* f, std::vector<uint8_t>& out);
 // sssp.hip
 wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f);
+wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f);
+wfst_fst* shortest_path_n1_end(wfst_sp_job* job);
+void shortest_path_n1_abandon(wfst_sp_job* job);
+wfst_ctx* sp_job_ctx(wfst_sp_job* job);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
 // nshortest.hip
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);

@@ -452,15 +452,21 @@ struct Solve {
   DBuf<uint32_t> improved;
   DBuf<Ctl> ctl;
   uint32_t sweeps = 0;
+  // schedule parameters fixed by relax_setup
+  uint8_t* fl[2] = {nullptr, nullptr};
+  uint32_t blocks = 1, near_low = 4096;
+  float delta = 0.0f;
+  uint64_t sweep_cap = 0;
 };
 
 constexpr uint32_t MAX_BATCH = 64;
 
-// Runs the relaxation to its fixed point. f must have a device copy and a start state.
-// Sweeps are launched in batches without returning to the host, and the NEXT batch is enqueued before the
-// host looks at the previous batch's flags (two batches in flight), so the device never idles on a host round
-// trip.  A sweep that changes nothing leaves an empty frontier: everything enqueued behind it is a ~3 us no-op.
-void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
+// The relaxation runs to its fixed point in sweeps launched in batches without returning to the host, and the NEXT
+// batch is enqueued before the host looks at the previous batch's flags (two batches in flight), so the device never
+// idles on a host round trip.  A sweep that changes nothing leaves an empty frontier: everything enqueued behind it is
+// a ~3 us no-op.
+// relax_setup allocates and initialises the state of a solve (keys, frontier flags, control block) and fixes its schedule parameters
+void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   const uint32_t n = f->n_states;
   DevicePool& pool = *ctx->pool;
   sv.key = DBuf<uint64_t>(pool, n);
@@ -474,21 +480,188 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   HIP_CHECK(hipMemsetAsync(sv.shadow.p, 0xFF, (size_t)n * sizeof(uint32_t), st));
   HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
   HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
-  uint8_t* fl[2] = {sv.flags.p, sv.flags.p + n_pad};
-
-  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
+  sv.fl[0] = sv.flags.p;
+  sv.fl[1] = sv.flags.p + n_pad;
+  sv.blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
   // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
   // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
   float delta = INF;
   if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) delta = 1.5f * f->mean_weight;
   if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
   if (!(delta > 0.0f)) delta = INF;
-  uint32_t near_low = 4096;  // activations below which a sweep is launch-latency bound anyway
-  if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) near_low = (uint32_t)std::atol(e);
+  sv.delta = delta;
+  sv.near_low = 4096;  // activations below which a sweep is launch-latency bound anyway
+  if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) sv.near_low = (uint32_t)std::atol(e);
   float tau0_mult = 1.0f;  // first band = tau0_mult x delta
   if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
-  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, fl[0], sv.ctl.p, (uint32_t)f->start, delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.shadow.p);
-  const uint64_t sweep_cap = 4ull * n + 64;
+  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, sv.fl[0], sv.ctl.p, (uint32_t)f->start,
+                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.shadow.p);
+  sv.sweep_cap = 4ull * n + 64;
+}
+
+// Queues the sweeps of a solve in batches and finds the sweep that changed nothing.  start() queues the first batch and
+// returns; finish() waits for it and continues until convergence (see the launch schedule in DESIGN.md §3.2).
+struct SweepBatch {
+  uint32_t first, count;
+  int which;
+};
+struct SweepDriver {
+  wfst_ctx* ctx = nullptr;
+  const wfst_fst* f = nullptr;
+  Solve* sv = nullptr;
+  uint32_t n = 0;
+  uint32_t* h_imp = nullptr;
+  bool use_graphs = false;
+  uint32_t next_sweep = 0, first_count = 8, sweeps_done = 0;
+  bool predicted = false;  // the first batch is expected to cover the whole solve: nothing is queued behind it
+  bool extended = false;   // more than the first batch was needed
+  hipEvent_t evs[2] = {nullptr, nullptr};
+  SweepBatch cur{};
+
+  void init(wfst_ctx* c, const wfst_fst* fst, Solve* s) {
+    ctx = c;
+    f = fst;
+    sv = s;
+    n = fst->n_states;
+    h_imp = (uint32_t*)ctx->pinned_flags.get(3 * IMP_RING * sizeof(uint32_t));
+    if (const char* e = std::getenv("WFST_SSSP_GRAPH")) use_graphs = std::atoi(e) != 0;
+    // A batch boundary costs ~14 us of idle GPU (profiles/r01d), so the FIRST batch of a solve is sized to what the
+    // previous solve of this FST needed (+1 sweep to see the quiet one, rounded up to a multiple of 4; batch sizes stay
+    // even because the flag parity of a sweep inside a batch is static).
+    const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 3) & ~3u);
+    predicted = last_sweeps != 0 && last_sweeps < first_count;
+    evs[0] = ctx->ev0;
+    evs[1] = ctx->ev1;
+  }
+
+  // One HIP graph = one batch (WFST_SSSP_GRAPH=1): `count` sweep kernels (static offsets from the device-side base) and the
+  // advance kernel, chained, built with explicit nodes — stream capture would make every other thread's
+  // hipStreamSynchronize fail while it is active.
+  hipGraphExec_t get_graph(int which, uint32_t count) {
+    wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
+    const uint32_t blocks = sv->blocks, near_low = sv->near_low;
+    const float delta = sv->delta;
+    const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn ^ ((uint64_t)count << 56), (uint64_t)sv->key.p,
+                             (uint64_t)sv->flags.p,
+                             (uint64_t)sv->improved.p ^ ((uint64_t)sv->shadow.p << 1), (uint64_t)sv->ctl.p,
+                             ((uint64_t)n << 32) | __float_as_uint_host(delta),
+                             (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
+    if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
+    if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
+    if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
+    g.exec = nullptr;
+    g.graph = nullptr;
+    HIP_CHECK(hipGraphCreate(&g.graph, 0));
+    hipGraphNode_t prev = nullptr;
+    const uint32_t* a_offsets = f->dev.offsets;
+    const uint2* a_wn = f->dev.wn;
+    uint64_t* a_key = sv->key.p;
+    uint32_t a_n = n;
+    uint32_t* a_imp = sv->improved.p;
+    Ctl* a_ctl = sv->ctl.p;
+    float a_delta = delta;
+    uint32_t a_low = near_low;
+    uint32_t* a_shadow = sv->shadow.p;
+    for (uint32_t j = 0; j < count; ++j) {
+      uint8_t* a_fc = sv->fl[j & 1u];
+      uint8_t* a_fn = sv->fl[(j & 1u) ^ 1u];
+      uint32_t a_off = j;
+      void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low, &a_shadow};
+      hipKernelNodeParams kp{};
+      kp.func = (void*)sssp_relax_kernel;
+      kp.gridDim = dim3(blocks);
+      kp.blockDim = dim3(256);
+      kp.sharedMemBytes = 0;
+      kp.kernelParams = args;
+      kp.extra = nullptr;
+      hipGraphNode_t node;
+      HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+      prev = node;
+    }
+    {
+      uint32_t a_count = count;
+      uint32_t* a_host = h_imp + which * IMP_RING;
+      void* args[] = {&a_ctl, &a_imp, &a_count, &a_host};
+      hipKernelNodeParams kp{};
+      kp.func = (void*)sssp_advance_kernel;
+      kp.gridDim = dim3(1);
+      kp.blockDim = dim3(64);
+      kp.kernelParams = args;
+      hipGraphNode_t node;
+      HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, &prev, 1, &kp));
+    }
+    HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    std::memcpy(g.key, key, sizeof(key));
+    return g.exec;
+  }
+
+  SweepBatch enqueue_batch(hipEvent_t ev) {
+    hipStream_t st = ctx->stream;
+    // after the first batch: constant small batches while the solve is shallow, larger ones for deep lattices
+    SweepBatch b{next_sweep, 8u, 1};
+    if (next_sweep == 0) b = SweepBatch{0u, first_count, 0};
+    else if (next_sweep >= 64) b = SweepBatch{next_sweep, MAX_BATCH, 2};
+    if (use_graphs) {
+      HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
+    } else {
+      // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
+      // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
+      for (uint32_t j = 0; j < b.count; ++j)
+        sssp_relax_kernel<<<sv->blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv->key.p, sv->fl[j & 1u], sv->fl[(j & 1u) ^ 1u],
+                                                      n, sv->improved.p, sv->ctl.p, j, sv->delta, sv->near_low, sv->shadow.p);
+      sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipEventRecord(ev, st));
+    next_sweep += b.count;
+    return b;
+  }
+
+  bool scan_flags(const SweepBatch& b) {  // true when a sweep of the batch changed nothing
+    const uint32_t* hf = h_imp + b.which * IMP_RING;
+    for (uint32_t k = 0; k < b.count; ++k) {
+      sweeps_done = b.first + k + 1;
+      if (!hf[(b.first + k) % IMP_RING]) return true;
+    }
+    return false;
+  }
+
+  void start() { cur = enqueue_batch(evs[0]); }
+
+  void finish() {
+    int which = 0;
+    bool done = false;
+    if (predicted) {  // expected to finish inside the first batch: no idle sweeps were queued behind it
+      HIP_CHECK(hipEventSynchronize(evs[0]));
+      done = scan_flags(cur);
+      if (!done) {
+        extended = true;
+        cur = enqueue_batch(evs[0]);
+      }
+    }
+    while (!done) {
+      if (next_sweep > sv->sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
+      // keep the device busy while the host inspects `cur`: the next batch is enqueued first
+      const SweepBatch nxt = enqueue_batch(evs[which ^ 1]);
+      extended = true;
+      HIP_CHECK(hipEventSynchronize(evs[which]));
+      done = scan_flags(cur);
+      cur = nxt;
+      which ^= 1;
+    }
+  }
+};
+
+// Runs the relaxation to its fixed point. f must have a device copy and a start state.
+void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
+  relax_setup(ctx, f, sv);
+  const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
+  uint8_t* const* fl = sv.fl;
+  const uint32_t blocks = sv.blocks, near_low = sv.near_low;
+  const float delta = sv.delta;
+  const uint64_t sweep_cap = sv.sweep_cap;
   ctx->stats.sweeps = 0;
 
   uint32_t sweeps_done = 0;
@@ -524,130 +697,11 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     ctx->stats.relax_arcs += h_ctl->arcs;
     ctx->stats.relax_states += h_ctl->states;
   } else {
-    // One HIP graph = one batch: `count` sweep kernels (static offsets 0..count-1 from the device-side base), the
-    // copy of the flag ring to pinned host memory and the advance kernel, chained.  A replay is ONE host call
-    // instead of count+2, which matters twice: a sweep on a small frontier (~4 us) is shorter than a launch, and
-    // the host thread of another context (bench.py overlaps the batch pipeline on a second stream) is not starved
-    // of the runtime.  The graph is built with explicit nodes — stream capture would make every other thread's
-    // hipStreamSynchronize fail while it is active.  Two replays are kept in flight.
-    uint32_t* h_imp = (uint32_t*)ctx->pinned_flags.get(3 * IMP_RING * sizeof(uint32_t));
-    auto get_graph = [&](int which, uint32_t count) -> hipGraphExec_t {
-      wfst_ctx::SweepGraph& g = ctx->sweep_graph[which];
-      const uint64_t key[8] = {(uint64_t)f->dev.offsets, (uint64_t)f->dev.wn ^ ((uint64_t)count << 56), (uint64_t)sv.key.p,
-                               (uint64_t)sv.flags.p,
-                               (uint64_t)sv.improved.p ^ ((uint64_t)sv.shadow.p << 1), (uint64_t)sv.ctl.p,
-                               ((uint64_t)n << 32) | __float_as_uint_host(delta),
-                               (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
-      if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
-      if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
-      if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
-      g.exec = nullptr;
-      g.graph = nullptr;
-      HIP_CHECK(hipGraphCreate(&g.graph, 0));
-      hipGraphNode_t prev = nullptr;
-      const uint32_t* a_offsets = f->dev.offsets;
-      const uint2* a_wn = f->dev.wn;
-      uint64_t* a_key = sv.key.p;
-      uint32_t a_n = n;
-      uint32_t* a_imp = sv.improved.p;
-      Ctl* a_ctl = sv.ctl.p;
-      float a_delta = delta;
-      uint32_t a_low = near_low;
-      uint32_t* a_shadow = sv.shadow.p;
-      for (uint32_t j = 0; j < count; ++j) {  // batches start at multiples of their size: flag parity is static
-        uint8_t* a_fc = fl[j & 1u];
-        uint8_t* a_fn = fl[(j & 1u) ^ 1u];
-        uint32_t a_off = j;
-        void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low, &a_shadow};
-        hipKernelNodeParams kp{};
-        kp.func = (void*)sssp_relax_kernel;
-        kp.gridDim = dim3(blocks);
-        kp.blockDim = dim3(256);
-        kp.sharedMemBytes = 0;
-        kp.kernelParams = args;
-        kp.extra = nullptr;
-        hipGraphNode_t node;
-        HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
-        prev = node;
-      }
-      {
-        uint32_t a_count = count;
-        uint32_t* a_host = h_imp + which * IMP_RING;
-        void* args[] = {&a_ctl, &a_imp, &a_count, &a_host};
-        hipKernelNodeParams kp{};
-        kp.func = (void*)sssp_advance_kernel;
-        kp.gridDim = dim3(1);
-        kp.blockDim = dim3(64);
-        kp.kernelParams = args;
-        hipGraphNode_t node;
-        HIP_CHECK(hipGraphAddKernelNode(&node, g.graph, &prev, 1, &kp));
-      }
-      HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-      std::memcpy(g.key, key, sizeof(key));
-      return g.exec;
-    };
-    struct Batch {
-      uint32_t first, count;
-      int which;
-    };
-    bool use_graphs = false;
-    if (const char* e = std::getenv("WFST_SSSP_GRAPH")) use_graphs = std::atoi(e) != 0;
-    uint32_t next_sweep = 0;
-    // A replay boundary costs ~14 us of idle GPU (measured: profiles/r01d) and the first replay ~34 us, so the FIRST
-    // batch of a solve is sized to what the previous solve of this FST needed (+1 sweep to see the quiet one, rounded
-    // up to a multiple of 4; batch sizes stay even because the flag parity of a graph node is static).
-    uint32_t first_count = 8;
-    const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 3) & ~3u);
-    const bool predicted = last_sweeps != 0 && last_sweeps < first_count;
-    auto enqueue_batch = [&](hipEvent_t ev) {
-      // after the first batch: constant small batches while the solve is shallow, larger ones for deep lattices
-      Batch b{next_sweep, 8u, 1};
-      if (next_sweep == 0) b = Batch{0u, first_count, 0};
-      else if (next_sweep >= 64) b = Batch{next_sweep, MAX_BATCH, 2};
-      if (use_graphs) {
-        HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
-      } else {
-        // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
-        // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
-        for (uint32_t j = 0; j < b.count; ++j)
-          sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[j & 1u], fl[(j & 1u) ^ 1u], n,
-                                                    sv.improved.p, sv.ctl.p, j, delta, near_low, sv.shadow.p);
-        sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, b.count, h_imp + b.which * IMP_RING);
-        HIP_CHECK(hipGetLastError());
-      }
-      HIP_CHECK(hipEventRecord(ev, st));
-      next_sweep += b.count;
-      return b;
-    };
-    auto scan_flags = [&](const Batch& b) {  // true when a sweep of the batch changed nothing
-      const uint32_t* hf = h_imp + b.which * IMP_RING;
-      for (uint32_t k = 0; k < b.count; ++k) {
-        sweeps_done = b.first + k + 1;
-        if (!hf[(b.first + k) % IMP_RING]) return true;
-      }
-      return false;
-    };
-    hipEvent_t evs[2] = {ctx->ev0, ctx->ev1};
-    Batch cur = enqueue_batch(evs[0]);
-    int which = 0;
-    bool done = false;
-    if (predicted) {  // expected to finish inside this batch: do not queue idle sweeps behind it
-      HIP_CHECK(hipEventSynchronize(evs[0]));
-      done = scan_flags(cur);
-      if (!done) {
-        cur = enqueue_batch(evs[0]);
-      }
-    }
-    while (!done) {
-      if (next_sweep > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
-      // keep the device busy while the host inspects `cur`: the next batch is enqueued first.
-      const Batch nxt = enqueue_batch(evs[which ^ 1]);
-      HIP_CHECK(hipEventSynchronize(evs[which]));
-      done = scan_flags(cur);
-      cur = nxt;
-      which ^= 1;
-    }
+    SweepDriver drv;
+    drv.init(ctx, f, &sv);
+    drv.start();
+    drv.finish();
+    sweeps_done = drv.sweeps_done;
   }
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
@@ -731,30 +785,98 @@ const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
   return r.get();
 }
 
-wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
+}  // namespace wfst
+
+// One single-shortest-path solve split in two halves: begin queues the set-up, the first batch of sweeps and (when the
+// solve is predicted to fit in that batch and the transpose is cached) the final-state search, the backtrace and the
+// read-back of the path behind it, then returns; end waits, continues the sweeps if the prediction was short, and
+// builds the output FST.  The synchronous shortest_path(nshortest = 1) is begin followed by end.
+struct wfst_sp_job {
+  wfst_ctx* ctx = nullptr;
+  const wfst_fst* f = nullptr;
+  bool trivial = false;      // no start state: the result is the empty FST (shortest_path.rs:185-187)
+  bool tail_queued = false;  // final / header / backtrace / read-back already queued behind the first batch
+  wfst::Solve sv;
+  wfst::SweepDriver drv;
+  const wfst::RevCsr* rev = nullptr;
+  wfst::Ctl* hc = nullptr;
+  wfst_tr* h_path = nullptr;
+};
+
+namespace wfst {
+namespace {
+constexpr uint32_t PATH_PINNED = 4096;  // arcs of the path written straight into pinned memory by the backtrace
+
+void queue_tail(wfst_sp_job* j) {
+  wfst_ctx* ctx = j->ctx;
+  const wfst_fst* f = j->f;
   const uint32_t n = f->n_states;
-  if (f->start < 0 || n == 0) return build_path_fst(ctx, false, 0, INF, nullptr);  // shortest_path.rs:185-187
-  ensure_device(const_cast<wfst_fst*>(f));
   hipStream_t st = ctx->stream;
-  Solve sv;
-  run_relaxation(ctx, f, sv);
+  Solve& sv = j->sv;
   sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p,
                                                                                                           n, sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
-  constexpr uint32_t PATH_PINNED = 4096;  // arcs of the path written straight into pinned memory by the backtrace
+  if (j->rev)
+    sssp_backtrace_rev_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, f->dev.wn, sv.key.p, j->rev->off.p,
+                                                j->rev->arc.p, sv.ctl.p, j->h_path, PATH_PINNED);
+  HIP_CHECK(hipMemcpyAsync(j->hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+}
+}  // namespace
+
+wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
+  std::unique_ptr<wfst_sp_job> j(new wfst_sp_job());
+  j->ctx = ctx;
+  j->f = f;
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) {
+    j->trivial = true;
+    return j.release();
+  }
+  ensure_device(const_cast<wfst_fst*>(f));
   char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 64 + PATH_PINNED * sizeof(wfst_tr));
-  Ctl* hc = (Ctl*)pin;
-  wfst_tr* h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
-  const RevCsr* rev = reverse_csr(ctx, f);
-  if (rev)
-    sssp_backtrace_rev_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, f->dev.wn, sv.key.p, rev->off.p, rev->arc.p,
-                                                sv.ctl.p, h_path, PATH_PINNED);
-  HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+  j->hc = (Ctl*)pin;
+  j->h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
+  j->rev = reverse_csr(ctx, f);  // may build the transpose (second query of a large FST): before anything is queued
+  if (ctx->profiling) {
+    run_relaxation(ctx, f, j->sv);  // per-sweep events: synchronous
+    return j.release();
+  }
+  relax_setup(ctx, f, j->sv);
+  ctx->stats.sweeps = 0;
+  j->drv.init(ctx, f, &j->sv);
+  j->drv.start();
+  if (j->drv.predicted && j->rev) {
+    queue_tail(j.get());
+    j->tail_queued = true;
+  }
+  return j.release();
+}
+
+wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
+  std::unique_ptr<wfst_sp_job> j(job);
+  wfst_ctx* ctx = j->ctx;
+  const wfst_fst* f = j->f;
+  if (j->trivial) return build_path_fst(ctx, false, 0, INF, nullptr);
+  const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
+  Solve& sv = j->sv;
+  if (!ctx->profiling) {
+    j->drv.finish();
+    sv.sweeps = j->drv.sweeps_done;
+    ctx->stats.sweeps = sv.sweeps;
+    f->last_sweeps.store(sv.sweeps, std::memory_order_relaxed);
+  }
+  if (j->tail_queued && j->drv.extended) {  // the speculative tail ran on unfinished distances: once more
+    HIP_CHECK(hipMemsetAsync(&sv.ctl.p->best, 0xFF, sizeof(unsigned long long), st));
+    j->tail_queued = false;
+  }
+  if (!j->tail_queued) queue_tail(j.get());
   HIP_CHECK(hipStreamSynchronize(st));
+  const Ctl* hc = j->hc;
   if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
   const uint32_t hops = hc->hops;
   const float final_weight = hc->final_weight;
-  if (rev && hops <= PATH_PINNED) return build_path_fst(ctx, true, hops, final_weight, h_path);
+  if (j->rev && hops <= PATH_PINNED) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
   std::vector<wfst_tr> path(hops);
   if (hops) {
     DBuf<unsigned long long> parent(*ctx->pool, n);
@@ -768,5 +890,14 @@ wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
   }
   return build_path_fst(ctx, true, hops, final_weight, path.data());
 }
+
+void shortest_path_n1_abandon(wfst_sp_job* job) {
+  std::unique_ptr<wfst_sp_job> j(job);
+  if (!j->trivial) (void)hipStreamSynchronize(j->ctx->stream);  // the solve's buffers go back to the pool after this
+}
+
+wfst_ctx* sp_job_ctx(wfst_sp_job* job) { return job->ctx; }
+
+wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) { return shortest_path_n1_end(shortest_path_n1_begin(ctx, f)); }
 
 }  // namespace wfst

@@ -249,6 +249,14 @@ class DeviceFst:
         check(_lib.lib().wfst_shortest_path(self.ctx._h, self._h, cfg, C.byref(out)), "Error computing shortest path")
         return DeviceFst(out, self.ctx)
 
+    def shortest_path_begin(self, config: Optional["ShortestPathConfig"] = None) -> "ShortestPathJob":
+        """Queue shortest_path (nshortest = 1) on this FST's context and return at once
+        (wfst_shortest_path_begin); job.finish() returns what shortest_path() returns."""
+        job = C.c_void_p()
+        cfg = config._c() if config is not None else None
+        check(_lib.lib().wfst_shortest_path_begin(self.ctx._h, self._h, cfg, C.byref(job)), "Error computing shortest path")
+        return ShortestPathJob(job, self)
+
     def reverse(self) -> "DeviceFst":
         """algorithms::reverse (reverse.rs:33-87): new FST with a super-initial state 0."""
         out = C.c_void_p()
@@ -311,6 +319,27 @@ class PathList(Sequence):
             except Exception:
                 pass
             self._arr = None
+
+
+class ShortestPathJob:
+    """A single-shortest-path solve in flight (wfst_shortest_path_begin); finish() = wfst_shortest_path_end."""
+
+    def __init__(self, job, fst):
+        self._job, self._fst = job, fst  # the input FST must outlive the job
+
+    def finish(self) -> "DeviceFst":
+        if self._job is None:
+            raise WfstError("shortest_path job already finished")
+        out = C.c_void_p()
+        job, self._job = self._job, None
+        check(_lib.lib().wfst_shortest_path_end(job, C.byref(out)), "Error computing shortest path")
+        fst, self._fst = self._fst, None
+        return DeviceFst(out, fst.ctx)
+
+    def __del__(self):
+        if getattr(self, "_job", None) is not None:  # abandoned: wait for the kernels and free the job
+            _lib.lib().wfst_shortest_path_end(self._job, None)
+            self._job = None
 
 
 class BatchJob:

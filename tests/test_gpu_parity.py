@@ -652,6 +652,54 @@ def test_shortest_path_repeated_queries_use_transpose(gpu_ctx, oracle, seed):
         assert_flat_identical(d.shortest_path().to_flat(), ref2, f"after tr_sort, query {q}")
 
 
+def test_async_shortest_path_matches_sync(gpu_ctx, oracle, monkeypatch):
+    """wfst_shortest_path_begin/_end: same FST as the synchronous call and the oracle — on the first queries (no
+    prediction, no transpose), on predicted ones (final search + backtrace queued speculatively behind the sweeps),
+    and when the prediction falls short (the schedule is changed between queries so that the solve needs more
+    sweeps than the previous one: the speculative tail must be redone)."""
+    t = synth.make_transducer(60000, 8, 64, 0.0, seed=77)
+    assert t["offsets"][-1] >= 1 << 18
+    d = to_device(t)
+    ref = to_oracle(oracle, t).shortest_path_canonical().to_flat()
+    monkeypatch.setenv("WFST_SSSP_DELTA", "0")  # plain frontier sweeps: the fewest sweeps
+    few = []
+    for q in range(4):
+        job = d.shortest_path_begin()
+        with pytest.raises(rustfst_amd.WfstError, match="in flight"):
+            d.shortest_path_begin()
+        assert_flat_identical(job.finish().to_flat(), ref, f"async query {q}")
+        few.append(gpu_ctx.stats()["sweeps"])
+        with pytest.raises(rustfst_amd.WfstError):
+            job.finish()
+    monkeypatch.setenv("WFST_SSSP_DELTA", "0.5")  # narrow bands: many more sweeps than predicted
+    job = d.shortest_path_begin()
+    assert_flat_identical(job.finish().to_flat(), ref, "async query after the schedule change")
+    many = gpu_ctx.stats()["sweeps"]
+    assert many > few[-1] + 4, (few, many)
+    assert_flat_identical(d.shortest_path_begin().finish().to_flat(), ref, "async query, long prediction")
+    monkeypatch.setenv("WFST_SSSP_DELTA", "0")  # and back: the prediction is now too long, which is harmless
+    assert_flat_identical(d.shortest_path_begin().finish().to_flat(), ref, "async query, prediction too long")
+    assert_flat_identical(d.shortest_path().to_flat(), ref, "sync after async")
+    del d.shortest_path_begin()._fst  # abandoned job is reclaimed
+    assert_flat_identical(d.shortest_path().to_flat(), ref, "sync after an abandoned job")
+    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
+        d.shortest_path_begin(ShortestPathConfig(nshortest=2))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_async_shortest_path_small_and_degenerate(gpu_ctx, oracle, seed):
+    """begin/end on small FSTs (no transpose: the tail is queued by _end), FSTs without start / without a path."""
+    rng = np.random.default_rng(8800 + seed)
+    f = random_fst_flat(rng, int(rng.integers(2, 60)), 4, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2 if seed else 0.0)
+    d = to_device(f)
+    ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
+    for q in range(3):
+        assert_flat_identical(d.shortest_path_begin().finish().to_flat(), ref, f"small async {q}")
+    empty = rustfst_amd.VectorFst()
+    out = empty.to_device().shortest_path_begin().finish()
+    assert out.num_states == 0
+
+
 # ------------------------------------------------------------------ §8(f) N4: the other ComposeFilterEnum values
 FILTERS = [ComposeFilter.NULLFILTER, ComposeFilter.TRIVIALFILTER, ComposeFilter.SEQUENCEFILTER,
            ComposeFilter.ALTSEQUENCEFILTER, ComposeFilter.MATCHFILTER, ComposeFilter.NOMATCHFILTER]
