@@ -13,6 +13,7 @@
 // No MFMA: this is sparse DP; the bound is HBM / L2-atomic traffic (20 B per arc relaxed by the
 // SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
@@ -54,6 +55,8 @@ constexpr uint32_t RING = 256;
 constexpr uint32_t NEAR_SHARDS = 16;
 constexpr uint32_t NEAR_RING = 4;     // sweep k writes slot k % 4, reads k-1 and k-2, recycles k+1
 constexpr uint32_t NEAR_STRIDE = 32;  // one shard per 128-B line: atomics on one LINE serialise like one address
+constexpr uint32_t PROF_STRIDE = 16;  // u64 counters: one shard per 128-B line
+constexpr uint32_t PROF_SHARDS = 64;
 constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, indexed by sweep % IMP_RING
 
 struct Ctl {
@@ -63,8 +66,9 @@ struct Ctl {
   // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
   uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
   uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
-  unsigned long long arcs;    // arcs leaving the current frontier (profiling only)
-  unsigned long long states;  // frontier states (profiling only)
+  // arcs / states relaxed so far (profiling only): sharded like `near`, shard j at [j * PROF_STRIDE]
+  unsigned long long arcs[PROF_SHARDS * PROF_STRIDE];
+  unsigned long long states[PROF_SHARDS * PROF_STRIDE];
   unsigned long long best;    // enc(total) << 32 | final state
   // backtrace header
   uint32_t f_parent, hops;
@@ -76,8 +80,9 @@ struct Ctl {
 // Called by one full wave (all 64 lanes): lanes 0..15 fetch the shards of sweep-1's counter, lanes 16..31 those of
 // sweep-2's, so the whole decision costs one load latency.
 __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
-                                           uint32_t* streak) {
+                                           uint32_t* streak, uint32_t* prev_near) {
   *streak = 0;
+  *prev_near = 0;
   if (sweep == 0) return ctl->tau0;
   const uint32_t p = (sweep - 1) % RING;
   const uint32_t lane = threadIdx.x & 63u;
@@ -88,6 +93,7 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
   const uint32_t prev_streak = ctl->streak[p];
   for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
   const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
+  *prev_near = cnt;
   if (cnt >= near_low) return prev;
   // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
   // widen the band by delta and keep relaxing
@@ -97,22 +103,26 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
   return prev + delta * (float)(1u << (st - 1u));
 }
 
-__global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint32_t start, float tau0, uint32_t* shadow) {
-  key[start] = (uint64_t)enc_f32(0.0f) << 32;  // d[source] = 1-bar, hops 0   (shortest_path.rs:204)
-  shadow[start] = enc_f32(0.0f);
-  flags0[start] = 1;
-  for (uint32_t i = threadIdx.x; i < RING; i += blockDim.x) {
-    ctl->tau[i] = 0;
-    ctl->streak[i] = 0;
+// Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
+// +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
+// flag in buffer 0, the activity ring and the control block zeroed.
+__global__ void __launch_bounds__(256) sssp_setup_kernel(uint64_t* __restrict__ key, uint32_t* __restrict__ shadow,
+                                                         uint32_t* __restrict__ flag_words, uint32_t n_flag_words,
+                                                         uint32_t* __restrict__ improved, Ctl* __restrict__ ctl, uint32_t n,
+                                                         uint32_t start, float tau0) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (uint32_t i = tid; i < n; i += nt) {
+    const bool is_start = i == start;
+    key[i] = is_start ? (uint64_t)enc_f32(0.0f) << 32 : KEY_INF;
+    shadow[i] = is_start ? enc_f32(0.0f) : 0xFFFFFFFFu;
   }
-  for (uint32_t i = threadIdx.x; i < NEAR_RING * NEAR_SHARDS * NEAR_STRIDE; i += blockDim.x) (&ctl->near[0][0])[i] = 0;
-  if (threadIdx.x) return;
-  ctl->base = 0;
-  ctl->tau0 = tau0;
-  ctl->arcs = 0;
-  ctl->states = 0;
-  ctl->best = KEY_INF;
-  ctl->has_path = 0;
+  for (uint32_t i = tid; i < n_flag_words; i += nt) flag_words[i] = i == (start >> 2) ? 1u << (8u * (start & 3u)) : 0u;
+  for (uint32_t i = tid; i < IMP_RING; i += nt) improved[i] = 0;
+  // control block: rings, counters and header zero, except the first threshold and the best-final key (+inf)
+  uint32_t* cw = (uint32_t*)ctl;
+  constexpr uint32_t W_TAU0 = offsetof(Ctl, tau0) / 4, W_BEST = offsetof(Ctl, best) / 4;
+  for (uint32_t i = tid; i < (uint32_t)(sizeof(Ctl) / 4); i += nt)
+    cw[i] = i == W_TAU0 ? __float_as_uint(tau0) : (i == W_BEST || i == W_BEST + 1) ? 0xFFFFFFFFu : 0u;
 }
 
 // One sweep: relax every arc leaving the current frontier.
@@ -120,24 +130,44 @@ __global__ void sssp_init_kernel(uint64_t* key, uint8_t* flags0, Ctl* ctl, uint3
 // scans 64 flags with one coalesced load + ballot, then GROUP lanes share each active state so its arcs
 // (contiguous 8-B {w,next} records) are read by consecutive lanes.  The only atomic is the atomicMin of
 // relaxations that pass the plain pre-check.
+//
+// Chasing: a relaxation that improves a target to a NEAR distance does not flag it for the next sweep but puts it on a
+// small list private to the wave (LDS); after its flagged states the wave relaxes the listed ones too, for up to
+// `chase_rounds` states per launch (narrow frontiers are followed deep, growing ones are cut off), spilling to the flags whatever does not fit (`chase_cap` entries) or is left over — in sweeps
+// that follow one with fewer than `chase_low` near activations only.  A sweep
+// costs a launch plus a chain of dependent memory trips (~7 us) however small its frontier is, and half of the sweeps
+// of a solve are that small (the head and the tail of every band): chasing walks several levels of such a frontier
+// inside one launch, at one chain (~2.5 us) per level.  The fixed point does not depend on the order of relaxations,
+// so results are unchanged; an entry whose key has been improved again since it was listed is dropped (the improver
+// listed or flagged the state itself).
+constexpr uint32_t CHASE_MAX = 128;  // list entries per wave (ring)
+constexpr uint32_t CHASE_OWN_MAX = 4;
+
 __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restrict__ offsets,
                                                          const uint2* __restrict__ wn, uint64_t* __restrict__ key,
                                                          uint8_t* __restrict__ flags_cur,
                                                          uint8_t* __restrict__ flags_next, uint32_t n,
                                                          uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
                                                          uint32_t sweep_offset, float delta, uint32_t near_low,
-                                                         uint32_t* __restrict__ shadow) {
+                                                         uint32_t* __restrict__ shadow, uint32_t chase_cap,
+                                                         uint32_t chase_rounds, uint32_t chase_low, uint32_t profile) {
   // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
   const uint32_t sweep = ctl->base + sweep_offset;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
   __shared__ uint32_t s_any;   // some activity (improvement or deferral) in this workgroup
   __shared__ uint32_t s_near;  // near activations of this workgroup
   __shared__ float s_tau;
+  __shared__ unsigned long long s_prof[2];  // arcs, states relaxed by this workgroup (profiling)
+  __shared__ uint32_t s_small;             // the previous sweep left fewer than chase_low near activations
+  __shared__ uint2 s_chase[4][CHASE_MAX];  // {state, enc(d) it was listed with}
   const uint32_t slot = sweep % RING;
   if (threadIdx.x < 64) {
-    uint32_t streak;
-    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak);
+    uint32_t streak, prev_near;
+    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak, &prev_near);
     if (threadIdx.x == 0) {
+      s_small = prev_near < chase_low ? 1u : 0u;
+      s_prof[0] = 0;
+      s_prof[1] = 0;
       s_tau = t0;
       s_any = 0;
       s_near = 0;
@@ -152,31 +182,53 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   }
   __syncthreads();
   const float tau = s_tau;
+  // only sweeps that follow a small one chase (a big sweep is not bound by its launch, and relaxing a state the moment
+  // it is first improved, before the rest of the sweep's candidates for it have arrived, costs re-relaxations)
+  if (!s_small) chase_cap = 0;
+  uint32_t own_states = 0;  // flagged near states this wave relaxed itself
   uint32_t near_cnt = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = lane % GROUP;         // lane inside its group
   const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  uint2* const chase = s_chase[threadIdx.x >> 6];
+  uint32_t c_head = 0, c_tail = 0;  // wave-uniform ring positions (monotone; slot = position % CHASE_MAX)
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  unsigned long long p_arcs = 0, p_states = 0;
   bool any = false;
-  for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
-    const uint32_t sc = base + lane;
-    bool act = sc < n && flags_cur[sc] != 0;
-    if (__ballot(act) == 0) continue;
-    // the lane that owns an active state fetches everything the relaxation of that state needs: ONE memory
-    // round trip for the whole 64-state chunk; the groups below get it by shuffle
-    uint64_t my_ks = 0;
-    uint32_t my_b = 0, my_e = 0;
-    if (act) {
-      flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
-      my_ks = key[sc];
-      my_b = offsets[sc];
-      my_e = offsets[sc + 1];
-      if (dec_f32((uint32_t)(my_ks >> 32)) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
-        flags_next[sc] = 1;
-        any = true;
-        act = false;
+
+  // the target of a successful relaxation: listed if it is near and there is room, flagged otherwise
+  auto activate = [&](bool won, uint32_t t, uint32_t enc_d, float d) {
+    const bool near = won && d <= tau;
+    if (won) shadow[t] = enc_d;
+    bool flag = won && !near;
+    if (chase_cap) {
+      const uint64_t bm = __ballot(near);
+      if (bm) {
+        const uint32_t room = chase_cap - (c_tail - c_head);
+        const uint32_t rank = (uint32_t)__popcll(bm & lanes_below);
+        if (near) {
+          if (rank < room) chase[(c_tail + rank) % CHASE_MAX] = make_uint2(t, enc_d);
+          else flag = true;
+        }
+        c_tail += min(room, (uint32_t)__popcll(bm));
       }
+    } else {
+      flag = won;
+    }
+    if (flag) {
+      flags_next[t] = 1;
+      any = true;
+      near_cnt += near ? 1u : 0u;
+    }
+  };
+
+  // relaxes the arcs of up to 64 states: lane i owns state i of the chunk (act, its key, its arc range)
+  auto relax_chunk = [&](bool act, uint64_t my_ks, uint32_t my_b, uint32_t my_e) {
+    if (profile && act) {
+      p_states += 1;
+      p_arcs += my_e - my_b;
     }
     uint64_t mask = __ballot(act);
     while (mask) {
@@ -221,22 +273,64 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
         uint64_t olda = 0, oldb = 0;
         if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
         if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
-        if (ta && cka < olda) {
-          shadow[aa.y] = eca;
-          flags_next[aa.y] = 1;
-          any = true;
-          near_cnt += ca <= tau ? 1u : 0u;
-        }
-        if (tb && ckb < oldb) {
-          shadow[ab.y] = ecb;
-          flags_next[ab.y] = 1;
-          any = true;
-          near_cnt += cb <= tau ? 1u : 0u;
-        }
+        activate(ta && cka < olda, aa.y, eca, ca);
+        activate(tb && ckb < oldb, ab.y, ecb, cb);
         ia += GROUP;
         ib += GROUP;
       }
     }
+  };
+
+  for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
+    const uint32_t sc = base + lane;
+    bool act = sc < n && flags_cur[sc] != 0;
+    if (__ballot(act) == 0) continue;
+    // the lane that owns an active state fetches everything the relaxation of that state needs: ONE memory
+    // round trip for the whole 64-state chunk; the groups get it by shuffle
+    uint64_t my_ks = 0;
+    uint32_t my_b = 0, my_e = 0;
+    if (act) {
+      flags_cur[sc] = 0;  // this buffer is the NEXT frontier two sweeps from now
+      my_ks = key[sc];
+      my_b = offsets[sc];
+      my_e = offsets[sc + 1];
+      if (dec_f32((uint32_t)(my_ks >> 32)) > tau) {  // far: stays in the frontier, is not relaxed in this sweep
+        flags_next[sc] = 1;
+        any = true;
+        act = false;
+      }
+    }
+    own_states += (uint32_t)__popcll(__ballot(act));
+    relax_chunk(act, my_ks, my_b, my_e);
+  }
+  // a wave that had a real share of a big frontier (the band was widened) leaves its discoveries to the next sweep
+  if (own_states > CHASE_OWN_MAX) chase_rounds = 0;
+  // the wave's own discoveries (wave-synchronous: the list is private to the wave, LDS accesses of one wave are ordered)
+  for (uint32_t chased = 0; c_tail != c_head;) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t take = min(64u, c_tail - c_head);
+    uint2 e = make_uint2(0u, 0u);
+    if (lane < take) e = chase[(c_head + lane) % CHASE_MAX];
+    c_head += take;
+    if (chased >= chase_rounds) {  // budget spent: what is left goes to the next sweep
+      if (lane < take) {
+        flags_next[e.x] = 1;
+        any = true;
+        near_cnt += 1;
+      }
+      continue;
+    }
+    chased += take;
+    bool act = lane < take;
+    uint64_t my_ks = 0;
+    uint32_t my_b = 0, my_e = 0;
+    if (act) {
+      my_ks = key[e.x];
+      my_b = offsets[e.x];
+      my_e = offsets[e.x + 1];
+      act = (uint32_t)(my_ks >> 32) == e.y;  // improved again since: whoever did that listed or flagged it
+    }
+    relax_chunk(act, my_ks, my_b, my_e);
   }
   // one conditional plain store + one sharded atomicAdd per workgroup (thousands of same-address atomics per
   // sweep would serialise at ~12 ns each)
@@ -246,11 +340,32 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
     if (wave_any) s_any = 1u;
     if (near_cnt) atomicAdd(&s_near, near_cnt);
   }
+  if (profile) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      p_arcs += __shfl_xor(p_arcs, d);
+      p_states += __shfl_xor(p_states, d);
+    }
+    if (lane == 0 && p_states) {
+      atomicAdd(&s_prof[0], p_arcs);
+      atomicAdd(&s_prof[1], p_states);
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (s_any && *improved == 0u) *improved = 1u;
     if (s_near) atomicAdd(&ctl->near[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_near);
+    if (profile && s_prof[1]) {
+      atomicAdd(&ctl->arcs[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[0]);
+      atomicAdd(&ctl->states[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[1]);
+    }
   }
+}
+
+// profiling helper: keeps the GPU busy right before the event that opens a timed sweep, as the previous sweep does in an
+// un-profiled solve (a launch into an idle GPU takes ~3 us longer)
+__global__ void sssp_nop_kernel(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* sink) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i] == 0xFF) *sink = i;  // flags are 0 / 1: never true
 }
 
 // closes a batch: the next replay continues at base + count, and the flag slots half a ring ahead are recycled
@@ -263,29 +378,6 @@ __global__ void sssp_advance_kernel(Ctl* ctl, uint32_t* improved_ring, uint32_t 
   }
   __syncthreads();
   if (threadIdx.x == 0) ctl->base = base + count;
-}
-
-// profiling helper (runs outside the timed events): size of the current frontier and of its arc set
-__global__ void sssp_count_kernel(const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ flags,
-                                  const uint64_t* __restrict__ key, uint32_t n, Ctl* __restrict__ ctl, uint32_t sweep,
-                                  float delta, uint32_t near_low) {
-  uint32_t streak_unused;
-  const float tau = sweep_tau(ctl, sweep, delta, near_low, &streak_unused);
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long arcs = 0, states = 0;
-  for (; s < n; s += gridDim.x * blockDim.x)
-    if (flags[s] && dec_f32((uint32_t)(key[s] >> 32)) <= tau) {
-      arcs += offsets[s + 1] - offsets[s];
-      states += 1;
-    }
-  for (int d = 32; d >= 1; d >>= 1) {
-    arcs += __shfl_xor(arcs, d);
-    states += __shfl_xor(states, d);
-  }
-  if ((threadIdx.x & 63) == 0 && states) {
-    atomicAdd(&ctl->arcs, arcs);
-    atomicAdd(&ctl->states, states);
-  }
 }
 
 // f_parent = argmin over final states of (d[s] (x) rho(s), s)      (shortest_path.rs:214-220)
@@ -457,6 +549,8 @@ struct Solve {
   uint32_t blocks = 1, near_low = 4096;
   float delta = 0.0f;
   uint64_t sweep_cap = 0;
+  // per-wave list of near discoveries relaxed inside the same launch, in sweeps that follow a small (< chase_low) one
+  uint32_t chase_cap = 32, chase_rounds = 8, chase_low = 4096;  // chase_rounds = states a wave may chase per launch
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -476,10 +570,6 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   sv.improved = DBuf<uint32_t>(pool, IMP_RING);
   sv.ctl = DBuf<Ctl>(pool, 1);
   hipStream_t st = ctx->stream;
-  HIP_CHECK(hipMemsetAsync(sv.key.p, 0xFF, (size_t)n * sizeof(uint64_t), st));
-  HIP_CHECK(hipMemsetAsync(sv.shadow.p, 0xFF, (size_t)n * sizeof(uint32_t), st));
-  HIP_CHECK(hipMemsetAsync(sv.flags.p, 0, 2 * n_pad, st));
-  HIP_CHECK(hipMemsetAsync(sv.improved.p, 0, IMP_RING * sizeof(uint32_t), st));
   sv.fl[0] = sv.flags.p;
   sv.fl[1] = sv.flags.p + n_pad;
   sv.blocks = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (n + 255) / 256));
@@ -494,9 +584,15 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (const char* e = std::getenv("WFST_SSSP_NEAR_LOW")) sv.near_low = (uint32_t)std::atol(e);
   float tau0_mult = 1.0f;  // first band = tau0_mult x delta
   if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
-  sssp_init_kernel<<<1, 256, 0, st>>>(sv.key.p, sv.fl[0], sv.ctl.p, (uint32_t)f->start,
-                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.shadow.p);
+  static_assert(sizeof(Ctl) % 4 == 0, "Ctl is cleared word by word");
+  sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
+                                               sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
+                                               delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  HIP_CHECK(hipGetLastError());
   sv.sweep_cap = 4ull * n + 64;
+  if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
+  if (const char* e = std::getenv("WFST_SSSP_CHASE_ROUNDS")) sv.chase_rounds = (uint32_t)std::atol(e);
+  if (const char* e = std::getenv("WFST_SSSP_CHASE_LOW")) sv.chase_low = (uint32_t)std::atol(e);
 }
 
 // Queues the sweeps of a solve in batches and finds the sweep that changed nothing.  start() queues the first batch and
@@ -546,7 +642,8 @@ struct SweepDriver {
                              (uint64_t)sv->flags.p,
                              (uint64_t)sv->improved.p ^ ((uint64_t)sv->shadow.p << 1), (uint64_t)sv->ctl.p,
                              ((uint64_t)n << 32) | __float_as_uint_host(delta),
-                             (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48)};
+                             (uint64_t)(h_imp + which * IMP_RING) ^ ((uint64_t)near_low << 48) ^ ((uint64_t)sv->chase_cap << 40) ^
+                                 ((uint64_t)sv->chase_rounds << 20) ^ ((uint64_t)sv->chase_low << 4)};
     if (g.exec && std::memcmp(g.key, key, sizeof(key)) == 0) return g.exec;
     if (g.exec) HIP_CHECK(hipGraphExecDestroy(g.exec));
     if (g.graph) HIP_CHECK(hipGraphDestroy(g.graph));
@@ -563,11 +660,13 @@ struct SweepDriver {
     float a_delta = delta;
     uint32_t a_low = near_low;
     uint32_t* a_shadow = sv->shadow.p;
+    uint32_t a_cap = sv->chase_cap, a_rounds = sv->chase_rounds, a_clow = sv->chase_low, a_profile = 0;
     for (uint32_t j = 0; j < count; ++j) {
       uint8_t* a_fc = sv->fl[j & 1u];
       uint8_t* a_fn = sv->fl[(j & 1u) ^ 1u];
       uint32_t a_off = j;
-      void* args[] = {&a_offsets, &a_wn, &a_key, &a_fc, &a_fn, &a_n, &a_imp, &a_ctl, &a_off, &a_delta, &a_low, &a_shadow};
+      void* args[] = {&a_offsets, &a_wn,  &a_key,   &a_fc,  &a_fn,     &a_n,   &a_imp,    &a_ctl,
+                      &a_off,     &a_delta, &a_low, &a_shadow, &a_cap, &a_rounds, &a_clow,   &a_profile};
       hipKernelNodeParams kp{};
       kp.func = (void*)sssp_relax_kernel;
       kp.gridDim = dim3(blocks);
@@ -609,7 +708,8 @@ struct SweepDriver {
       // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
       for (uint32_t j = 0; j < b.count; ++j)
         sssp_relax_kernel<<<sv->blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv->key.p, sv->fl[j & 1u], sv->fl[(j & 1u) ^ 1u],
-                                                      n, sv->improved.p, sv->ctl.p, j, sv->delta, sv->near_low, sv->shadow.p);
+                                                      n, sv->improved.p, sv->ctl.p, j, sv->delta, sv->near_low, sv->shadow.p,
+                                                      sv->chase_cap, sv->chase_rounds, sv->chase_low, 0u);
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
       HIP_CHECK(hipGetLastError());
     }
@@ -671,12 +771,18 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     Ctl* h_ctl = (Ctl*)((char*)h_imp + 64);
     ctx->sweep_trace.clear();
     uint64_t prev_arcs = 0, prev_states = 0;
+    auto shard_sum = [](const unsigned long long* v) {
+      uint64_t t = 0;
+      for (uint32_t j = 0; j < PROF_SHARDS; ++j) t += v[j * PROF_STRIDE];
+      return t;
+    };
     for (uint32_t k = 0;; ++k) {
       if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
-      sssp_count_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, fl[k & 1u], sv.key.p, n, sv.ctl.p, k, delta, near_low);
+      sssp_nop_kernel<<<blocks, 256, 0, st>>>(fl[k & 1u], n, sv.improved.p);
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
       sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
-                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low, sv.shadow.p);
+                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low, sv.shadow.p, sv.chase_cap,
+                                                sv.chase_rounds, sv.chase_low, 1u);  // counts the states / arcs it relaxes
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u, nullptr);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -684,18 +790,17 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       HIP_CHECK(hipStreamSynchronize(st));
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-      ctx->sweep_trace.push_back({(double)ms, h_ctl->arcs - prev_arcs, h_ctl->states - prev_states});
-      prev_arcs = h_ctl->arcs;
-      prev_states = h_ctl->states;
+      const uint64_t arcs = shard_sum(h_ctl->arcs), states = shard_sum(h_ctl->states);
+      ctx->sweep_trace.push_back({(double)ms, arcs - prev_arcs, states - prev_states});
+      prev_arcs = arcs;
+      prev_states = states;
       ctx->stats.relax_ms += ms;
       ctx->stats.relax_launches += 1;
       sweeps_done = k + 1;
       if (!h_imp[0]) break;
     }
-    HIP_CHECK(hipMemcpyAsync(h_ctl, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    ctx->stats.relax_arcs += h_ctl->arcs;
-    ctx->stats.relax_states += h_ctl->states;
+    ctx->stats.relax_arcs += prev_arcs;
+    ctx->stats.relax_states += prev_states;
   } else {
     SweepDriver drv;
     drv.init(ctx, f, &sv);

@@ -432,6 +432,36 @@ def test_near_far_schedule_does_not_change_results(oracle, delta):
         del os.environ["WFST_SSSP_DELTA"]
 
 
+@pytest.mark.parametrize("cap,budget,low", [(0, 0, 0), (1, 1, 1 << 30), (8, 3, 1 << 30), (32, 8, 4096), (128, 1000, 1 << 30),
+                                            (128, 1000, 64), (5, 1000, 1 << 30)])
+@pytest.mark.parametrize("delta", [None, "0", "0.7"])
+def test_chasing_does_not_change_results(oracle, monkeypatch, cap, budget, low, delta):
+    """Waves relaxing their own near discoveries inside the same launch only reorder relaxations:
+    list capacity, per-launch budget and the small-sweep gate (1<<30 = chase in every sweep) leave distances, hops
+    and the path untouched, on branching graphs (with and without epsilons), a sparse deep one and small cyclic FSTs
+    with many ties."""
+    monkeypatch.setenv("WFST_SSSP_CHASE_CAP", str(cap))
+    monkeypatch.setenv("WFST_SSSP_CHASE_ROUNDS", str(budget))
+    monkeypatch.setenv("WFST_SSSP_CHASE_LOW", str(low))
+    if delta is not None:
+        monkeypatch.setenv("WFST_SSSP_DELTA", delta)
+    ctx = rustfst_amd.Context(0)
+    for n, fan, p_eps, seed in ((70_000, 8, 0.02, 1), (3_000, 20, 0.0, 2), (30_000, 2, 0.3, 3)):
+        t = synth.make_transducer(n, fan, 64, p_eps, seed=seed)
+        d = to_device(t, ctx)
+        can = to_oracle(oracle, t).shortest_path_canonical()
+        for q in range(2):
+            dist, hops = d.shortest_distance(want_hops=True)
+            np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+            np.testing.assert_array_equal(hops, can.hops)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"chase {cap}/{budget}/{low} n={n} q={q}")
+    rng = np.random.default_rng(cap * 1000 + budget)
+    for k in range(6):  # small cyclic FSTs with epsilons and ties
+        f = random_fst_flat(rng, int(rng.integers(2, 200)), 5, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2, weight_grid=4, max_w=12)
+        ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
+        assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"chase small {k}")
+
+
 # ------------------------------------------------------------------ n > 1 shortest paths (B4-B6)
 def test_nshortest_known_graph(gpu_ctx, oracle):
     """The K2 graph (test_shortest_path.py:5-30) asked for 2 and 3 paths."""
