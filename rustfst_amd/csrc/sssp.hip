@@ -132,14 +132,14 @@ __global__ void __launch_bounds__(256) sssp_setup_kernel(uint64_t* __restrict__ 
 // relaxations that pass the plain pre-check.
 //
 // Chasing: a relaxation that improves a target to a NEAR distance does not flag it for the next sweep but puts it on a
-// small list private to the wave (LDS); after its flagged states the wave relaxes the listed ones too, for up to
-// `chase_rounds` states per launch (narrow frontiers are followed deep, growing ones are cut off), spilling to the flags whatever does not fit (`chase_cap` entries) or is left over — in sweeps
-// that follow one with fewer than `chase_low` near activations only.  A sweep
+// small list private to the wave (LDS); after its flagged states the wave relaxes the listed ones too, up to
+// `chase_rounds` states per launch (narrow frontiers are followed deep, growing ones are cut off), spilling to the flags
+// whatever does not fit (`chase_cap` entries) or is left over — only in sweeps that follow one with fewer than
+// `chase_low` near activations, and only by waves that had at most CHASE_OWN_MAX flagged states of their own.  A sweep
 // costs a launch plus a chain of dependent memory trips (~7 us) however small its frontier is, and half of the sweeps
 // of a solve are that small (the head and the tail of every band): chasing walks several levels of such a frontier
-// inside one launch, at one chain (~2.5 us) per level.  The fixed point does not depend on the order of relaxations,
-// so results are unchanged; an entry whose key has been improved again since it was listed is dropped (the improver
-// listed or flagged the state itself).
+// inside one launch.  The fixed point does not depend on the order of relaxations, so results are unchanged; an entry
+// whose key has been improved again since it was listed is dropped (the improver listed or flagged the state itself).
 constexpr uint32_t CHASE_MAX = 128;  // list entries per wave (ring)
 constexpr uint32_t CHASE_OWN_MAX = 4;
 
