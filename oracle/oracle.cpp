@@ -322,6 +322,8 @@ struct oracle_fst {
   }
 };
 
+extern "C" void oracle_fst_tr_sort(oracle_fst* f, int by_olabel);
+
 namespace {
 using Fst = oracle_fst;
 
@@ -1765,6 +1767,729 @@ bool path_rec(const Fst& f, uint32_t s, const std::vector<Tr>& labels, size_t i,
   return false;
 }
 
+// ================================================================ look-ahead composition (A12 / N1)
+// Restates the configuration the reference wires in rustfst-cli/src/cmds/compose.rs:77-181 and in its golden test
+// rustfst/src/tests_openfst/algorithms/compose.rs:118-254:
+//   fst1 -> MatcherFst::new_with_relabeling (LabelReachable on OUTPUT labels, both FSTs relabelled and re-sorted),
+//   M1 = LabelLookAheadMatcher<SortedMatcher> (flags OUTPUT_LOOKAHEAD_MATCHER | LOOKAHEAD_WEIGHT | LOOKAHEAD_PREFIX |
+//        LOOKAHEAD_EPSILONS | LOOKAHEAD_NON_EPSILON_PREFIX), M2 = SortedMatcher,
+//   filter = PushLabels(PushWeights(LookAhead(AltSequence))) with SMatchOutput, result = dyn_fst.compute() (no connect).
+// PIN STATUS: IntervalSet is pinned on the reference's unit tests (interval_set.rs:208-275); everything else in this
+// section is UNPINNED (the reference's "lookahead" goldens are generated by OpenFST at test time) and is checked
+// through invariants only (same weighted relation as the plain composition, reachability against brute force).
+namespace la {
+
+// IntInterval / IntervalSet — compose/interval_set.rs:8-190
+struct IntInterval {
+  size_t begin, end;
+};
+inline bool interval_less(const IntInterval& a, const IntInterval& b) {  // Ord :29-44: begin ascending, then end DESCENDING
+  if (a.begin != b.begin) return a.begin < b.begin;
+  return a.end > b.end;
+}
+struct IntervalSet {
+  std::vector<IntInterval> iv;
+  size_t count = 0;
+  size_t len() const { return iv.size(); }
+  void unite(const IntervalSet& o) { iv.insert(iv.end(), o.iv.begin(), o.iv.end()); }  // union :133-135 (not normalized)
+  bool member(size_t value) const {  // :138-145 (requires normalized)
+    const IntInterval x{value, value};
+    size_t lo = 0, hi = iv.size();
+    while (lo < hi) {
+      size_t mid = lo + (hi - lo) / 2;
+      if (interval_less(iv[mid], x))
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo == 0) return false;
+    return iv[lo - 1].end > value;
+  }
+  bool normalize() {  // :156-190; false = an empty interval was met (the reference loops forever there)
+    std::stable_sort(iv.begin(), iv.end(), interval_less);
+    const size_t n = iv.size();
+    std::vector<bool> keep(n, false);
+    size_t cnt = 0, i = 0;
+    while (i < n) {
+      IntInterval& inti = iv[i];
+      const size_t inti_index = i;
+      if (inti.begin == inti.end) return false;
+      for (size_t j = inti_index + 1; j < n; ++j) {
+        const IntInterval& intj = iv[j];
+        if (intj.begin > inti.end) break;
+        if (intj.end > inti.end) inti.end = intj.end;
+        i += 1;
+      }
+      cnt += inti.end - inti.begin;
+      keep[inti_index] = true;
+      i += 1;
+    }
+    size_t w = 0;
+    for (size_t k = 0; k < n; ++k)
+      if (keep[k]) iv[w++] = iv[k];
+    iv.resize(w);
+    count = cnt;
+    return true;
+  }
+};
+
+constexpr size_t UNASSIGNED = std::numeric_limits<size_t>::max();
+
+// IntervalReachVisitor — compose/interval_reach_visitor.rs:10-96 (fresh visitor: index starts at 1)
+struct IntervalReachVisitor {
+  const Fst* fst;
+  std::vector<IntervalSet> isets;
+  std::vector<size_t> state2index;
+  size_t index = 1;
+  bool failed = false;
+  explicit IntervalReachVisitor(const Fst& f) : fst(&f) {}
+  void init_visit(const Fst&) {}
+  bool init_state(uint32_t s, uint32_t) {  // :36-63
+    while (isets.size() <= s) isets.emplace_back();
+    while (state2index.size() <= s) state2index.push_back(UNASSIGNED);
+    const State& st = fst->states[s];
+    if (st.has_final && !wis_zero(st.final_w)) {
+      isets[s].iv.push_back(IntInterval{index, index + 1});
+      state2index[s] = index;
+      index += 1;
+    }
+    return true;
+  }
+  bool tree_tr(uint32_t, const Tr&) { return true; }
+  bool back_tr(uint32_t, const Tr&) {  // :71-73 panics
+    failed = true;
+    t_err = "IntervalReachVisitor: Cyclic input";
+    return false;
+  }
+  bool forward_or_cross_tr(uint32_t s, const Tr& tr) {  // :76-79
+    isets[s].unite(isets[tr.nextstate]);
+    return true;
+  }
+  void finish_state(uint32_t s, bool has_parent, uint32_t parent) {  // :83-95
+    const State& st = fst->states[s];
+    if (st.has_final && !wis_zero(st.final_w)) isets[s].iv[0].end = index;
+    if (!isets[s].normalize()) {
+      failed = true;
+      t_err = "IntervalSet::normalize: empty interval";
+    }
+    if (has_parent) isets[parent].unite(isets[s]);
+  }
+  void finish_visit() {}
+};
+
+// detects cycles the way compute_and_update_properties(ACYCLIC) does (a back arc, self loops included)
+struct CycleVisitor {
+  bool cyclic = false;
+  void init_visit(const Fst&) {}
+  bool init_state(uint32_t, uint32_t) { return true; }
+  bool tree_tr(uint32_t, const Tr&) { return true; }
+  bool back_tr(uint32_t, const Tr&) {
+    cyclic = true;
+    return true;
+  }
+  bool forward_or_cross_tr(uint32_t, const Tr&) { return true; }
+  void finish_state(uint32_t, bool, uint32_t) {}
+  void finish_visit() {}
+};
+
+// StateReachable — compose/state_reachable.rs:20-87
+struct StateReachable {
+  std::vector<IntervalSet> isets;
+  std::vector<size_t> state2index;
+};
+bool state_reachable_acyclic(const Fst& fst, StateReachable& out) {  // :69-76
+  IntervalReachVisitor v(fst);
+  dfs_visit(fst, v, false);
+  if (v.failed) return false;
+  out.isets = std::move(v.isets);
+  out.state2index = std::move(v.state2index);
+  return true;
+}
+// condense — algorithms/condense.rs:15-55
+void condense(const Fst& ifst, std::vector<int32_t>& scc, Fst& ofst) {
+  SccVisitor visitor(ifst, true);
+  dfs_visit(ifst, visitor, false);
+  scc = visitor.scc;
+  ofst = Fst();
+  if (scc.empty()) return;
+  int32_t mx = *std::max_element(scc.begin(), scc.end());
+  ofst.add_states((size_t)mx + 1);
+  for (size_t s = 0; s < scc.size(); ++s) {
+    const uint32_t c = (uint32_t)scc[s];
+    if (ifst.has_start && s == ifst.start) {
+      ofst.has_start = true;
+      ofst.start = c;
+    }
+    const State& st = ifst.states[s];
+    if (st.has_final) {
+      State& oc = ofst.states[c];
+      oc.final_w = oc.has_final ? wplus(oc.final_w, st.final_w) : st.final_w;
+      oc.has_final = true;
+    }
+    for (const Tr& tr : st.trs) {
+      const uint32_t nextc = (uint32_t)scc[tr.nextstate];
+      if (nextc != c) {
+        Tr t = tr;
+        t.nextstate = nextc;
+        ofst.states[c].trs.push_back(t);
+      }
+    }
+  }
+}
+bool state_reachable(const Fst& fst, StateReachable& out) {  // new :27-35, new_cyclic :37-67
+  CycleVisitor cv;
+  dfs_visit(fst, cv, false);
+  if (!cv.cyclic) return state_reachable_acyclic(fst, out);
+  std::vector<int32_t> scc;
+  Fst cfst;
+  condense(fst, scc, cfst);
+  StateReachable reachable;
+  if (!state_reachable_acyclic(cfst, reachable)) return false;
+  std::vector<size_t> nscc;
+  for (int32_t c : scc) {
+    while ((size_t)c >= nscc.size()) nscc.push_back(0);
+    nscc[c] += 1;
+  }
+  out.state2index.assign(scc.size(), UNASSIGNED);
+  out.isets.assign(scc.size(), IntervalSet());
+  for (size_t s = 0; s < scc.size(); ++s) {
+    const size_t c = (size_t)scc[s];
+    out.isets[s] = reachable.isets[c];
+    out.state2index[s] = reachable.state2index[c];
+    if (cfst.states[c].has_final && nscc[c] > 1) {
+      t_err = "StateReachable: Final state contained in a cycle";
+      return false;
+    }
+  }
+  return true;
+}
+
+// LabelReachableData / LabelReachable — compose/label_reachable.rs:16-403
+struct LabelReachableData {
+  bool reach_input = false;
+  uint32_t final_label = NO_LABEL;
+  std::unordered_map<uint32_t, uint32_t> label2index;
+  std::vector<IntervalSet> interval_sets;
+
+  uint32_t relabel(uint32_t label) {  // :52-61
+    if (label == EPS_LABEL) return EPS_LABEL;
+    const size_t n = label2index.size();
+    auto it = label2index.find(label);
+    if (it != label2index.end()) return it->second;
+    label2index.emplace(label, (uint32_t)n + 1);
+    return (uint32_t)n + 1;
+  }
+};
+
+// update_properties_labels + keep_only_relevant_properties — trs_iter_mut.rs:241-302 (set_arc_properties() is empty)
+uint64_t new_properties_labels(uint64_t p, uint32_t oi, uint32_t oo, uint32_t ni, uint32_t no) {
+  if (oi != oo) p &= ~P::NOT_ACCEPTOR;
+  if (oi == EPS_LABEL) {
+    p &= ~P::I_EPSILONS;
+    if (oo == EPS_LABEL) p &= ~P::EPSILONS;
+  }
+  if (oo == EPS_LABEL) p &= ~P::O_EPSILONS;
+  if (ni != no) {
+    p |= P::NOT_ACCEPTOR;
+    p &= ~P::ACCEPTOR;
+  }
+  if (ni == EPS_LABEL) {
+    p |= P::I_EPSILONS;
+    p &= ~P::NO_I_EPSILONS;
+    if (no == EPS_LABEL) {
+      p |= P::EPSILONS;
+      p &= ~P::NO_EPSILONS;
+    }
+  }
+  if (no == EPS_LABEL) {
+    p |= P::O_EPSILONS;
+    p &= ~P::NO_O_EPSILONS;
+  }
+  p &= P::ACCEPTOR | P::NOT_ACCEPTOR | P::EPSILONS | P::NO_EPSILONS | P::I_EPSILONS | P::NO_I_EPSILONS | P::O_EPSILONS |
+       P::NO_O_EPSILONS | P::WEIGHTED | P::UNWEIGHTED;
+  return p;
+}
+
+// LabelReachableData::relabel_fst — label_reachable.rs:63-93
+void relabel_fst(LabelReachableData& data, Fst& fst, bool relabel_input) {
+  for (State& st : fst.states) {
+    for (Tr& tr : st.trs) {
+      if (relabel_input) {
+        const uint32_t nl = data.relabel(tr.ilabel);
+        fst.properties = new_properties_labels(fst.properties, tr.ilabel, tr.olabel, nl, tr.olabel);
+        if (tr.ilabel == EPS_LABEL && nl != EPS_LABEL) st.niepsilons--;  // (relabel keeps epsilon as epsilon)
+        tr.ilabel = nl;
+      } else {
+        const uint32_t nl = data.relabel(tr.olabel);
+        fst.properties = new_properties_labels(fst.properties, tr.ilabel, tr.olabel, tr.ilabel, nl);
+        if (tr.olabel == EPS_LABEL && nl != EPS_LABEL) st.noepsilons--;
+        tr.olabel = nl;
+      }
+    }
+  }
+  oracle_fst_tr_sort(&fst, relabel_input ? 0 : 1);
+}
+
+// LabelReachable::transform_fst :172-248 + find_intervals :250-273 = compute_data :135-150
+bool compute_data(const Fst& ifst, bool reach_input, LabelReachableData& data) {
+  Fst fst = ifst;
+  data = LabelReachableData();
+  data.reach_input = reach_input;
+  std::unordered_map<uint32_t, uint32_t> label2state;
+  const uint32_t ins = (uint32_t)fst.num_states();
+  std::vector<size_t> indeg(ins, 0);
+  uint32_t ons = ins;
+  auto label_state = [&](uint32_t label) {
+    auto it = label2state.find(label);
+    if (it != label2state.end()) return it->second;
+    const uint32_t v = ons;
+    label2state.emplace(label, v);
+    indeg.push_back(0);
+    ons += 1;
+    return v;
+  };
+  for (uint32_t s = 0; s < ins; ++s) {
+    State& st = fst.states[s];
+    for (Tr& tr : st.trs) {
+      const uint32_t label = reach_input ? tr.ilabel : tr.olabel;
+      const uint32_t nextstate = label != EPS_LABEL ? label_state(label) : tr.nextstate;
+      indeg[nextstate] += 1;
+      tr.nextstate = nextstate;
+    }
+    if (st.has_final && !wis_zero(st.final_w)) {
+      const uint32_t nextstate = label_state(NO_LABEL);
+      st.trs.push_back(Tr{NO_LABEL, NO_LABEL, st.final_w, nextstate});
+      indeg[nextstate] += 1;
+      st.has_final = false;
+      st.final_w = INF;
+    }
+  }
+  while (fst.num_states() < (size_t)ons) {  // new final (label) states
+    fst.states.emplace_back();
+    fst.states.back().has_final = true;
+    fst.states.back().final_w = 0.0f;
+  }
+  fst.states.emplace_back();  // super-initial state for all states with zero in-degree
+  const uint32_t start = (uint32_t)fst.num_states() - 1;
+  fst.has_start = true;
+  fst.start = start;
+  for (uint32_t s = 0; s < start; ++s)
+    if (indeg[s] == 0) fst.states[start].trs.push_back(Tr{0, 0, 0.0f, s});
+
+  StateReachable sr;
+  if (!state_reachable(fst, sr)) return false;
+  data.interval_sets = std::move(sr.isets);
+  data.interval_sets.resize(ins);
+  for (const auto& kv : label2state) {
+    const size_t i = sr.state2index[kv.second];
+    data.label2index[kv.first] = (uint32_t)i;
+    if (kv.first == NO_LABEL) data.final_label = (uint32_t)i;
+  }
+  return true;
+}
+
+// LookAheadMatcherData — lookahead_matchers/mod.rs:27-69
+struct LaData {
+  float lookahead_weight = 0.0f;
+  Tr prefix_tr{0, 0, 0.0f, NO_STATE_ID};
+};
+
+// LabelReachable::reach :312-373 with reach_fst_input = true (labels of the look-ahead FST are its ilabels)
+bool reach(const LabelReachableData& data, uint32_t current_state, const std::vector<Tr>& trs, size_t aiter_begin,
+           size_t aiter_end, bool compute_weight, size_t* rb, size_t* re, float* rw) {
+  size_t reach_begin = UNASSIGNED, reach_end = UNASSIGNED;
+  float reach_weight = INF;
+  const IntervalSet& iset = data.interval_sets[current_state];
+  auto lower_bound = [&](size_t lo, size_t hi, uint32_t match_label) {  // :375-402
+    while (lo < hi) {
+      size_t mid = lo + (hi - lo) / 2;
+      if (trs[mid].ilabel < match_label)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  if (2 * (aiter_end - aiter_begin) < iset.len()) {
+    uint32_t reach_label = NO_LABEL;
+    for (size_t pos = aiter_begin; pos < aiter_end; ++pos) {
+      const Tr& tr = trs[pos];
+      const uint32_t label = tr.ilabel;
+      // reach_label :287-296: epsilon is never reachable
+      if (label == reach_label || (label != EPS_LABEL && iset.member(label))) {
+        reach_label = label;
+        if (reach_begin == UNASSIGNED) reach_begin = pos;
+        reach_end = pos + 1;
+        if (compute_weight) reach_weight = wplus(reach_weight, tr.weight);
+      }
+    }
+  } else {
+    size_t begin_low, end_low = aiter_begin;
+    for (const IntInterval& interval : iset.iv) {
+      begin_low = lower_bound(end_low, aiter_end, (uint32_t)interval.begin);
+      end_low = lower_bound(begin_low, aiter_end, (uint32_t)interval.end);
+      if (end_low - begin_low > 0) {
+        if (reach_begin == UNASSIGNED) reach_begin = begin_low;
+        reach_end = end_low;
+        if (compute_weight)
+          for (size_t i = begin_low; i < end_low; ++i) reach_weight = wplus(reach_weight, trs[i].weight);
+      }
+    }
+  }
+  if (reach_begin == UNASSIGNED) return false;
+  *rb = reach_begin;
+  *re = reach_end;
+  *rw = reach_weight;
+  return true;
+}
+
+// LabelLookAheadMatcher::lookahead_fst :154-213 (flags: LOOKAHEAD_WEIGHT and LOOKAHEAD_PREFIX set)
+bool lookahead_fst(const LabelReachableData& data, uint32_t matcher_state, const Fst& lfst, uint32_t lfst_state, LaData* out) {
+  LaData la;
+  bool compute_weight = true;
+  const bool compute_prefix = true;
+  const State& ls = lfst.states[lfst_state];
+  size_t rb = 0, re = 0;
+  float rw = INF;
+  const bool reach_tr = reach(data, matcher_state, ls.trs, 0, ls.trs.size(), compute_weight, &rb, &re, &rw);
+  const bool reach_final =
+      ls.has_final && !wis_zero(ls.final_w) && data.interval_sets[matcher_state].member(data.final_label);
+  if (reach_tr) {
+    if (compute_prefix && (re - rb) == 1 && !reach_final) {
+      la.prefix_tr = ls.trs[rb];
+      compute_weight = false;
+    } else {
+      la.lookahead_weight = rw;
+    }
+  }
+  if (reach_final && compute_weight) {
+    if (reach_tr)
+      la.lookahead_weight = wplus(la.lookahead_weight, ls.final_w);
+    else
+      la.lookahead_weight = ls.final_w;
+  }
+  if (reach_tr || reach_final) {
+    *out = la;
+    return true;
+  }
+  return false;
+}
+
+// quantize — semirings/semiring.rs:132-145
+inline float quantize(float v, float delta) {
+  if (std::isinf(v)) return v;
+  return std::floor((v / delta) + 0.5f) * delta;
+}
+
+// filter state of PushLabels(PushWeights(LookAhead(AltSequence))):
+// PairFilterState<PairFilterState<IntegerFilterState, WeightFilterState>, IntegerFilterState>
+struct FS {
+  uint32_t fs1;     // AltSequence state
+  float fweight;    // pushed weight (quantized)
+  uint32_t flabel;  // pushed label, NO_LABEL = none
+};
+struct Tuple5 {
+  uint32_t s1, s2;
+  FS fs;
+  // ComposeStateTuple equality: derived PartialEq; the weight compares within KDELTA in the reference while its hash
+  // uses the exact bits, so tuples whose weights differ by less than KDELTA are merged or not depending on hash-bucket
+  // collisions there.  Weights here are multiples of KDELTA after quantize; they are compared exactly.
+  bool operator==(const Tuple5& o) const {
+    uint32_t a, b;
+    std::memcpy(&a, &fs.fweight, 4);
+    std::memcpy(&b, &o.fs.fweight, 4);
+    return s1 == o.s1 && s2 == o.s2 && fs.fs1 == o.fs.fs1 && a == b && fs.flabel == o.fs.flabel;
+  }
+};
+struct Tuple5Hash {
+  size_t operator()(const Tuple5& t) const {
+    uint32_t wb;
+    std::memcpy(&wb, &t.fs.fweight, 4);
+    uint64_t h = ((uint64_t)t.s1 << 32) | t.s2;
+    h ^= ((uint64_t)t.fs.fs1 + 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
+    h ^= ((uint64_t)wb << 32 | t.fs.flabel) * 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    return (size_t)h;
+  }
+};
+
+struct LaComposeOp {
+  const Fst& fst1;  // relabelled, olabel-sorted
+  const Fst& fst2;  // relabelled, ilabel-sorted
+  const LabelReachableData& data;
+  uint64_t properties;
+  std::unordered_map<Tuple5, uint32_t, Tuple5Hash> tuple_to_id;
+  std::vector<Tuple5> id_to_tuple;
+
+  // filter object state (rebuilt per compute_trs / compute_final_weight: compose_fst_op.rs:411,425)
+  uint32_t c_s1 = 0, c_s2 = 0;
+  FS c_fs{0, 0.0f, NO_LABEL};
+  bool alleps2 = false, noeps2 = false;
+  size_t ntrsa = 0;
+  bool lookahead_tr = false;
+  LaData la;
+
+  LaComposeOp(const Fst& a, const Fst& b, const LabelReachableData& d) : fst1(a), fst2(b), data(d) {
+    // PushLabels::properties(PushWeights::properties(LookAhead::properties(AltSequence::properties(cprops))))
+    const uint64_t weight_invariant =
+        P::ACCEPTOR | P::NOT_ACCEPTOR | P::I_DETERMINISTIC | P::NOT_I_DETERMINISTIC | P::O_DETERMINISTIC |
+        P::NOT_O_DETERMINISTIC | P::EPSILONS | P::NO_EPSILONS | P::I_EPSILONS | P::NO_I_EPSILONS | P::O_EPSILONS |
+        P::NO_O_EPSILONS | P::I_LABEL_SORTED | P::NOT_I_LABEL_SORTED | P::O_LABEL_SORTED | P::NOT_O_LABEL_SORTED |
+        P::CYCLIC | P::ACYCLIC | P::INITIAL_CYCLIC | P::INITIAL_ACYCLIC | P::TOP_SORTED | P::NOT_TOP_SORTED |
+        P::ACCESSIBLE | P::NOT_ACCESSIBLE | P::COACCESSIBLE | P::NOT_COACCESSIBLE | P::STRING | P::NOT_STRING;  // properties.rs:436-465
+    const uint64_t o_label_invariant =
+        P::I_DETERMINISTIC | P::NOT_I_DETERMINISTIC | P::I_EPSILONS | P::NO_I_EPSILONS | P::I_LABEL_SORTED |
+        P::NOT_I_LABEL_SORTED | P::WEIGHTED | P::UNWEIGHTED | P::CYCLIC | P::ACYCLIC | P::INITIAL_CYCLIC |
+        P::INITIAL_ACYCLIC | P::TOP_SORTED | P::NOT_TOP_SORTED | P::ACCESSIBLE | P::NOT_ACCESSIBLE | P::COACCESSIBLE |
+        P::NOT_COACCESSIBLE | P::STRING | P::NOT_STRING | P::WEIGHTED_CYCLES | P::UNWEIGHTED_CYCLES;  // :409-432
+    properties = P::compose_properties(a.properties, b.properties) & weight_invariant & o_label_invariant;
+  }
+
+  uint32_t find_id(const Tuple5& t) {
+    auto it = tuple_to_id.find(t);
+    if (it != tuple_to_id.end()) return it->second;
+    const uint32_t n = (uint32_t)id_to_tuple.size();
+    id_to_tuple.push_back(t);
+    tuple_to_id.emplace(t, n);
+    return n;
+  }
+
+  // set_state: push_labels_compose_filter.rs:167-191 -> push_weights :139-142 -> lookahead :275-277 -> alt_sequence :143-158
+  void set_state(uint32_t s1, uint32_t s2, const FS& fs) {
+    c_s1 = s1;
+    c_s2 = s2;
+    c_fs = fs;
+    const State& st2 = fst2.states[s2];
+    alleps2 = st2.trs.size() == st2.niepsilons && !st2.has_final;
+    noeps2 = st2.niepsilons == 0;
+    ntrsa = fst1.states[s1].trs.size();  // lookahead_output(): num_trs(s1)
+  }
+
+  // AltSequenceComposeFilter::filter_tr :160-181
+  uint32_t alt_sequence(const Tr& arc1, const Tr& arc2) const {
+    if (arc2.ilabel == NO_LABEL) {
+      if (alleps2) return NO_STATE_ID;
+      return noeps2 ? 0u : 1u;
+    } else if (arc1.olabel == NO_LABEL) {
+      return c_fs.fs1 == 1 ? NO_STATE_ID : 0u;
+    } else if (arc1.olabel == EPS_LABEL) {
+      return NO_STATE_ID;
+    }
+    return 0u;
+  }
+  // LookAheadComposeFilter::filter_tr :279-290 + lookahead_filter_tr :191-228 (lookahead_output() = true, Fst2Matcher1)
+  uint32_t lookahead_filter(Tr& arc1, Tr& arc2) {
+    lookahead_tr = false;
+    const uint32_t fs = alt_sequence(arc1, arc2);
+    if (fs == NO_STATE_ID) return NO_STATE_ID;
+    const uint32_t labela = arc1.olabel;
+    if (labela != EPS_LABEL) return fs;  // LOOKAHEAD_NON_EPSILONS is not set
+    lookahead_tr = true;                 // LOOKAHEAD_EPSILONS is set
+    if (!lookahead_fst(data, arc1.nextstate, fst2, arc2.nextstate, &la)) return NO_STATE_ID;
+    return fs;
+  }
+  // PushWeightsComposeFilter::filter_tr :144-176
+  bool push_weights_filter(Tr& arc1, Tr& arc2, uint32_t* fs1, float* w) {
+    const uint32_t f = lookahead_filter(arc1, arc2);
+    if (f == NO_STATE_ID) return false;
+    const float lweight = lookahead_tr ? la.lookahead_weight : 0.0f;
+    const float fweight = c_fs.fweight;
+    if (wis_zero(lweight)) return false;  // disallows zero() weight futures
+    arc2.weight = wtimes(arc2.weight, lweight);
+    arc2.weight -= fweight;  // divide_assign: tropical_weight.rs:128-131
+    *fs1 = f;
+    *w = quantize(lweight, KDELTA);
+    return true;
+  }
+  // PushLabelsComposeFilter::filter_tr :193-222, pushed_label_filter_tr :285-336, push_label_filter_tr :339-400
+  bool filter_tr(Tr& arc1, Tr& arc2, FS* out) {
+    const uint32_t flabel = c_fs.flabel;
+    if (flabel != NO_LABEL) {  // consumes an already pushed label
+      const uint32_t labelb = arc2.ilabel;
+      if (labelb != NO_LABEL) return false;
+      if (arc1.olabel == flabel) {
+        arc1.olabel = EPS_LABEL;
+        *out = FS{0u, 0.0f, NO_LABEL};  // self.start()
+        return true;
+      }
+      if (arc1.olabel == EPS_LABEL) {
+        // ntrsa == 1 || matcher1.lookahead_label(arca.nextstate, flabel) (label_lookahead_matcher.rs:215-224)
+        if (ntrsa == 1 || data.interval_sets[arc1.nextstate].member(flabel)) {
+          *out = c_fs;
+          return true;
+        }
+        return false;
+      }
+      return false;
+    }
+    uint32_t fs1;
+    float w;
+    if (!push_weights_filter(arc1, arc2, &fs1, &w)) return false;
+    if (!lookahead_tr) {
+      *out = FS{fs1, w, NO_LABEL};
+      return true;
+    }
+    // pushes a label forward when possible
+    const uint32_t labelb = arc2.olabel;
+    if (labelb != EPS_LABEL) {
+      *out = FS{fs1, w, NO_LABEL};
+      return true;
+    }
+    // (labela == EPS here: the look-ahead only ran for an epsilon on fst1's output side; LOOKAHEAD_NON_EPSILON_PREFIX is set)
+    if (arc1.olabel != EPS_LABEL) {
+      *out = FS{fs1, w, NO_LABEL};
+      return true;
+    }
+    if (la.prefix_tr.nextstate != NO_STATE_ID) {  // default_lookahead_prefix, lookahead_matchers/mod.rs:60-68
+      const Tr& larc = la.prefix_tr;
+      arc1.olabel = larc.ilabel;
+      arc2.ilabel = larc.ilabel;
+      arc2.olabel = larc.olabel;
+      arc2.weight = wtimes(arc2.weight, larc.weight);
+      arc2.nextstate = larc.nextstate;
+      *out = FS{fs1, w, arc1.olabel};
+      return true;
+    }
+    *out = FS{fs1, w, NO_LABEL};
+    return true;
+  }
+
+  // items a matcher yields for (state, label): 0 = EpsLoop, else pointer to a real arc
+  struct Item {
+    bool loop;
+    const Tr* tr;
+  };
+  void sorted_items(const std::vector<Tr>& trs, uint32_t label, bool by_ilabel, std::vector<Item>& out) const {
+    MatcherIter it(trs, label, by_ilabel);
+    const Tr* real = nullptr;
+    for (;;) {
+      int k = it.next(&real);
+      if (k == 0) break;
+      out.push_back(k == 1 ? Item{true, nullptr} : Item{false, real});
+    }
+  }
+  // MultiEpsMatcher::iter + IteratorMultiEpsMatcher::next — matchers/multi_eps_matcher.rs:64-110,160-210.  The set of
+  // multi-epsilon labels is {flabel} or empty (push_labels_compose_filter.rs:183-189); matcher1 (fst1, by olabel) has
+  // MULTI_EPS_LIST, matcher2 (fst2, by ilabel) MULTI_EPS_LOOP (:115-137 with lookahead_output() = true).
+  void multi_eps_items(bool side2, uint32_t state, uint32_t label, std::vector<Item>& out) const {
+    const std::vector<Tr>& trs = side2 ? fst2.states[state].trs : fst1.states[state].trs;
+    const bool by_ilabel = side2;
+    const uint32_t flabel = c_fs.flabel;
+    if (label == EPS_LABEL) {
+      sorted_items(trs, EPS_LABEL, by_ilabel, out);
+    } else if (label == NO_LABEL) {
+      if (!side2 && flabel != NO_LABEL) {  // MULTI_EPS_LIST: arcs carrying the multi-epsilon label, then the epsilon arcs
+        const size_t before = out.size();
+        sorted_items(trs, flabel, by_ilabel, out);
+        (void)before;
+        sorted_items(trs, NO_LABEL, by_ilabel, out);
+      } else {
+        sorted_items(trs, NO_LABEL, by_ilabel, out);
+      }
+    } else if (side2 && flabel != NO_LABEL && label == flabel) {  // MULTI_EPS_LOOP: the label behaves like an epsilon loop
+      out.push_back(Item{true, nullptr});
+    } else {
+      sorted_items(trs, label, by_ilabel, out);
+    }
+  }
+
+  Tr add_tr(Tr arc1, const Tr& arc2, const FS& fs) {  // compose_fst_op.rs:267-285
+    Tuple5 t{arc1.nextstate, arc2.nextstate, fs};
+    arc1.weight = wtimes(arc1.weight, arc2.weight);
+    return Tr{arc1.ilabel, arc2.olabel, arc1.weight, find_id(t)};
+  }
+  void match_tr(uint32_t sa, const Tr& tr, bool mi, std::vector<Tr>& trs) {  // :287-353
+    const uint32_t label = mi ? tr.olabel : tr.ilabel;
+    std::vector<Item> items;
+    multi_eps_items(/*side2=*/mi, sa, label, items);
+    for (const Item& item : items) {
+      Tr arca = item.loop ? (mi ? Tr{NO_LABEL, EPS_LABEL, 0.0f, sa} : Tr{EPS_LABEL, NO_LABEL, 0.0f, sa}) : *item.tr;
+      Tr arcb = tr;
+      FS fs;
+      if (mi) {
+        if (filter_tr(arcb, arca, &fs)) trs.push_back(add_tr(arcb, arca, fs));
+      } else {
+        if (filter_tr(arca, arcb, &fs)) trs.push_back(add_tr(arca, arcb, fs));
+      }
+    }
+  }
+  std::vector<Tr> compute_trs(uint32_t state) {  // :406-418, ordered_expand :221-265, match_input :199-219
+    const Tuple5 tuple = id_to_tuple[state];
+    set_state(tuple.s1, tuple.s2, tuple.fs);
+    const bool mi = fst1.states[tuple.s1].trs.size() <= fst2.states[tuple.s2].trs.size();  // priorities = num_trs
+    const uint32_t sa = mi ? tuple.s2 : tuple.s1, sb = mi ? tuple.s1 : tuple.s2;
+    const Tr tr_loop = mi ? Tr{EPS_LABEL, NO_LABEL, 0.0f, sb} : Tr{NO_LABEL, EPS_LABEL, 0.0f, sb};
+    std::vector<Tr> trs;
+    match_tr(sa, tr_loop, mi, trs);
+    const std::vector<Tr>& sb_trs = mi ? fst1.states[sb].trs : fst2.states[sb].trs;
+    for (const Tr& tr : sb_trs) match_tr(sa, tr, mi, trs);
+    return trs;
+  }
+  bool compute_final_weight(uint32_t state, float* out) {  // :420-449 + the filters' filter_final
+    const Tuple5 tuple = id_to_tuple[state];
+    const State& a = fst1.states[tuple.s1];
+    if (!a.has_final) return false;
+    const State& b = fst2.states[tuple.s2];
+    if (!b.has_final) return false;
+    float w1 = a.final_w, w2 = b.final_w;
+    set_state(tuple.s1, tuple.s2, tuple.fs);
+    if (!wis_zero(w1)) w1 -= tuple.fs.fweight;                              // push_weights :178-189
+    if (!wis_zero(w1) && tuple.fs.flabel != NO_LABEL) w1 = INF;             // push_labels :224-238
+    const float f = wtimes(w1, w2);
+    if (wis_zero(f)) return false;
+    *out = f;
+    return true;
+  }
+};
+
+// the whole pipeline of cmds/compose.rs:131-180; r1 / r2 receive the relabelled inputs
+bool compose_lookahead(const Fst& in1, const Fst& in2, Fst& out, Fst& r1, Fst& r2, LabelReachableData& data) {
+  r1 = in1;
+  r2 = in2;
+  // MatcherFst::new_with_relabeling(fst1, &mut fst2, true) — matcher_fst.rs:73-94: data for MatchOutput only (the
+  // flags hold OUTPUT_LOOKAHEAD_MATCHER), init relabels fst1's olabels, relabel() fst2's ilabels
+  if (!compute_data(r1, /*reach_input=*/false, data)) return false;
+  relabel_fst(data, r1, /*relabel_input=*/false);
+  relabel_fst(data, r2, /*relabel_input=*/true);
+  oracle_fst_tr_sort(&r2, 0);  // cmds/compose.rs:151
+  // matcher1 needs O_LABEL_SORTED on fst1 (SortedMatcher, MatchOutput), reach_init needs I_LABEL_SORTED on fst2
+  // (label_reachable.rs:275-291): both hold after the sorts above.
+  LaComposeOp op(r1, r2, data);
+  out = Fst();
+  if (r1.has_start && r2.has_start) {
+    const uint32_t start_state = op.find_id(Tuple5{r1.start, r2.start, FS{0u, 0.0f, NO_LABEL}});
+    out.add_states((size_t)start_state + 1);
+    out.set_start(start_state);
+    std::deque<uint32_t> queue;
+    std::vector<bool> visited((size_t)start_state + 1, false);
+    visited[start_state] = true;
+    queue.push_back(start_state);
+    while (!queue.empty()) {  // LazyFst::compute, lazy/lazy_fst.rs:226-269
+      const uint32_t s = queue.front();
+      queue.pop_front();
+      std::vector<Tr> trs = op.compute_trs(s);
+      for (const Tr& tr : trs) {
+        if ((size_t)tr.nextstate >= visited.size()) visited.resize((size_t)tr.nextstate + 1, false);
+        if (!visited[tr.nextstate]) {
+          queue.push_back(tr.nextstate);
+          visited[tr.nextstate] = true;
+        }
+        const size_t n = out.num_states();
+        if ((size_t)tr.nextstate >= n) out.add_states((size_t)tr.nextstate - n + 1);
+      }
+      out.set_trs_unchecked(s, std::move(trs));
+      float fw;
+      if (op.compute_final_weight(s, &fw)) out.set_final(s, fw);
+    }
+    out.set_properties(op.properties);
+  }
+  return true;
+}
+
+}  // namespace la
+
 }  // namespace
 
 // ================================================================ C API
@@ -1869,6 +2594,69 @@ int oracle_compose_filter(const oracle_fst* f1, const oracle_fst* f2, int connec
   if (!compose_impl(*f1, *f2, connect != 0, *res, nullptr, filter)) return 1;
   *out = res.release();
   return 0;
+}
+
+// look-ahead composition (A12): cmds/compose.rs:77-181
+int oracle_compose_lookahead(const oracle_fst* f1, const oracle_fst* f2, oracle_fst** out, oracle_fst** relabeled1,
+                             oracle_fst** relabeled2) {
+  DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  std::unique_ptr<oracle_fst> o(new oracle_fst()), r1(new oracle_fst()), r2(new oracle_fst());
+  la::LabelReachableData data;
+  if (!la::compose_lookahead(*f1, *f2, *o, *r1, *r2, data)) return 1;
+  *out = o.release();
+  if (relabeled1) *relabeled1 = r1.release();
+  if (relabeled2) *relabeled2 = r2.release();
+  return 0;
+}
+
+int64_t oracle_interval_set_normalize(uint64_t* pairs, size_t n, uint64_t* count) {
+  la::IntervalSet s;
+  for (size_t i = 0; i < n; ++i) s.iv.push_back(la::IntInterval{(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]});
+  if (!s.normalize()) return -1;
+  for (size_t i = 0; i < s.iv.size(); ++i) {
+    pairs[2 * i] = s.iv[i].begin;
+    pairs[2 * i + 1] = s.iv[i].end;
+  }
+  if (count) *count = s.count;
+  return (int64_t)s.iv.size();
+}
+
+int oracle_interval_set_member(const uint64_t* pairs, size_t n, uint64_t value) {
+  la::IntervalSet s;
+  for (size_t i = 0; i < n; ++i) s.iv.push_back(la::IntInterval{(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]});
+  return s.member((size_t)value) ? 1 : 0;
+}
+
+struct oracle_label_reachable {
+  la::LabelReachableData data;
+};
+oracle_label_reachable* oracle_label_reachable_new(const oracle_fst* f, int reach_input) {
+  DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  std::unique_ptr<oracle_label_reachable> h(new oracle_label_reachable());
+  if (!la::compute_data(*f, reach_input != 0, h->data)) return nullptr;
+  return h.release();
+}
+void oracle_label_reachable_free(oracle_label_reachable* h) { delete h; }
+uint32_t oracle_label_reachable_final_label(const oracle_label_reachable* h) { return h->data.final_label; }
+size_t oracle_label_reachable_num_labels(const oracle_label_reachable* h) { return h->data.label2index.size(); }
+void oracle_label_reachable_labels(const oracle_label_reachable* h, uint32_t* labels, uint32_t* indices) {
+  std::vector<std::pair<uint32_t, uint32_t>> v(h->data.label2index.begin(), h->data.label2index.end());
+  std::sort(v.begin(), v.end());
+  for (size_t i = 0; i < v.size(); ++i) {
+    labels[i] = v[i].first;
+    indices[i] = v[i].second;
+  }
+}
+size_t oracle_label_reachable_num_states(const oracle_label_reachable* h) { return h->data.interval_sets.size(); }
+size_t oracle_label_reachable_num_intervals(const oracle_label_reachable* h, uint32_t state) {
+  return h->data.interval_sets[state].iv.size();
+}
+void oracle_label_reachable_intervals(const oracle_label_reachable* h, uint32_t state, uint64_t* pairs) {
+  const auto& iv = h->data.interval_sets[state].iv;
+  for (size_t i = 0; i < iv.size(); ++i) {
+    pairs[2 * i] = iv[i].begin;
+    pairs[2 * i + 1] = iv[i].end;
+  }
 }
 
 int oracle_connect(oracle_fst* f) {

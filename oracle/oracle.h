@@ -20,7 +20,12 @@
  * non-default compose filters (Null, Trivial, AltSequence, Match, NoMatch) and the
  * n > 1 shortest-path search — no reference output for them exists in the repository;
  * they are checked through invariants only (same best weight under every epsilon
- * filter, path membership, n = 1 agreement).
+ * filter, path membership, n = 1 agreement).  Look-ahead composition (row A12:
+ * LabelReachable, relabelling, LabelLookAheadMatcher, the PushLabels(PushWeights(
+ * LookAhead(AltSequence))) filter stack as wired in rustfst-cli/src/cmds/compose.rs:77-181):
+ * IntervalSet is pinned on the reference's unit tests (interval_set.rs:208-275), the rest
+ * is UNPINNED (its goldens are OpenFST-generated) and checked through invariants: reachable
+ * label sets against brute force, same multiset of weighted paths as plain composition.
  */
 #ifndef WFST_ORACLE_H
 #define WFST_ORACLE_H
@@ -79,6 +84,27 @@ int oracle_compose(const oracle_fst* f1, const oracle_fst* f2, int connect, int 
  * 0 Auto, 1 Null, 2 Trivial, 3 Sequence, 4 AltSequence, 5 Match, 6 NoMatch (default SortedMatchers) */
 int oracle_compose_filter(const oracle_fst* f1, const oracle_fst* f2, int connect, int eq_mode, int filter,
                           oracle_fst** out);
+/* look-ahead composition exactly as the reference wires it in rustfst-cli/src/cmds/compose.rs:77-181 and
+ * tests_openfst/algorithms/compose.rs:118-254: MatcherFst::new_with_relabeling(fst1, &mut fst2, true),
+ * LabelLookAheadMatcher (OUTPUT_LOOKAHEAD_MATCHER|LOOKAHEAD_WEIGHT|LOOKAHEAD_PREFIX|LOOKAHEAD_EPSILONS|
+ * LOOKAHEAD_NON_EPSILON_PREFIX) on fst1, SortedMatcher on fst2, PushLabels(PushWeights(LookAhead(AltSequence))),
+ * compute() without connect.  relabeled1/2 (may be NULL) receive the relabelled, re-sorted inputs.  UNPINNED. */
+int oracle_compose_lookahead(const oracle_fst* f1, const oracle_fst* f2, oracle_fst** out, oracle_fst** relabeled1,
+                             oracle_fst** relabeled2);
+/* IntervalSet (compose/interval_set.rs): normalize n (begin,end) pairs in place, returns the new length (-1: empty
+ * interval), *count = number of points; member() on a normalized set.  Pinned on interval_set.rs:208-275. */
+int64_t oracle_interval_set_normalize(uint64_t* pairs, size_t n, uint64_t* count);
+int oracle_interval_set_member(const uint64_t* pairs, size_t n, uint64_t value);
+/* LabelReachable::compute_data(fst, reach_input) (compose/label_reachable.rs:135-273) */
+typedef struct oracle_label_reachable oracle_label_reachable;
+oracle_label_reachable* oracle_label_reachable_new(const oracle_fst* f, int reach_input);
+void oracle_label_reachable_free(oracle_label_reachable*);
+uint32_t oracle_label_reachable_final_label(const oracle_label_reachable*);
+size_t oracle_label_reachable_num_labels(const oracle_label_reachable*);
+void oracle_label_reachable_labels(const oracle_label_reachable*, uint32_t* labels, uint32_t* indices); /* by label */
+size_t oracle_label_reachable_num_states(const oracle_label_reachable*);
+size_t oracle_label_reachable_num_intervals(const oracle_label_reachable*, uint32_t state);
+void oracle_label_reachable_intervals(const oracle_label_reachable*, uint32_t state, uint64_t* pairs);
 /* connect(): connect.rs:51-66 */
 int oracle_connect(oracle_fst*);
 /* shortest_path_with_config(nshortest=1): shortest_path.rs:107-133,173-282.

@@ -61,6 +61,23 @@ def lib():
         L.oracle_compose.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_compose_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_connect.argtypes = [vp]
+        L.oracle_compose_lookahead.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.oracle_interval_set_normalize.argtypes = [vp, C.c_size_t, C.POINTER(u64)]
+        L.oracle_interval_set_normalize.restype = i64
+        L.oracle_interval_set_member.argtypes = [vp, C.c_size_t, u64]
+        L.oracle_label_reachable_new.argtypes = [vp, C.c_int]
+        L.oracle_label_reachable_new.restype = vp
+        L.oracle_label_reachable_free.argtypes = [vp]
+        L.oracle_label_reachable_final_label.argtypes = [vp]
+        L.oracle_label_reachable_final_label.restype = u32
+        L.oracle_label_reachable_num_labels.argtypes = [vp]
+        L.oracle_label_reachable_num_labels.restype = C.c_size_t
+        L.oracle_label_reachable_labels.argtypes = [vp, vp, vp]
+        L.oracle_label_reachable_num_states.argtypes = [vp]
+        L.oracle_label_reachable_num_states.restype = C.c_size_t
+        L.oracle_label_reachable_num_intervals.argtypes = [vp, u32]
+        L.oracle_label_reachable_num_intervals.restype = C.c_size_t
+        L.oracle_label_reachable_intervals.argtypes = [vp, u32, vp]
         L.oracle_shortest_path.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.POINTER(f32)]
         L.oracle_shortest_path_canonical.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(f32), C.POINTER(u32)]
         L.oracle_shortest_path_n.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
@@ -182,6 +199,41 @@ class OracleFst:
             raise _err()
         return OracleFst(out.value)
 
+    def compose_lookahead(self, other, want_relabeled=False):
+        """Look-ahead composition as rustfst-cli/src/cmds/compose.rs:77-181 wires it (no connect).  With
+        want_relabeled also returns the relabelled, re-sorted copies of both inputs."""
+        out, r1, r2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if lib().oracle_compose_lookahead(self._h, other._h, C.byref(out), C.byref(r1) if want_relabeled else None,
+                                          C.byref(r2) if want_relabeled else None):
+            raise _err()
+        if want_relabeled:
+            return OracleFst(out.value), OracleFst(r1.value), OracleFst(r2.value)
+        return OracleFst(out.value)
+
+    def label_reachable(self, reach_input=False):
+        """LabelReachable::compute_data (label_reachable.rs:135-273): dict(final_label, label2index {label: index},
+        intervals [per state list of (begin, end)])."""
+        h = lib().oracle_label_reachable_new(self._h, 1 if reach_input else 0)
+        if not h:
+            raise _err()
+        try:
+            L = lib()
+            n = L.oracle_label_reachable_num_labels(h)
+            labels = np.zeros(n, dtype=np.uint32)
+            idx = np.zeros(n, dtype=np.uint32)
+            L.oracle_label_reachable_labels(h, labels.ctypes.data, idx.ctypes.data)
+            ivs = []
+            for s in range(L.oracle_label_reachable_num_states(h)):
+                k = L.oracle_label_reachable_num_intervals(h, s)
+                a = np.zeros(2 * k, dtype=np.uint64)
+                if k:
+                    L.oracle_label_reachable_intervals(h, s, a.ctypes.data)
+                ivs.append([(int(a[2 * i]), int(a[2 * i + 1])) for i in range(k)])
+            return {"final_label": int(L.oracle_label_reachable_final_label(h)),
+                    "label2index": {int(l): int(i) for l, i in zip(labels, idx)}, "intervals": ivs}
+        finally:
+            lib().oracle_label_reachable_free(h)
+
     def connect(self):
         lib().oracle_connect(self._h)
 
@@ -265,6 +317,21 @@ def flat_equal(a, b, delta=1.0 / 1024.0):
         return bool(np.all(both_inf | close))
 
     return approx(a["arcs"]["weight"], b["arcs"]["weight"]) and approx(a["finals"], b["finals"])
+
+
+def interval_set_normalize(pairs):
+    """IntervalSet::normalize (interval_set.rs:156-190): returns (normalized [(begin, end)], count)."""
+    a = np.array([x for p in pairs for x in p], dtype=np.uint64)
+    cnt = C.c_uint64()
+    n = lib().oracle_interval_set_normalize(a.ctypes.data if len(a) else None, len(pairs), C.byref(cnt))
+    if n < 0:
+        raise OracleError("empty interval")
+    return [(int(a[2 * i]), int(a[2 * i + 1])) for i in range(n)], cnt.value
+
+
+def interval_set_member(pairs, value):
+    a = np.array([x for p in pairs for x in p], dtype=np.uint64)
+    return bool(lib().oracle_interval_set_member(a.ctypes.data if len(a) else None, len(pairs), int(value)))
 
 
 def compose_shortest_path_batch(accs, t, n_threads=1, eq_mode=EQ_REF_KDELTA, keep_outputs=True):

@@ -339,3 +339,121 @@ def test_compose_filters_preserve_the_best_path(oracle, seed):
     # Null: a sub-relation (no lone epsilon moves) — never better than the others
     wn = float(oa.compose(ob, compose_filter=1).shortest_path_canonical().total_weight)
     assert wn >= ref - 1e-5
+
+
+# ------------------------------------------------------------------ look-ahead composition (row A12 / N1)
+def test_interval_set_reference_unit_tests(oracle):
+    """compose/interval_set.rs:208-275 (the reference's own unit tests): normalize collapses overlapping and adjacent
+    intervals and counts points; member() on the normalized set; Ord = begin ascending then end DESCENDING."""
+    assert not oracle.interval_set_member([], 3)
+    norm, count = oracle.interval_set_normalize([(0, 5), (3, 10)])
+    assert norm == [(0, 10)] and count == 10
+    assert oracle.interval_set_member(norm, 3)
+    norm, count = oracle.interval_set_normalize(norm + [(12, 13)])  # union + normalize
+    assert norm == [(0, 10), (12, 13)] and count == 11
+    assert oracle.interval_set_normalize([(1, 4), (1, 3)])[0] == [(1, 4)]   # (1,4) < (1,3): the longer one comes first
+    assert oracle.interval_set_normalize([(1, 4), (4, 6)])[0] == [(1, 6)]   # adjacent intervals merge
+    assert oracle.interval_set_normalize([(3, 4), (2, 3), (7, 9)]) == ([(2, 4), (7, 9)], 4)
+    assert not oracle.interval_set_member([(2, 4), (7, 9)], 4) and oracle.interval_set_member([(2, 4), (7, 9)], 8)
+
+
+def _reachable_olabels(flat, s):
+    """labels readable on the output side from s after any number of output-epsilon arcs; 'final' reachable likewise"""
+    off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
+    seen, stack, labels, final = {s}, [s], set(), False
+    while stack:
+        q = stack.pop()
+        final = final or bool(np.isfinite(fin[q]))
+        for k in range(off[q], off[q + 1]):
+            if arcs[k]["olabel"] == 0:
+                t = int(arcs[k]["nextstate"])
+                if t not in seen:
+                    seen.add(t)
+                    stack.append(t)
+            else:
+                labels.add(int(arcs[k]["olabel"]))
+    return labels, final
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_label_reachable_against_bruteforce(oracle, seed):
+    """LabelReachable::compute_data on output labels (label_reachable.rs:135-273): for every state the interval set
+    holds exactly the (relabelled) labels reachable through output-epsilon paths, and the final label iff a final
+    state is; cyclic epsilon structure goes through the condensation (state_reachable.rs:37-67)."""
+    rng = np.random.default_rng(600 + seed)
+    f = random_fst_flat(rng, int(rng.integers(1, 25)), 4, 6, p_eps_i=0.2, p_eps_o=0.5, p_final=0.25, sort="olabel",
+                        acyclic=(seed % 3 == 0))
+    of = to_oracle(oracle, f)
+    try:
+        data = of.label_reachable(reach_input=False)
+    except oracle.OracleError as e:
+        assert "Final state contained in a cycle" in str(e)  # the reference bails on such inputs too
+        return
+    l2i = data["label2index"]
+    assert sorted(v for v in l2i.values()) == list(range(1, len(l2i) + 1))  # DFS indices 1..n
+    for s in range(f["n_states"]):
+        labels, final = _reachable_olabels(f, s)
+        ivs = data["intervals"][s]
+        assert ivs == sorted(ivs) and all(b < e for b, e in ivs)
+        members = {i for b, e in ivs for i in range(b, e)}
+        expect = {l2i[l] for l in labels} | ({data["final_label"]} if final else set())
+        assert members == expect, (s, members, expect)
+
+
+def _successful_paths(flat, max_paths=200000):
+    from collections import Counter
+    off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
+    out = Counter()
+    if flat["start"] < 0:
+        return out
+    stack = [(flat["start"], (), (), 0.0)]
+    while stack:
+        s, il, ol, w = stack.pop()
+        if np.isfinite(fin[s]):
+            out[(il, ol, round(float(w + fin[s]) * 1024))] += 1
+            assert sum(out.values()) < max_paths
+        for k in range(off[s], off[s + 1]):
+            a = arcs[k]
+            stack.append((int(a["nextstate"]), il + ((int(a["ilabel"]),) if a["ilabel"] else ()),
+                          ol + ((int(a["olabel"]),) if a["olabel"] else ()), w + float(a["weight"])))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_lookahead_compose_is_the_same_weighted_relation(oracle, seed):
+    """The look-ahead configuration of cmds/compose.rs:77-181 prunes dead ends and pushes labels / weights forward, but
+    the result must accept exactly the successful paths of the plain composition: same multiset of (input string, output
+    string, weight) on acyclic inputs (weights on the 1/512 grid: sums and the pushed differences are exact)."""
+    rng = np.random.default_rng(7000 + seed)
+    a = random_fst_flat(rng, int(rng.integers(2, 9)), 3, 3, p_eps_i=0.2, p_eps_o=0.4, p_final=0.4, sort="olabel", acyclic=True)
+    b = random_fst_flat(rng, int(rng.integers(2, 9)), 3, 3, p_eps_i=0.3, p_eps_o=0.2, p_final=0.4, sort="ilabel", acyclic=True)
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    plain = oa.compose(ob, connect=False).to_flat()
+    la = oa.compose_lookahead(ob).to_flat()
+    assert _successful_paths(plain) == _successful_paths(la)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_lookahead_compose_keeps_the_best_path_on_cyclic_inputs(oracle, seed):
+    rng = np.random.default_rng(17000 + seed)
+    a = random_fst_flat(rng, int(rng.integers(2, 12)), 3, 3, p_eps_i=0.2, p_eps_o=0.45, p_final=0.3, sort="olabel")
+    b = random_fst_flat(rng, int(rng.integers(2, 12)), 3, 3, p_eps_i=0.3, p_eps_o=0.2, p_final=0.3, sort="ilabel")
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    try:
+        la, r1, r2 = oa.compose_lookahead(ob, want_relabeled=True)
+    except oracle.OracleError as e:
+        assert "Final state contained in a cycle" in str(e)
+        return
+    # the relabelled inputs: same shape, fst1 sorted by olabel, fst2 by ilabel, epsilons stay epsilons
+    f1, f2 = r1.to_flat(), r2.to_flat()
+    assert f1["n_states"] == a["n_states"] and len(f1["arcs"]) == len(a["arcs"])
+    for k in range(f1["n_states"]):
+        ol = f1["arcs"]["olabel"][f1["offsets"][k]:f1["offsets"][k + 1]]
+        assert np.all(np.diff(ol.astype(np.int64)) >= 0)
+    assert np.array_equal(np.sort(f1["arcs"]["olabel"] == 0), np.sort(a["arcs"]["olabel"] == 0))
+    assert np.array_equal(np.sort(f2["arcs"]["ilabel"] == 0), np.sort(b["arcs"]["ilabel"] == 0))
+
+    def total(p):
+        p = p.to_flat()
+        return None if p["n_states"] == 0 else round((float(p["arcs"]["weight"].sum()) + float(p["finals"][0])) * 1024)
+    assert total(oa.compose(ob).shortest_path()) == total(la.shortest_path())
