@@ -145,6 +145,40 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* ---- look-ahead composition: the configuration rustfst-cli/src/cmds/compose.rs:77-181 (ComposeType::LookAhead) and
+ *      rustfst/src/tests_openfst/algorithms/compose.rs:118-254 build by hand — there is no single reference entry point:
+ *        graph1look = MatcherFst::new_with_relabeling(fst1, &mut fst2, true)        (compose/matcher_fst.rs:73-94)
+ *        M1 = LabelLookAheadMatcher<SortedMatcher> with OUTPUT_LOOKAHEAD_MATCHER | LOOKAHEAD_WEIGHT | LOOKAHEAD_PREFIX |
+ *             LOOKAHEAD_EPSILONS | LOOKAHEAD_NON_EPSILON_PREFIX, M2 = SortedMatcher
+ *        filter = PushLabels(PushWeights(LookAhead(AltSequence))) with SMatchOutput  (compose/lookahead_filters/...)
+ *        ComposeFst::new_with_options(..).compute()                                   (no connect)
+ *      wfst_lookahead_create  = MatcherFst::new on fst1: LabelReachable::compute_data(fst1, reach_input = false)
+ *        (compose/label_reachable.rs:135-273, host) + fst1's olabels relabelled and re-sorted (:63-93); the relabelled FST
+ *        and the per-state reachable-label intervals live in HBM.  KO "StateReachable: Final state contained in a cycle"
+ *        like the reference (state_reachable.rs:62-64).
+ *      wfst_lookahead_relabel = LabelLookAheadRelabeler::relabel(fst2, .., relabel_input = true) + tr_sort(ILabelCompare)
+ *        (lookahead_matchers/label_lookahead_relabeler.rs:27-41, cmds/compose.rs:151): a NEW handle; labels fst1 never
+ *        emits get fresh indices, the map inside `la` grows as the reference's does.
+ *      wfst_compose_lookahead = the composition itself on the GPU; output numbered like LazyFst::compute, not connected.
+ *      The handle owns the relabelled fst1 (wfst_lookahead_fst1 lends it). ---- */
+typedef struct wfst_lookahead wfst_lookahead;
+wfst_status wfst_lookahead_create(wfst_ctx* ctx, const wfst_fst* fst1, wfst_lookahead** out);
+wfst_status wfst_lookahead_relabel(wfst_lookahead* la, const wfst_fst* fst2, wfst_fst** out);
+wfst_status wfst_lookahead_fst1(const wfst_lookahead* la, const wfst_fst** out);
+wfst_status wfst_compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* relabeled_fst2, wfst_fst** out);
+wfst_status wfst_lookahead_destroy(wfst_lookahead* la);
+/* LabelReachableData of a look-ahead handle: sizes, then the arrays (interval_offsets[n_states + 1], intervals[2 *
+ * n_intervals] = half-open [begin, end) pairs over relabelled labels, labels[n_labels] ascending with their indices;
+ * the NO_LABEL entry is the final label).  Any output may be NULL. */
+wfst_status wfst_lookahead_info(const wfst_lookahead* la, uint32_t* n_states, uint64_t* n_intervals, uint32_t* n_labels,
+                                uint32_t* final_label);
+wfst_status wfst_lookahead_download(const wfst_lookahead* la, uint32_t* interval_offsets, uint32_t* intervals,
+                                    uint32_t* labels, uint32_t* indices);
+/* host-only handle (no GPU, no relabelled FST): LabelReachable::compute_data on flat CSR arrays (offsets[n_states + 1],
+ * arcs, finals with +inf = not final).  Serves wfst_lookahead_info / _download / _destroy only. */
+wfst_status wfst_label_reachable_compute(uint32_t n_states, const uint32_t* offsets, const wfst_tr* arcs, const float* finals,
+                                         int reach_input, wfst_lookahead** out);
+
 /* asynchronous form of wfst_shortest_path for nshortest == 1: _begin queues the relaxation (and, from the second
  * query of an FST on, the final-state search, backtrace and read-back behind it) on ctx's stream and returns; _end
  * waits, continues the relaxation if it needed more sweeps than the previous query, and returns the same FST the

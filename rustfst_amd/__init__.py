@@ -19,6 +19,7 @@ from .fst import (  # noqa: F401
     compose_shortest_path_batch,
     compose_shortest_path_batch_begin,
     HandleArray,
+    LookAhead,
     compose_with_config,
     default_context,
     set_default_context,
@@ -28,6 +29,6 @@ from .fst import (  # noqa: F401
 
 __all__ = [
     "ComposeConfig", "ComposeFilter", "Context", "DeviceFst", "ShortestPathConfig", "Tr", "VectorFst", "acceptor",
-    "compose", "compose_shortest_path_batch", "compose_shortest_path_batch_begin", "HandleArray", "compose_with_config", "default_context", "set_default_context",
+    "compose", "compose_shortest_path_batch", "compose_shortest_path_batch_begin", "HandleArray", "LookAhead", "compose_with_config", "default_context", "set_default_context",
     "shortestpath", "shortestpath_with_config", "WfstError", "TR_DTYPE", "LIB_PATH",
 ]

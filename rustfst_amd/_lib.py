@@ -56,6 +56,14 @@ SYMBOLS = [
     ("wfst_fst_destroy_many", C.c_int, [_P(_vp), _sz]),
     ("wfst_compose", C.c_int, [_vp, _vp, _vp, _P(ComposeConfig), _P(_vp)]),
     ("wfst_shortest_path", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
+    ("wfst_lookahead_create", C.c_int, [_vp, _vp, _P(_vp)]),
+    ("wfst_lookahead_relabel", C.c_int, [_vp, _vp, _P(_vp)]),
+    ("wfst_lookahead_fst1", C.c_int, [_vp, _P(_vp)]),
+    ("wfst_compose_lookahead", C.c_int, [_vp, _vp, _vp, _P(_vp)]),
+    ("wfst_lookahead_destroy", C.c_int, [_vp]),
+    ("wfst_lookahead_info", C.c_int, [_vp, _P(_u32), _P(_u64), _P(_u32), _P(_u32)]),
+    ("wfst_lookahead_download", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("wfst_label_reachable_compute", C.c_int, [_u32, _vp, _vp, _vp, C.c_int, _P(_vp)]),
     ("wfst_shortest_path_begin", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_path_end", C.c_int, [_vp, _P(_vp)]),
     ("wfst_shortest_distance", C.c_int, [_vp, _vp, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "lookahead.h"
 #include "fst_props.h"
 
 namespace wfst {
@@ -345,6 +346,94 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
     if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
     HIP_CHECK(hipSetDevice(ctx->device));
     compose_shortest_path_batch(ctx, acceptors, n, t, c.connect != 0, outs, composed_arcs, c.compose_filter);
+  });
+}
+
+wfst_status wfst_lookahead_create(wfst_ctx* ctx, const wfst_fst* fst1, wfst_lookahead** out) {
+  return wrap([&] {
+    if (!ctx || !fst1 || !out) throw Error("null pointer");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = lookahead_create(ctx, fst1);
+  });
+}
+
+wfst_status wfst_lookahead_relabel(wfst_lookahead* la, const wfst_fst* fst2, wfst_fst** out) {
+  return wrap([&] {
+    if (!la || !fst2 || !out) throw Error("null pointer");
+    *out = nullptr;
+    if (!la->ctx) throw Error("host-only look-ahead handle");
+    HIP_CHECK(hipSetDevice(la->ctx->device));
+    *out = lookahead_relabel(la, fst2);
+  });
+}
+
+wfst_status wfst_lookahead_fst1(const wfst_lookahead* la, const wfst_fst** out) {
+  return wrap([&] {
+    if (!la || !out) throw Error("null pointer");
+    if (!la->fst1) throw Error("host-only look-ahead handle");
+    *out = la->fst1;
+  });
+}
+
+wfst_status wfst_compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* relabeled_fst2, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !la || !relabeled_fst2 || !out) throw Error("null pointer");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = compose_lookahead(ctx, la, relabeled_fst2);
+  });
+}
+
+wfst_status wfst_lookahead_destroy(wfst_lookahead* la) {
+  return wrap([&] {
+    if (!la) return;
+    if (la->ctx) (void)hipSetDevice(la->ctx->device);
+    delete la;
+  });
+}
+
+wfst_status wfst_lookahead_info(const wfst_lookahead* la, uint32_t* n_states, uint64_t* n_intervals, uint32_t* n_labels,
+                                uint32_t* final_label) {
+  return wrap([&] {
+    if (!la) throw Error("null pointer");
+    if (n_states) *n_states = (uint32_t)(la->data.iv_off.size() - 1);
+    if (n_intervals) *n_intervals = la->data.iv.size() / 2;
+    if (n_labels) *n_labels = (uint32_t)la->data.label2index.size();
+    if (final_label) *final_label = la->data.final_label;
+  });
+}
+
+wfst_status wfst_lookahead_download(const wfst_lookahead* la, uint32_t* interval_offsets, uint32_t* intervals,
+                                    uint32_t* labels, uint32_t* indices) {
+  return wrap([&] {
+    if (!la) throw Error("null pointer");
+    if (interval_offsets) std::copy(la->data.iv_off.begin(), la->data.iv_off.end(), interval_offsets);
+    if (intervals) std::copy(la->data.iv.begin(), la->data.iv.end(), intervals);
+    if (labels || indices) {
+      std::vector<std::pair<uint32_t, uint32_t>> v(la->data.label2index.begin(), la->data.label2index.end());
+      std::sort(v.begin(), v.end());
+      for (size_t i = 0; i < v.size(); ++i) {
+        if (labels) labels[i] = v[i].first;
+        if (indices) indices[i] = v[i].second;
+      }
+    }
+  });
+}
+
+wfst_status wfst_label_reachable_compute(uint32_t n_states, const uint32_t* offsets, const wfst_tr* arcs, const float* finals,
+                                         int reach_input, wfst_lookahead** out) {
+  return wrap([&] {
+    if (!offsets || !out || (n_states && !finals) || (offsets[n_states] && !arcs)) throw Error("null pointer");
+    *out = nullptr;
+    for (uint32_t s = 0; s < n_states; ++s) {
+      if (offsets[s] > offsets[s + 1]) throw Error("offsets are not monotone");
+      for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k)
+        if (arcs[k].nextstate >= n_states) throw Error("arc to a state that does not exist");
+    }
+    std::unique_ptr<wfst_lookahead> la(new wfst_lookahead());
+    la->data.compute(n_states, offsets, arcs, finals, reach_input != 0);
+    *out = la.release();
   });
 }
 

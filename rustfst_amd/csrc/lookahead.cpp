@@ -1,0 +1,339 @@
+// Host side of look-ahead composition: the per-state sets of output labels reachable through
+// output-epsilon paths, as sorted disjoint intervals over relabelled labels, and the relabelling of both operands.
+//
+// Mirrors rustfst::algorithms::compose::{LabelReachable (label_reachable.rs:135-273), StateReachable
+// (state_reachable.rs:20-87), IntervalReachVisitor (interval_reach_visitor.rs:28-96), IntervalSet::normalize
+// (interval_set.rs:153-190), condense (algorithms/condense.rs:15-55), LabelReachableData::{relabel, relabel_fst}
+// (label_reachable.rs:52-93)}.  The label -> index map is the order in which a depth-first visit (dfs_visit.rs:97-187)
+// of the transformed FST discovers the per-label sink states, so the visit order is reproduced exactly; everything
+// works on flat CSR arrays with explicit stacks (decoding graphs have millions of states).
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+
+#include "common.h"
+#include "fst_props.h"
+#include "lookahead.h"
+
+namespace wfst {
+namespace {
+
+constexpr uint32_t NO_LABEL = WFST_NO_LABEL;
+constexpr uint32_t UNASSIGNED = 0xFFFFFFFFu;
+
+// successor lists of the transformed FST (label_reachable.rs:172-248): only the targets matter to the visit
+struct Graph {
+  std::vector<uint32_t> off, dst;
+  std::vector<uint8_t> is_final;
+  uint32_t start = 0;
+  uint32_t n() const { return (uint32_t)is_final.size(); }
+};
+
+// the depth-first visit of dfs_visit.rs:97-187 (every state, roots: start, then 0, 1, 2, ... among the unvisited)
+template <class V>
+void depth_first(const Graph& g, V& v) {
+  enum : uint8_t { White, Grey, Black };
+  const uint32_t n = g.n();
+  std::vector<uint8_t> color(n, White);
+  std::vector<std::pair<uint32_t, uint32_t>> stack;  // {state, next arc position}
+  uint32_t root = g.start;
+  while (root < n) {
+    color[root] = Grey;
+    stack.push_back({root, g.off[root]});
+    v.discover(root);
+    while (!stack.empty()) {
+      const uint32_t s = stack.back().first;
+      const uint32_t pos = stack.back().second;
+      if (pos >= g.off[s + 1]) {
+        color[s] = Black;
+        stack.pop_back();
+        if (!stack.empty()) {
+          v.finish(s, true, stack.back().first);
+          stack.back().second++;
+        } else {
+          v.finish(s, false, 0);
+        }
+        continue;
+      }
+      const uint32_t t = g.dst[pos];
+      if (color[t] == White) {
+        color[t] = Grey;
+        v.discover(t);
+        stack.push_back({t, g.off[t]});
+      } else if (color[t] == Grey) {
+        v.back(s, t);
+        stack.back().second++;
+      } else {
+        v.cross(s, t);
+        stack.back().second++;
+      }
+    }
+    root = root == g.start ? 0 : root + 1;
+    while (root < n && color[root] != White) root++;
+  }
+}
+
+using Intervals = std::vector<std::pair<uint32_t, uint32_t>>;  // half-open [begin, end)
+
+// IntervalSet::normalize (interval_set.rs:156-190): order by begin (longer first on ties), merge overlapping and adjacent
+void normalize(Intervals& iv) {
+  std::stable_sort(iv.begin(), iv.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+    return a.first != b.first ? a.first < b.first : a.second > b.second;
+  });
+  size_t w = 0;
+  for (size_t i = 0; i < iv.size();) {
+    std::pair<uint32_t, uint32_t> cur = iv[i];
+    if (cur.first == cur.second) throw Error("IntervalSet: empty interval");  // (the reference does not terminate on it)
+    size_t j = i + 1;
+    for (; j < iv.size(); ++j) {
+      if (iv[j].first > cur.second) break;
+      if (iv[j].second > cur.second) cur.second = iv[j].second;
+    }
+    iv[w++] = cur;
+    i = j;
+  }
+  iv.resize(w);
+}
+
+// IntervalReachVisitor (interval_reach_visitor.rs:28-96)
+struct ReachVisitor {
+  const Graph& g;
+  std::vector<Intervals> sets;
+  std::vector<uint32_t> state2index;
+  uint32_t index = 1;
+  explicit ReachVisitor(const Graph& gr) : g(gr), sets(gr.n()), state2index(gr.n(), UNASSIGNED) {}
+  void discover(uint32_t s) {
+    if (g.is_final[s]) {
+      sets[s].push_back({index, index + 1});
+      state2index[s] = index;
+      index++;
+    }
+  }
+  void back(uint32_t, uint32_t) { throw Error("IntervalReachVisitor: cyclic input"); }
+  void cross(uint32_t s, uint32_t t) { sets[s].insert(sets[s].end(), sets[t].begin(), sets[t].end()); }
+  void finish(uint32_t s, bool has_parent, uint32_t parent) {
+    if (g.is_final[s]) sets[s][0].second = index;  // every final state discovered below s has an index in [mine, index)
+    normalize(sets[s]);
+    if (has_parent) sets[parent].insert(sets[parent].end(), sets[s].begin(), sets[s].end());
+  }
+};
+
+struct CycleVisitor {
+  bool cyclic = false;
+  void discover(uint32_t) {}
+  void back(uint32_t, uint32_t) { cyclic = true; }
+  void cross(uint32_t, uint32_t) {}
+  void finish(uint32_t, bool, uint32_t) {}
+};
+
+// SccVisitor (visitors/scc_visitors.rs:10-180): Tarjan over the same visit; component ids are reversed at the end, so
+// they are a topological numbering of the condensation
+struct SccVisitor {
+  std::vector<int32_t> scc, dfnumber, lowlink;
+  std::vector<uint8_t> onstack;
+  std::vector<uint32_t> stack;
+  int32_t nstates = 0, nscc = 0;
+  explicit SccVisitor(uint32_t n) : scc(n, -1), dfnumber(n, -1), lowlink(n, -1), onstack(n, 0) {}
+  void discover(uint32_t s) {
+    stack.push_back(s);
+    dfnumber[s] = lowlink[s] = nstates++;
+    onstack[s] = 1;
+  }
+  void back(uint32_t s, uint32_t t) {
+    if (dfnumber[t] < lowlink[s]) lowlink[s] = dfnumber[t];
+  }
+  void cross(uint32_t s, uint32_t t) {
+    if (dfnumber[t] < dfnumber[s] && onstack[t] && dfnumber[t] < lowlink[s]) lowlink[s] = dfnumber[t];
+  }
+  void finish(uint32_t s, bool has_parent, uint32_t parent) {
+    if (dfnumber[s] == lowlink[s]) {
+      uint32_t t;
+      do {
+        t = stack.back();
+        stack.pop_back();
+        scc[t] = nscc;
+        onstack[t] = 0;
+      } while (t != s);
+      nscc++;
+    }
+    if (has_parent && lowlink[s] < lowlink[parent]) lowlink[parent] = lowlink[s];
+  }
+  void done() {
+    for (auto& c : scc) c = nscc - 1 - c;
+  }
+};
+
+// StateReachable::new (state_reachable.rs:26-76): interval sets + discovery index of the final states; cyclic inputs go
+// through their condensation (no final state may lie on a cycle)
+void state_reachable(const Graph& g, std::vector<Intervals>& sets, std::vector<uint32_t>& state2index) {
+  CycleVisitor cv;
+  depth_first(g, cv);
+  if (!cv.cyclic) {
+    ReachVisitor rv(g);
+    depth_first(g, rv);
+    sets = std::move(rv.sets);
+    state2index = std::move(rv.state2index);
+    return;
+  }
+  SccVisitor sv(g.n());
+  depth_first(g, sv);
+  sv.done();
+  const uint32_t nc = (uint32_t)sv.nscc;
+  Graph c;  // condense (condense.rs:15-55): arcs between different components, in source-state then arc order
+  c.is_final.assign(nc, 0);
+  c.start = (uint32_t)sv.scc[g.start];
+  std::vector<uint32_t> members(nc, 0), deg(nc + 1, 0);
+  for (uint32_t s = 0; s < g.n(); ++s) {
+    const uint32_t cs = (uint32_t)sv.scc[s];
+    members[cs]++;
+    if (g.is_final[s]) c.is_final[cs] = 1;
+    for (uint32_t k = g.off[s]; k < g.off[s + 1]; ++k)
+      if ((uint32_t)sv.scc[g.dst[k]] != cs) deg[cs + 1]++;
+  }
+  c.off.assign(nc + 1, 0);
+  for (uint32_t i = 0; i < nc; ++i) c.off[i + 1] = c.off[i] + deg[i + 1];
+  c.dst.resize(c.off[nc]);
+  std::vector<uint32_t> cur(c.off.begin(), c.off.end() - 1);
+  for (uint32_t s = 0; s < g.n(); ++s) {
+    const uint32_t cs = (uint32_t)sv.scc[s];
+    for (uint32_t k = g.off[s]; k < g.off[s + 1]; ++k) {
+      const uint32_t ct = (uint32_t)sv.scc[g.dst[k]];
+      if (ct != cs) c.dst[cur[cs]++] = ct;
+    }
+  }
+  ReachVisitor rv(c);
+  depth_first(c, rv);
+  sets.assign(g.n(), Intervals());
+  state2index.assign(g.n(), UNASSIGNED);
+  for (uint32_t s = 0; s < g.n(); ++s) {
+    const uint32_t cs = (uint32_t)sv.scc[s];
+    if (c.is_final[cs] && members[cs] > 1) throw Error("StateReachable: Final state contained in a cycle");
+    sets[s] = rv.sets[cs];
+    state2index[s] = rv.state2index[cs];
+  }
+}
+
+}  // namespace
+
+// LabelReachable::compute_data (label_reachable.rs:135-150) = transform_fst (:172-248) + find_intervals (:250-273)
+void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const wfst_tr* arcs, const float* finals,
+                             bool reach_input_) {
+  reach_input = reach_input_;
+  final_label = NO_LABEL;
+  label2index.clear();
+  const uint32_t ins = n_states;
+  // labelled arcs go to a sink state per label (created in order of first appearance), final states get an arc to the
+  // NO_LABEL sink, a super-initial state points at every state nothing points at
+  std::unordered_map<uint32_t, uint32_t> label2state;
+  std::vector<uint32_t> sink_label;  // label of sink state ins + k
+  Graph g;
+  g.off.assign(1, 0);
+  g.dst.reserve((size_t)offsets[ins] + ins);
+  auto sink = [&](uint32_t label) {
+    auto it = label2state.find(label);
+    if (it != label2state.end()) return it->second;
+    const uint32_t st = ins + (uint32_t)sink_label.size();
+    label2state.emplace(label, st);
+    sink_label.push_back(label);
+    return st;
+  };
+  for (uint32_t s = 0; s < ins; ++s) {
+    for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k) {
+      const uint32_t label = reach_input ? arcs[k].ilabel : arcs[k].olabel;
+      g.dst.push_back(label != 0 ? sink(label) : arcs[k].nextstate);
+    }
+    if (finals[s] != INF) g.dst.push_back(sink(NO_LABEL));  // final_weight Some and not zero
+    g.off.push_back((uint32_t)g.dst.size());
+  }
+  const uint32_t ons = ins + (uint32_t)sink_label.size();
+  std::vector<uint32_t> indeg(ons, 0);
+  for (uint32_t t : g.dst) indeg[t]++;
+  for (uint32_t s = ins; s < ons; ++s) g.off.push_back((uint32_t)g.dst.size());  // sinks have no arcs
+  const uint32_t start = ons;
+  for (uint32_t s = 0; s < ons; ++s)
+    if (indeg[s] == 0) g.dst.push_back(s);
+  g.off.push_back((uint32_t)g.dst.size());
+  g.is_final.assign((size_t)ons + 1, 0);
+  for (uint32_t s = ins; s < ons; ++s) g.is_final[s] = 1;
+  g.start = start;
+
+  std::vector<Intervals> sets;
+  std::vector<uint32_t> state2index;
+  state_reachable(g, sets, state2index);
+
+  iv_off.assign((size_t)ins + 1, 0);
+  iv.clear();
+  for (uint32_t s = 0; s < ins; ++s) {
+    for (const auto& p : sets[s]) {
+      iv.push_back(p.first);
+      iv.push_back(p.second);
+    }
+    iv_off[s + 1] = (uint32_t)(iv.size() / 2);
+  }
+  for (uint32_t k = 0; k < sink_label.size(); ++k) {
+    const uint32_t idx = state2index[ins + k];
+    label2index[sink_label[k]] = idx;
+    if (sink_label[k] == NO_LABEL) final_label = idx;
+  }
+}
+
+uint32_t LabelReachData::relabel(uint32_t label) {  // label_reachable.rs:52-61
+  if (label == 0) return 0;
+  auto it = label2index.find(label);
+  if (it != label2index.end()) return it->second;
+  const uint32_t v = (uint32_t)label2index.size() + 1;
+  label2index.emplace(label, v);
+  return v;
+}
+
+// LabelReachableData::relabel_fst (label_reachable.rs:63-93): rewrite one label column, then tr_sort on it.  Returns the
+// property word after the per-arc label bookkeeping (trs_iter_mut.rs:241-302) and tr_sort (tr_sort.rs:13-62).
+uint64_t LabelReachData::relabel_fst(uint32_t n_states, const uint32_t* offsets, wfst_tr* arcs, uint64_t props_in,
+                                     bool relabel_input) {
+  uint64_t p = props_in;
+  const uint64_t keep = props::ACCEPTOR | props::NOT_ACCEPTOR | props::EPSILONS | props::NO_EPSILONS | props::I_EPSILONS |
+                        props::NO_I_EPSILONS | props::O_EPSILONS | props::NO_O_EPSILONS | props::WEIGHTED | props::UNWEIGHTED;
+  for (uint64_t k = 0; k < offsets[n_states]; ++k) {
+    wfst_tr& tr = arcs[k];
+    const uint32_t oi = tr.ilabel, oo = tr.olabel;
+    if (relabel_input)
+      tr.ilabel = relabel(tr.ilabel);
+    else
+      tr.olabel = relabel(tr.olabel);
+    const uint32_t ni = tr.ilabel, no = tr.olabel;
+    if (oi != oo) p &= ~props::NOT_ACCEPTOR;
+    if (oi == 0) {
+      p &= ~props::I_EPSILONS;
+      if (oo == 0) p &= ~props::EPSILONS;
+    }
+    if (oo == 0) p &= ~props::O_EPSILONS;
+    if (ni != no) {
+      p |= props::NOT_ACCEPTOR;
+      p &= ~props::ACCEPTOR;
+    }
+    if (ni == 0) {
+      p |= props::I_EPSILONS;
+      p &= ~props::NO_I_EPSILONS;
+      if (no == 0) {
+        p |= props::EPSILONS;
+        p &= ~props::NO_EPSILONS;
+      }
+    }
+    if (no == 0) {
+      p |= props::O_EPSILONS;
+      p &= ~props::NO_O_EPSILONS;
+    }
+    p &= keep;
+  }
+  for (uint32_t s = 0; s < n_states; ++s) {
+    wfst_tr* b = arcs + offsets[s];
+    wfst_tr* e = arcs + offsets[s + 1];
+    if (relabel_input)
+      std::stable_sort(b, e, [](const wfst_tr& x, const wfst_tr& y) { return x.ilabel < y.ilabel; });
+    else
+      std::stable_sort(b, e, [](const wfst_tr& x, const wfst_tr& y) { return x.olabel < y.olabel; });
+  }
+  return tr_sort_props(p, relabel_input);
+}
+
+}  // namespace wfst

@@ -321,6 +321,78 @@ class PathList(Sequence):
             self._arr = None
 
 
+class LookAhead:
+    """Look-ahead composition set up on a first operand (wfst_lookahead_*): what the reference builds with
+    MatcherFst::new_with_relabeling + LabelLookAheadMatcher + PushLabels(PushWeights(LookAhead(AltSequence)))
+    (rustfst-cli/src/cmds/compose.rs:77-181).
+
+        la = LookAhead(fst1_on_device)           # reachability data + relabelled fst1 (MatcherFst::new)
+        fst2r = la.relabel(fst2_on_device)        # LabelLookAheadRelabeler::relabel + tr_sort(ILabelCompare)
+        out = la.compose(fst2r)                   # ComposeFst(..).compute(), not connected
+    """
+
+    def __init__(self, fst1: Optional["DeviceFst"] = None, _handle=None, _ctx=None):
+        if _handle is not None:
+            self._h, self.ctx = _handle, _ctx
+            return
+        h = C.c_void_p()
+        check(_lib.lib().wfst_lookahead_create(fst1.ctx._h, fst1._h, C.byref(h)), "wfst_lookahead_create")
+        self._h, self.ctx = h, fst1.ctx
+
+    @classmethod
+    def reachable_from_arrays(cls, n_states: int, offsets, arcs, finals, reach_input: bool = False) -> "LookAhead":
+        """Host-only handle: LabelReachable::compute_data on flat CSR arrays (no GPU); serves data() only."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        arcs = np.ascontiguousarray(arcs, dtype=TR_DTYPE)
+        finals = np.ascontiguousarray(finals, dtype=np.float32)
+        h = C.c_void_p()
+        check(_lib.lib().wfst_label_reachable_compute(n_states, offsets.ctypes.data, arcs.ctypes.data if len(arcs) else None,
+                                                      finals.ctypes.data if n_states else None, 1 if reach_input else 0,
+                                                      C.byref(h)), "wfst_label_reachable_compute")
+        return cls(_handle=h, _ctx=None)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().wfst_lookahead_destroy(h)
+            except Exception:
+                pass
+        self._h = None
+
+    @property
+    def fst1(self) -> "DeviceFst":
+        """The relabelled, olabel-sorted first operand (a view: the handle stays owned by this object)."""
+        h = C.c_void_p()
+        check(_lib.lib().wfst_lookahead_fst1(self._h, C.byref(h)), "wfst_lookahead_fst1")
+        return DeviceFst(h, self.ctx, owner=self)
+
+    def relabel(self, fst2: "DeviceFst") -> "DeviceFst":
+        out = C.c_void_p()
+        check(_lib.lib().wfst_lookahead_relabel(self._h, fst2._h, C.byref(out)), "wfst_lookahead_relabel")
+        return DeviceFst(out, fst2.ctx)
+
+    def compose(self, relabeled_fst2: "DeviceFst", ctx: Optional[Context] = None) -> "DeviceFst":
+        ctx = ctx or self.ctx
+        out = C.c_void_p()
+        check(_lib.lib().wfst_compose_lookahead(ctx._h, self._h, relabeled_fst2._h, C.byref(out)), "Error during look-ahead composition")
+        return DeviceFst(out, ctx)
+
+    def data(self) -> dict:
+        """LabelReachableData: dict(final_label, label2index {label: index}, intervals [per state list of (begin, end)])."""
+        n, ni, nl, fl = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        check(_lib.lib().wfst_lookahead_info(self._h, C.byref(n), C.byref(ni), C.byref(nl), C.byref(fl)), "wfst_lookahead_info")
+        off = np.zeros(n.value + 1, dtype=np.uint32)
+        iv = np.zeros(2 * ni.value, dtype=np.uint32)
+        labels = np.zeros(nl.value, dtype=np.uint32)
+        idx = np.zeros(nl.value, dtype=np.uint32)
+        check(_lib.lib().wfst_lookahead_download(self._h, off.ctypes.data, iv.ctypes.data if len(iv) else None,
+                                                 labels.ctypes.data if nl.value else None,
+                                                 idx.ctypes.data if nl.value else None), "wfst_lookahead_download")
+        ivs = [[(int(iv[2 * k]), int(iv[2 * k + 1])) for k in range(off[s], off[s + 1])] for s in range(n.value)]
+        return {"final_label": int(fl.value), "label2index": {int(l): int(i) for l, i in zip(labels, idx)}, "intervals": ivs}
+
+
 class ShortestPathJob:
     """A single-shortest-path solve in flight (wfst_shortest_path_begin); finish() = wfst_shortest_path_end."""
 

@@ -1016,3 +1016,85 @@ def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
         for x, out in zip(batch, outs):
             want = to_oracle(oracle, x).compose(to_oracle(oracle, t3), compose_filter=flt.value).shortest_path_canonical().to_flat()
             assert_flat_identical(out.to_flat(), want, f"mixed batch {flt.name}")
+
+
+# ------------------------------------------------------------------ §8 row A12 / N1: look-ahead composition
+def _lookahead_pair(rng, n1, n2, acyclic=False, sigma=3, p_oeps=0.45, p_ieps=0.3):
+    a = random_fst_flat(rng, n1, 3, sigma, p_eps_i=0.2, p_eps_o=p_oeps, p_final=0.3, sort="olabel", acyclic=acyclic)
+    b = random_fst_flat(rng, n2, 3, sigma, p_eps_i=p_ieps, p_eps_o=0.2, p_final=0.3, sort="ilabel", acyclic=acyclic)
+    return a, b
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_lookahead_compose_matches_oracle(gpu_ctx, oracle, seed):
+    """wfst_lookahead_create / _relabel / wfst_compose_lookahead against the oracle's restatement of the reference's
+    look-ahead configuration (cmds/compose.rs:77-181): relabelled operands, state numbering, arc order, pushed weights
+    and labels, finals and the property word are identical, on epsilon-rich cyclic and acyclic pairs."""
+    rng = np.random.default_rng(21_000 + seed)
+    a, b = _lookahead_pair(rng, int(rng.integers(1, 30)), int(rng.integers(1, 30)), acyclic=(seed % 4 == 0),
+                           sigma=int(rng.integers(2, 6)))
+    ref, r1, r2 = to_oracle(oracle, a).compose_lookahead(to_oracle(oracle, b), want_relabeled=True)
+    la = rustfst_amd.LookAhead(to_device(a))
+    assert_flat_identical(la.fst1.to_flat(), r1.to_flat(), "relabelled fst1")
+    d2 = la.relabel(to_device(b))
+    assert_flat_identical(d2.to_flat(), r2.to_flat(), "relabelled fst2")
+    out = la.compose(d2)
+    assert_flat_identical(out.to_flat(), ref.to_flat(), "look-ahead composition")
+    # and it is the same weighted relation as the plain composition: same best path weight after trimming
+    plain = to_device(a).compose(to_device(b))
+    w1, w2 = plain.shortest_path().to_flat(), out.shortest_path().to_flat()
+    tot = lambda p: None if p["n_states"] == 0 else round((float(p["arcs"]["weight"].sum()) + float(p["finals"][0])) * 1024)
+    assert tot(w1) == tot(w2)
+
+
+def _swap_labels(t):
+    """output-epsilon version of a synthetic transducer (its epsilons sit on the input side): swap the label columns and
+    re-sort by olabel"""
+    arcs = t["arcs"].copy()
+    arcs["ilabel"], arcs["olabel"] = t["arcs"]["olabel"].copy(), t["arcs"]["ilabel"].copy()
+    off = t["offsets"]
+    for s in range(t["n_states"]):
+        seg = arcs[off[s]:off[s + 1]]
+        arcs[off[s]:off[s + 1]] = seg[np.argsort(seg["olabel"], kind="stable")]
+    out = dict(t)
+    out["arcs"] = arcs
+    out["props"] = synth.O_LABEL_SORTED
+    return out
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(400, 300, 1), (1500, 800, 2), (3000, 3000, 3)])
+def test_lookahead_compose_larger(gpu_ctx, oracle, n1, n2, seed):
+    """Thousands of states per operand, 5-20 % output epsilons on fst1 (several arena growth retries, levels of
+    hundreds of arcs, pushed labels and weights on most paths)."""
+    a = _swap_labels(synth.make_transducer(n1, 3, 12, 0.2, seed=seed, p_final=0.05))
+    b = synth.make_transducer(n2, 3, 12, 0.05, seed=100 + seed, p_final=0.05)
+    ref, r1, r2 = to_oracle(oracle, a).compose_lookahead(to_oracle(oracle, b), want_relabeled=True)
+    la = rustfst_amd.LookAhead(to_device(a))
+    d2 = la.relabel(to_device(b))
+    assert_flat_identical(la.fst1.to_flat(), r1.to_flat(), "relabelled fst1")
+    assert_flat_identical(d2.to_flat(), r2.to_flat(), "relabelled fst2")
+    out = la.compose(d2)
+    assert_flat_identical(out.to_flat(), ref.to_flat(), f"look-ahead composition {n1}x{n2}")
+    # the same handle serves further second operands (labels unseen so far get fresh indices, as in the reference)
+    b2 = synth.make_transducer(50, 3, 40, 0.05, seed=500 + seed, p_final=0.1)
+    out2 = la.compose(la.relabel(to_device(b2))).to_flat()
+    assert out2["n_states"] >= 0
+
+
+def test_lookahead_compose_degenerate_and_errors(gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    a, b = _lookahead_pair(rng, 6, 6)
+    la = rustfst_amd.LookAhead(to_device(a))
+    with pytest.raises(rustfst_amd.WfstError, match="not sorted"):
+        la.compose(to_device(random_fst_flat(rng, 5, 3, 3, sort="none")))
+    # an operand without a start state: empty result with VectorFst::new() properties
+    empty = rustfst_amd.VectorFst().to_device()
+    out = la.compose(la.relabel(empty))
+    assert out.num_states == 0
+    ref = to_oracle(oracle, a).compose_lookahead(oracle.OracleFst()).to_flat()
+    assert out.to_flat()["props"] == ref["props"]
+    # fst1 without arcs / single state
+    one = random_fst_flat(rng, 1, 0, 3, p_final=1.0, sort="olabel")
+    la1 = rustfst_amd.LookAhead(to_device(one))
+    ref1 = to_oracle(oracle, one).compose_lookahead(to_oracle(oracle, b)).to_flat()
+    assert_flat_identical(la1.compose(la1.relabel(to_device(b))).to_flat(), ref1, "single-state fst1")

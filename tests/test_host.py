@@ -181,3 +181,27 @@ def test_cpp_mirror_header_compiles_and_links(tmp_path, wfst_lib):
                     os.path.join(ROOT, "examples", "reference_style_tests.cpp"), "-L", libdir, "-lwfst_amd",
                     f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-o", str(exe)], check=True)
     assert exe.exists()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_label_reachable_host_precompute_matches_oracle(wfst_lib, oracle, seed):
+    """Product host code of look-ahead composition (rustfst_amd/csrc/lookahead.cpp: LabelReachable::compute_data on flat
+    arrays, no GPU involved) against the oracle's restatement: same label -> index map (depth-first discovery order of
+    the per-label sink states), same final label, same interval sets for every state — acyclic and cyclic epsilon
+    structure (the latter through the condensation)."""
+    import rustfst_amd
+    from helpers import random_fst_flat, to_oracle
+    rng = np.random.default_rng(900 + seed)
+    f = random_fst_flat(rng, int(rng.integers(1, 60)), 4, 6, p_eps_i=0.2, p_eps_o=0.5, p_final=0.25, sort="olabel",
+                        acyclic=(seed % 3 == 0))
+    for reach_input in (False, True):
+        ref = to_oracle(oracle, f).label_reachable(reach_input)
+        la = rustfst_amd.LookAhead.reachable_from_arrays(f["n_states"], f["offsets"], f["arcs"], f["finals"], reach_input)
+        assert la.data() == ref
+        with pytest.raises(rustfst_amd.WfstError, match="host-only"):
+            la.fst1
+    bad = f["arcs"].copy()
+    if len(bad):
+        bad["nextstate"][0] = f["n_states"] + 3
+        with pytest.raises(rustfst_amd.WfstError, match="does not exist"):
+            rustfst_amd.LookAhead.reachable_from_arrays(f["n_states"], f["offsets"], bad, f["finals"])
