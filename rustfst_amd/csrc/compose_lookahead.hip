@@ -18,11 +18,26 @@
 // set of arc1's destination against the sorted arcs of arc2's destination), it rewrites arc2 (pushed weight, pushed label,
 // jump over a unique prefix arc), and the composed-state tuple is (s1, s2, fs, pushed weight, pushed label): 128 bits.
 // Lanes share the iterated side's arcs of one composed state (one item per lane); each lane walks its own matches, once
-// to count and once to write (emission order = item order, then match order); destinations are interned after the level
-// in emission order, 64 at a time: duplicates inside a chunk are folded with shuffles, the distinct keys then probe a
-// table of two 64-bit words per slot (the claim is one CAS on the first word, the second word is written by the winner
-// before anybody compares it: the wave executes the two steps in program order).
+// to count and once to write (emission order = item order, then match order).
+//
+// Two drivers over the same per-state code:
+//  * compose_lookahead_kernel: ONE wave does the whole composition (small results: no launch per level).  Destinations
+//    are interned after each level in emission order, 64 at a time: duplicates inside a chunk are folded with shuffles,
+//    the distinct keys then probe a table of two 64-bit words per slot (the claim is one CAS on the first word, the
+//    second word is written by the winner before anybody compares it: the wave executes the two steps in program order).
+//    It gives up (LA_SWITCH_WIDE) once the result passes WIDE_SWITCH_STATES states.
+//  * the wide path (la_emit / la_first / la_assign / la_patch kernels, one launch each per BFS level, the host reads back
+//    one control block per level): one wave per composed state of the level, thousands of waves in flight.  A state's
+//    arcs go to a segment reserved with one atomicAdd; every destination tuple is inserted into the table together with
+//    atomicMin(order of the emission = position of the state in the level << 32 | position of the arc in its segment);
+//    a tuple is new iff it has no id yet, its first emission is the arc whose order equals the table's minimum; firsts
+//    are counted per state, scanned over the level, and numbered = the reference's first-touch ids.  Segments are
+//    gathered into CSR order at the end.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 #include "fst_props.h"
@@ -36,7 +51,10 @@ constexpr uint32_t NO_LABEL = WFST_NO_LABEL;
 constexpr uint32_t REJECT = 0xFFFFFFFFu;
 constexpr float KDELTA_F = 1.0f / 1024.0f;  // lib.rs:269
 constexpr uint64_t K_EMPTY = ~0ull;
-enum : uint32_t { LA_OK = 0, LA_OVERFLOW_STATES = 1, LA_OVERFLOW_ARCS = 2 };
+enum : uint32_t { LA_OK = 0, LA_OVERFLOW_STATES = 1, LA_OVERFLOW_ARCS = 2, LA_SWITCH_WIDE = 3 };
+constexpr uint32_t WIDE_SWITCH_STATES = 2048;  // results larger than this are redone on the wide path
+constexpr uint64_t KHI_UNSET = ~0ull;           // second key word of a slot whose winner has not written it yet (wide path)
+constexpr uint32_t ID_UNSET = 0xFFFFFFFFu;
 
 struct LaView {
   const wfst_tr* arcs;
@@ -279,8 +297,88 @@ __device__ void equal_range(const wfst_tr* arcs, uint32_t n, bool by_ilabel, uin
   *cnt_out = lo - first;
 }
 
+// everything the expansion of ONE composed state needs (compute_trs, compose_fst_op.rs:406-418)
+struct Expand {
+  StateCtx c;
+  bool mi;                 // match_input :199-219: both matchers report priority = num_trs
+  const wfst_tr* it_arcs;  // iterated side's arcs, searched side's arcs
+  const wfst_tr* se_arcs;
+  uint32_t n_it, n_se, sa, sb;
+  float final_weight;      // compute_final_weight :420-449 after filter_final of PushWeights (:178-189) / PushLabels (:224-238)
+};
+__device__ Expand make_expand(const LaView& f1, const LaView& f2, uint64_t tlo, uint64_t thi) {
+  Expand x;
+  const uint32_t s1 = (uint32_t)(tlo >> 32), s2 = (uint32_t)tlo;
+  x.c.fs = unpack_hi(thi);
+  const uint4 r1 = f1.srec[s1], r2 = f2.srec[s2];
+  const uint32_t n1 = r1.y, n2 = r2.y;
+  const float fin1 = __uint_as_float(r1.z), fin2 = __uint_as_float(r2.z);
+  x.c.alleps2 = (r2.w & SREC_ALL_IEPS) && !(fin2 != INF);
+  x.c.noeps2 = (r2.w & SREC_NO_IEPS) != 0;
+  x.c.ntrsa = n1;
+  x.final_weight = INF;
+  if (fin1 != INF && fin2 != INF) {
+    float w1 = fin1 - x.c.fs.fweight;
+    if (x.c.fs.flabel != NO_LABEL) w1 = INF;
+    x.final_weight = wtimes(w1, fin2);
+  }
+  x.mi = n1 <= n2;
+  x.it_arcs = x.mi ? f1.arcs + r1.x : f2.arcs + r2.x;
+  x.se_arcs = x.mi ? f2.arcs + r2.x : f1.arcs + r1.x;
+  x.n_it = x.mi ? n1 : n2;
+  x.n_se = x.mi ? n2 : n1;
+  x.sa = x.mi ? s2 : s1;
+  x.sb = x.mi ? s1 : s2;
+  return x;
+}
+
+// One item (item 0 = the loop pseudo-arc of ordered_expand :229-233, item j = the j-th arc of the iterated side) against
+// everything the (multi-epsilon) matcher of the searched side yields for its label (matchers/multi_eps_matcher.rs:160-210
+// over sorted_matcher.rs:124-184): an optional EpsLoop, then the arcs carrying the pushed label (fst1 side only:
+// MULTI_EPS_LIST), then the arcs with key == label (0 for NO_LABEL).  Returns the number of pairs the filter accepts;
+// with `write`, the composed arcs (add_tr :267-285) and their destination tuples go to position write_pos onwards.
+__device__ uint32_t eval_item(const Reach& reach, const LaView& f2, const Expand& x, uint32_t j, bool write, uint32_t write_pos,
+                              wfst_tr* arcs, uint64_t* a_lo, uint64_t* a_hi) {
+  const bool mi = x.mi;
+  const ArcReg ab = j == 0 ? (mi ? ArcReg{0u, NO_LABEL, 0.0f, x.sb} : ArcReg{NO_LABEL, 0u, 0.0f, x.sb}) : load_arc(x.it_arcs + (j - 1));
+  const uint32_t label = mi ? ab.ol : ab.il;
+  const uint32_t flabel = x.c.fs.flabel;
+  uint32_t has_loop = 0, loA = 0, cntA = 0, loB = 0, cntB = 0;
+  if (label == 0u) {
+    has_loop = 1;
+    equal_range(x.se_arcs, x.n_se, mi, 0u, &loB, &cntB);
+  } else if (label == NO_LABEL) {
+    if (!mi && flabel != NO_LABEL) equal_range(x.se_arcs, x.n_se, false, flabel, &loA, &cntA);
+    equal_range(x.se_arcs, x.n_se, mi, 0u, &loB, &cntB);
+  } else if (mi && flabel != NO_LABEL && label == flabel) {
+    has_loop = 1;  // MULTI_EPS_LOOP on fst2: the pushed label behaves like an epsilon self-loop
+  } else {
+    equal_range(x.se_arcs, x.n_se, mi, label, &loB, &cntB);
+  }
+  const uint32_t n_match = has_loop + cntA + cntB;
+  uint32_t k = 0;
+  for (uint32_t m = 0; m < n_match; ++m) {
+    ArcReg aa;
+    if (m < has_loop) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, x.sa} : ArcReg{0u, NO_LABEL, 0.0f, x.sa};  // eps_loop, mod.rs:98-105
+    else if (m - has_loop < cntA) aa = load_arc(x.se_arcs + loA + (m - has_loop));
+    else aa = load_arc(x.se_arcs + loB + (m - has_loop - cntA));
+    const ArcReg a1 = mi ? ab : aa;  // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319)
+    ArcReg a2 = mi ? aa : ab;
+    FState nfs;
+    if (!la_filter(reach, f2, x.c, a1, a2, &nfs)) continue;
+    if (write) {
+      const uint32_t e = write_pos + k;
+      *reinterpret_cast<uint4*>(arcs + e) = make_uint4(a1.il, a2.ol, __float_as_uint(wtimes(a1.w, a2.w)), 0u);
+      a_lo[e] = ((uint64_t)a1.ns << 32) | a2.ns;
+      a_hi[e] = pack_hi(nfs);
+    }
+    k++;
+  }
+  return k;
+}
+
 __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView f2, Reach reach, LaCaps caps, LaArena ar,
-                                                               LaResult* __restrict__ result) {
+                                                               LaResult* __restrict__ result, uint32_t switch_states) {
   const uint32_t lane = lane_id();
   const uint32_t hmask = caps.H - 1;
   LaResult res{LA_OK, 0, 0, 0};
@@ -307,90 +405,23 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView
       const uint32_t level_begin = n_arcs;
       for (uint32_t q = lo; q < hi && ok; ++q) {
         if (lane == 0) ar.off[q] = n_arcs;
-        const uint64_t tlo = ld_l2(&ar.t_lo[q]), thi = ld_l2(&ar.t_hi[q]);
-        const uint32_t s1 = (uint32_t)(tlo >> 32), s2 = (uint32_t)tlo;
-        StateCtx c;
-        c.fs = unpack_hi(thi);
-        const uint4 r1 = f1.srec[s1], r2 = f2.srec[s2];
-        const uint32_t n1 = r1.y, n2 = r2.y;
-        const float fin1 = __uint_as_float(r1.z), fin2 = __uint_as_float(r2.z);
-        c.alleps2 = (r2.w & SREC_ALL_IEPS) && !(fin2 != INF);
-        c.noeps2 = (r2.w & SREC_NO_IEPS) != 0;
-        c.ntrsa = n1;
-        // compute_final_weight :420-449 + filter_final of PushWeights (:178-189) and PushLabels (:224-238)
-        if (lane == 0) {
-          float fw = INF;
-          if (fin1 != INF && fin2 != INF) {
-            float w1 = fin1 - c.fs.fweight;
-            if (c.fs.flabel != NO_LABEL) w1 = INF;
-            fw = wtimes(w1, fin2);
-          }
-          ar.fin[q] = fw;
-        }
-        // match_input :199-219: both matchers report priority = num_trs
-        const bool mi = n1 <= n2;
-        const wfst_tr* it_arcs = mi ? f1.arcs + r1.x : f2.arcs + r2.x;
-        const wfst_tr* se_arcs = mi ? f2.arcs + r2.x : f1.arcs + r1.x;
-        const uint32_t n_it = mi ? n1 : n2, n_se = mi ? n2 : n1;
-        const uint32_t sa = mi ? s2 : s1, sb = mi ? s1 : s2;
-        const uint32_t n_items = n_it + 1;  // item 0 = the loop pseudo-arc (ordered_expand :229-233)
-        for (uint32_t base = 0; base < n_items && ok; base += 64) {
+        const Expand x = make_expand(f1, f2, ld_l2(&ar.t_lo[q]), ld_l2(&ar.t_hi[q]));
+        if (lane == 0) ar.fin[q] = x.final_weight;
+        const uint32_t n_items = x.n_it + 1;
+        for (uint32_t base = 0; base < n_items; base += 64) {
           const uint32_t j = base + lane;
           const bool have = j < n_items;
-          ArcReg ab{0, 0, 0.0f, 0};
-          if (have) ab = j == 0 ? (mi ? ArcReg{0u, NO_LABEL, 0.0f, sb} : ArcReg{NO_LABEL, 0u, 0.0f, sb}) : load_arc(it_arcs + (j - 1));
-          // what the (multi-epsilon) matcher on the searched side yields for this item's label
-          // (matchers/multi_eps_matcher.rs:160-210 over sorted_matcher.rs:124-184): an optional EpsLoop, then the arcs
-          // carrying the pushed label (fst1 side only: MULTI_EPS_LIST), then the arcs with key == label (0 for NO_LABEL)
-          const uint32_t label = mi ? ab.ol : ab.il;
-          uint32_t has_loop = 0, loA = 0, cntA = 0, loB = 0, cntB = 0;
-          if (have) {
-            if (label == 0u) {
-              has_loop = 1;
-              equal_range(se_arcs, n_se, mi, 0u, &loB, &cntB);
-            } else if (label == NO_LABEL) {
-              if (!mi && c.fs.flabel != NO_LABEL) equal_range(se_arcs, n_se, false, c.fs.flabel, &loA, &cntA);
-              equal_range(se_arcs, n_se, mi, 0u, &loB, &cntB);
-            } else if (mi && c.fs.flabel != NO_LABEL && label == c.fs.flabel) {
-              has_loop = 1;  // MULTI_EPS_LOOP on fst2: the pushed label behaves like an epsilon self-loop
-            } else {
-              equal_range(se_arcs, n_se, mi, label, &loB, &cntB);
-            }
+          const uint32_t cnt = have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u;
+          uint32_t total;
+          const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+          if (total == 0) continue;
+          if ((uint64_t)n_arcs + total > caps.A) {
+            res.status = LA_OVERFLOW_ARCS;
+            ok = false;
+            break;
           }
-          const uint32_t n_match = has_loop + cntA + cntB;
-          uint32_t cnt = 0, pos = 0, total = 0;
-          for (int pass = 0; pass < 2; ++pass) {  // count, then write at the wave-scanned positions
-            uint32_t k = 0;
-            for (uint32_t m = 0; m < n_match; ++m) {
-              ArcReg aa;
-              if (m < has_loop) aa = mi ? ArcReg{NO_LABEL, 0u, 0.0f, sa} : ArcReg{0u, NO_LABEL, 0.0f, sa};  // eps_loop, mod.rs:98-105
-              else if (m - has_loop < cntA) aa = load_arc(se_arcs + loA + (m - has_loop));
-              else aa = load_arc(se_arcs + loB + (m - has_loop - cntA));
-              // arc1 from fst1, arc2 from fst2 (match_tr_selected :301-319)
-              const ArcReg a1 = mi ? ab : aa;
-              ArcReg a2 = mi ? aa : ab;
-              FState nfs;
-              if (!la_filter(reach, f2, c, a1, a2, &nfs)) continue;
-              if (pass == 1) {  // add_tr :267-285
-                const uint32_t e = n_arcs + pos + k;
-                *reinterpret_cast<uint4*>(ar.arcs + e) = make_uint4(a1.il, a2.ol, __float_as_uint(wtimes(a1.w, a2.w)), 0u);
-                ar.a_lo[e] = ((uint64_t)a1.ns << 32) | a2.ns;
-                ar.a_hi[e] = pack_hi(nfs);
-              }
-              k++;
-            }
-            if (pass == 0) {
-              cnt = k;
-              pos = wave_excl_scan(cnt, lane, &total);
-              if (total == 0) break;
-              if ((uint64_t)n_arcs + total > caps.A) {
-                res.status = LA_OVERFLOW_ARCS;
-                ok = false;
-                break;
-              }
-            }
-          }
-          n_arcs += ok ? total : 0u;
+          if (cnt) eval_item(reach, f2, x, j, true, n_arcs + pos, ar.arcs, ar.a_lo, ar.a_hi);
+          n_arcs += total;
         }
       }
       if (!ok) break;
@@ -458,6 +489,10 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView
       lo = hi;
       hi += n_new;
       n_states = hi;
+      if (n_states > switch_states && lo < hi) {  // a big composition: thousands of waves do it faster
+        res.status = LA_SWITCH_WIDE;
+        ok = false;
+      }
       __syncthreads();
     }
   }
@@ -465,6 +500,195 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView
   res.n_arcs = n_arcs;
   res.n_levels = n_levels;
   if (lane == 0) *result = res;
+}
+
+// ---------------------------------------------------------------- wide path: one wave per composed state of a level
+struct WideArena {
+  uint64_t* t_lo;      // [S]
+  uint64_t* t_hi;      // [S]
+  uint64_t* klo;       // [H]
+  uint64_t* khi;       // [H] KHI_UNSET until the slot's winner has written it
+  uint64_t* hord;      // [H] min over this level's emissions of (state position in the level << 32 | arc position)
+  uint32_t* hid;       // [H] state id, ID_UNSET while the tuple is new
+  wfst_tr* arcs;       // [A] segments in reservation order; nextstate = table slot until la_patch
+  uint64_t* a_lo;      // [A]
+  uint64_t* a_hi;      // [A]
+  uint32_t* seg_base;  // [S] first arc of the state's segment
+  uint32_t* seg_cnt;   // [S+1]
+  uint32_t* nfirst;    // [S+1] per state of the level: arcs that are the first emission of a new tuple
+  uint32_t* fbase;     // [S+1] exclusive scan of nfirst
+  float* fin;          // [S]
+};
+struct WideCtl {
+  uint32_t status;
+  uint32_t cursor;  // arcs reserved so far
+};
+
+__global__ void la_wide_init(WideArena ar, LaCaps caps, LaView f1, LaView f2, WideCtl* ctl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t hmask = caps.H - 1;
+  const uint64_t lo0 = ((uint64_t)(uint32_t)f1.start << 32) | (uint32_t)f2.start;
+  const uint64_t hi0 = pack_hi(FState{0u, 0.0f, NO_LABEL});
+  const uint32_t slot0 = hash_128(lo0, hi0) & hmask;
+  for (uint32_t k = i; k < caps.H; k += gridDim.x * blockDim.x) {
+    const bool s0 = k == slot0;
+    ar.klo[k] = s0 ? lo0 : K_EMPTY;
+    ar.khi[k] = s0 ? hi0 : KHI_UNSET;
+    ar.hord[k] = ~0ull;
+    ar.hid[k] = s0 ? 0u : ID_UNSET;
+  }
+  if (i == 0) {
+    ar.t_lo[0] = lo0;
+    ar.t_hi[0] = hi0;
+    ctl->status = LA_OK;
+    ctl->cursor = 0;
+  }
+}
+
+// compute_trs of every state of the level [lo, hi): arcs into a reserved segment, destinations into the table
+__global__ void __launch_bounds__(256) la_emit(LaView f1, LaView f2, Reach reach, LaCaps caps, WideArena ar, uint32_t lo,
+                                               uint32_t hi, WideCtl* ctl) {
+  const uint32_t lane = lane_id();
+  const uint32_t hmask = caps.H - 1;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+    const Expand x = make_expand(f1, f2, ar.t_lo[q], ar.t_hi[q]);
+    const uint32_t n_items = x.n_it + 1;
+    // size of the segment
+    uint32_t cnt0 = 0, seg_total = 0;
+    for (uint32_t base = 0; base < n_items; base += 64) {
+      const uint32_t j = base + lane;
+      const uint32_t cnt = j < n_items ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u;
+      if (base == 0) cnt0 = cnt;
+      uint32_t s = cnt;
+      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+      seg_total += s;
+    }
+    uint32_t seg = 0;
+    if (lane == 0) {
+      seg = seg_total ? atomicAdd(&ctl->cursor, seg_total) : 0u;
+      ar.seg_base[q] = seg;
+      ar.fin[q] = x.final_weight;
+    }
+    seg = __shfl(seg, 0);
+    const bool fits = (uint64_t)seg + seg_total <= caps.A;
+    if (lane == 0) {
+      ar.seg_cnt[q] = fits ? seg_total : 0u;
+      if (!fits) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_ARCS);
+    }
+    if (!fits || seg_total == 0) continue;
+    // the arcs, in item order
+    uint32_t running = seg;
+    for (uint32_t base = 0; base < n_items; base += 64) {
+      const uint32_t j = base + lane;
+      const bool have = j < n_items;
+      // (the first chunk's counts are still in registers; states with more than 63 arcs on the iterated side recount)
+      const uint32_t cnt = base == 0 ? cnt0 : (have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u);
+      uint32_t total;
+      const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+      if (cnt) eval_item(reach, f2, x, j, true, running + pos, ar.arcs, ar.a_lo, ar.a_hi);
+      running += total;
+    }
+    __threadfence();
+    // destinations: slot of the tuple + the order of its first emission in this level
+    for (uint32_t base = 0; base < seg_total; base += 64) {
+      const uint32_t k = base + lane;
+      const bool have = k < seg_total;
+      uint64_t klo = K_EMPTY, khi = 0;
+      if (have) {
+        klo = ld_l2(&ar.a_lo[seg + k]);
+        khi = ld_l2(&ar.a_hi[seg + k]);
+      }
+      uint32_t slot = hash_128(klo, khi) & hmask;
+      bool done = !have;
+      while (__any(!done)) {  // (no lane ever spins on another: a slot whose second word is not there yet is retried)
+        uint64_t prev = 0;
+        if (!done) prev = atomicCAS((unsigned long long*)&ar.klo[slot], (unsigned long long)K_EMPTY, (unsigned long long)klo);
+        const bool won = !done && prev == K_EMPTY;
+        if (won) st_l2(&ar.khi[slot], khi);
+        __threadfence();
+        const bool same_lo = !done && !won && prev == klo;
+        uint64_t h = KHI_UNSET;
+        if (same_lo) h = ld_l2(&ar.khi[slot]);
+        if (won || (same_lo && h == khi)) done = true;
+        else if (!done && !(same_lo && h == KHI_UNSET)) slot = (slot + 1) & hmask;
+      }
+      if (have) {
+        atomicMin((unsigned long long*)&ar.hord[slot], ((unsigned long long)(q - lo) << 32) | k);
+        ar.arcs[seg + k].nextstate = slot;
+      }
+    }
+  }
+}
+
+// per state of the level: how many of its arcs are the first emission of a tuple that has no id yet
+__global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t lo, uint32_t hi) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ar.nfirst[hi - lo] = 0;  // the scan's extra element: fbase[hi - lo] = total
+  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
+    uint32_t c = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t k = base + lane;
+      bool first = false;
+      if (k < n) {
+        const uint32_t slot = ar.arcs[seg + k].nextstate;
+        first = ld_l2(&ar.hid[slot]) == ID_UNSET && ld_l2(&ar.hord[slot]) == (((uint64_t)(q - lo) << 32) | k);
+      }
+      c += (uint32_t)__popcll(__ballot(first));
+    }
+    if (lane == 0) ar.nfirst[q - lo] = c;
+  }
+}
+
+// numbers the new tuples in emission order: id = id_base + firsts before it (StateTable::find_id, state_table.rs:49-59)
+__global__ void __launch_bounds__(256) la_assign(WideArena ar, uint32_t lo, uint32_t hi, uint32_t id_base) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
+    uint32_t next = id_base + ar.fbase[q - lo];
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t k = base + lane;
+      bool first = false;
+      uint32_t slot = 0;
+      if (k < n) {
+        slot = ar.arcs[seg + k].nextstate;
+        // same predicate as la_first: only the one arc whose order the table kept can pass it for a new tuple, and only
+        // its lane writes that tuple's id, so the ids written by other waves meanwhile do not disturb it
+        first = ld_l2(&ar.hid[slot]) == ID_UNSET && ld_l2(&ar.hord[slot]) == (((uint64_t)(q - lo) << 32) | k);
+      }
+      const uint64_t m = __ballot(first);
+      if (first) {
+        const uint32_t id = next + lanes_below(m);
+        st_l2(&ar.hid[slot], id);
+        ar.t_lo[id] = ld_l2(&ar.klo[slot]);
+        ar.t_hi[id] = ld_l2(&ar.khi[slot]);
+      }
+      next += (uint32_t)__popcll(m);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) la_patch(WideArena ar, uint32_t lo, uint32_t hi) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
+    for (uint32_t k = lane; k < n; k += 64) ar.arcs[seg + k].nextstate = ld_l2(&ar.hid[ar.arcs[seg + k].nextstate]);
+  }
+}
+
+// segments -> CSR order
+__global__ void __launch_bounds__(256) la_gather(WideArena ar, const uint32_t* __restrict__ off, wfst_tr* __restrict__ out,
+                                                 uint32_t n_states) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = wave; q < n_states; q += n_waves) {
+    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q], o = off[q];
+    for (uint32_t k = lane; k < n; k += 64) *reinterpret_cast<uint4*>(out + o + k) = *reinterpret_cast<const uint4*>(ar.arcs + seg + k);
+  }
 }
 
 size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -533,6 +757,91 @@ wfst_fst* lookahead_relabel(wfst_lookahead* la, const wfst_fst* fst2) {
   return out;
 }
 
+namespace {
+
+// the wide path: one launch set per BFS level (see the header of this file)
+wfst_fst* compose_lookahead_wide(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* f1, const wfst_fst* fst2,
+                                 uint64_t out_props, uint64_t est_s, uint64_t est_a) {
+  hipStream_t st = ctx->stream;
+  const Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
+  const LaView v1 = view_of(f1), v2 = view_of(fst2);
+  for (int attempt = 0;; ++attempt) {
+    if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose_lookahead: composition too large");
+    const LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, next_pow2(2 * est_s + 128)};
+    size_t bytes = 0;
+    auto take = [&](size_t n) {
+      const size_t o = bytes;
+      bytes += al16(n);
+      return o;
+    };
+    const size_t o_tlo = take((size_t)caps.S * 8), o_thi = take((size_t)caps.S * 8), o_klo = take((size_t)caps.H * 8),
+                 o_khi = take((size_t)caps.H * 8), o_hord = take((size_t)caps.H * 8), o_hid = take((size_t)caps.H * 4),
+                 o_arcs = take((size_t)caps.A * 16), o_alo = take((size_t)caps.A * 8), o_ahi = take((size_t)caps.A * 8),
+                 o_sb = take((size_t)caps.S * 4), o_sc = take(((size_t)caps.S + 1) * 4), o_nf = take(((size_t)caps.S + 1) * 4),
+                 o_fb = take(((size_t)caps.S + 1) * 4), o_fin = take((size_t)caps.S * 4), o_off = take(((size_t)caps.S + 1) * 4),
+                 o_out = take((size_t)caps.A * 16);
+    DBuf<char> arena(*ctx->pool, bytes);
+    DBuf<WideCtl> d_ctl(*ctx->pool, 1);
+    char* b = arena.p;
+    const WideArena ar{(uint64_t*)(b + o_tlo), (uint64_t*)(b + o_thi), (uint64_t*)(b + o_klo),  (uint64_t*)(b + o_khi),
+                       (uint64_t*)(b + o_hord), (uint32_t*)(b + o_hid), (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo),
+                       (uint64_t*)(b + o_ahi), (uint32_t*)(b + o_sb),  (uint32_t*)(b + o_sc),  (uint32_t*)(b + o_nf),
+                       (uint32_t*)(b + o_fb),  (float*)(b + o_fin)};
+    uint32_t* d_off = (uint32_t*)(b + o_off);
+    wfst_tr* d_out = (wfst_tr*)(b + o_out);
+    size_t temp_bytes = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)caps.S + 1, rocprim::plus<uint32_t>(), st));
+    DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+    struct HostCtl {
+      WideCtl ctl;
+      uint32_t n_new;
+    };
+    HostCtl* hc = (HostCtl*)ctx->pinned.get(sizeof(HostCtl));
+    const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
+    la_wide_init<<<std::min<uint32_t>(max_blocks, (caps.H + 255) / 256), 256, 0, st>>>(ar, caps, v1, v2, d_ctl.p);
+    uint32_t lo = 0, hi = 1, levels = 0;
+    bool overflow = false;
+    while (lo < hi) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
+      const uint32_t n_level = hi - lo;
+      const uint32_t blocks = std::min<uint32_t>(max_blocks, (n_level + 3) / 4);
+      la_emit<<<blocks, 256, 0, st>>>(v1, v2, reach, caps, ar, lo, hi, d_ctl.p);
+      la_first<<<blocks, 256, 0, st>>>(ar, lo, hi);
+      HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)n_level + 1, rocprim::plus<uint32_t>(), st));
+      HIP_CHECK(hipMemcpyAsync(&hc->ctl, d_ctl.p, sizeof(WideCtl), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(&hc->n_new, ar.fbase + n_level, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      levels++;
+      if (hc->ctl.status != LA_OK || (uint64_t)hi + hc->n_new > caps.S) {
+        overflow = true;
+        break;
+      }
+      la_assign<<<blocks, 256, 0, st>>>(ar, lo, hi, hi);
+      la_patch<<<blocks, 256, 0, st>>>(ar, lo, hi);
+      lo = hi;
+      hi += hc->n_new;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (!overflow) {
+      const uint32_t n_states = hi;
+      HIP_CHECK(hipMemsetAsync(ar.seg_cnt + n_states, 0, sizeof(uint32_t), st));
+      HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.seg_cnt, d_off, 0u, (size_t)n_states + 1, rocprim::plus<uint32_t>(), st));
+      la_gather<<<std::min<uint32_t>(max_blocks, (n_states + 3) / 4), 256, 0, st>>>(ar, d_off, d_out, n_states);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(st));
+      ctx->stats.compose_states = n_states;
+      ctx->stats.compose_arcs = hc->ctl.cursor;
+      return adopt_device(ctx, n_states, hc->ctl.cursor, 0, out_props, d_off, d_out, ar.fin);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    ctx->stats.compose_retries++;
+    if (attempt > 24) throw Error("compose_lookahead: arena overflow after retries");
+    est_s *= 4;
+    est_a *= 4;
+  }
+}
+
+}  // namespace
+
 wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* fst2) {
   using namespace props;
   if (!la->fst1) throw Error("compose_lookahead: the look-ahead handle has no device FST (host-only handle)");
@@ -550,9 +859,12 @@ wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_
     return make_host_fst(ctx, 0, -1, out_props, std::move(h));
   }
   hipStream_t st = ctx->stream;
-  uint64_t est_s = 4ull * std::max<uint64_t>(std::max(f1->n_states, fst2->n_states), 64) + 1024;
+  int force = 0;  // WFST_LOOKAHEAD_PATH=wave|wide pins one driver (tests)
+  if (const char* e = std::getenv("WFST_LOOKAHEAD_PATH")) force = std::strcmp(e, "wide") == 0 ? 2 : (std::strcmp(e, "wave") == 0 ? 1 : 0);
+  uint64_t est_s = force == 1 ? 4ull * std::max<uint64_t>(std::max(f1->n_states, fst2->n_states), 64) + 1024
+                              : 2ull * WIDE_SWITCH_STATES + 256;  // the single wave stops soon after WIDE_SWITCH_STATES
   uint64_t est_a = 4ull * est_s;
-  for (int attempt = 0;; ++attempt) {
+  for (int attempt = 0; force != 2; ++attempt) {
     if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose_lookahead: composition too large");
     LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, next_pow2(2 * est_s + 128)};
     size_t bytes = 0;
@@ -573,7 +885,7 @@ wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_
                (uint32_t*)(b + o_hv),  (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo), (uint64_t*)(b + o_ahi),
                (uint32_t*)(b + o_off), (float*)(b + o_fin)};
     Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
-    compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), view_of(fst2), reach, caps, ar, d_res.p);
+    compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), view_of(fst2), reach, caps, ar, d_res.p, force == 1 ? 0xFFFFFFFFu : WIDE_SWITCH_STATES);
     HIP_CHECK(hipGetLastError());
     LaResult r;
     HIP_CHECK(hipMemcpyAsync(&r, d_res.p, sizeof(r), hipMemcpyDeviceToHost, st));
@@ -582,11 +894,14 @@ wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_
     ctx->stats.compose_arcs = r.n_arcs;
     if (r.status == LA_OK)
       return adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1, out_props, ar.off, ar.arcs, ar.fin);
+    if (r.status == LA_SWITCH_WIDE) break;
     ctx->stats.compose_retries++;
     if (attempt > 24) throw Error("compose_lookahead: arena overflow after retries");
     est_s *= 4;
     est_a *= 4;
   }
+  const uint64_t ws = 8ull * std::max<uint64_t>(std::max(f1->n_states, fst2->n_states), 4096);
+  return compose_lookahead_wide(ctx, la, f1, fst2, out_props, ws, 4 * ws);
 }
 
 }  // namespace wfst

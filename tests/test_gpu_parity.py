@@ -1025,6 +1025,21 @@ def _lookahead_pair(rng, n1, n2, acyclic=False, sigma=3, p_oeps=0.45, p_ieps=0.3
     return a, b
 
 
+@pytest.mark.parametrize("path", ["wave", "wide"])
+@pytest.mark.parametrize("seed", range(24))
+def test_lookahead_compose_both_drivers(gpu_ctx, oracle, monkeypatch, seed, path):
+    """The single-wave kernel and the level-per-launch wide path (one wave per composed state, tuples interned through
+    atomicMin of their emission order) give the oracle's FST bit for bit on the same inputs."""
+    monkeypatch.setenv("WFST_LOOKAHEAD_PATH", path)
+    rng = np.random.default_rng(31_000 + seed)
+    a, b = _lookahead_pair(rng, int(rng.integers(1, 60)), int(rng.integers(1, 40)), acyclic=(seed % 5 == 0),
+                           sigma=int(rng.integers(2, 5)), p_oeps=0.5 if seed % 2 else 0.3)
+    ref = to_oracle(oracle, a).compose_lookahead(to_oracle(oracle, b))
+    la = rustfst_amd.LookAhead(to_device(a))
+    out = la.compose(la.relabel(to_device(b)))
+    assert_flat_identical(out.to_flat(), ref.to_flat(), f"look-ahead composition on the {path} path")
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_lookahead_compose_matches_oracle(gpu_ctx, oracle, seed):
     """wfst_lookahead_create / _relabel / wfst_compose_lookahead against the oracle's restatement of the reference's
@@ -1062,23 +1077,25 @@ def _swap_labels(t):
     return out
 
 
-@pytest.mark.parametrize("n1,n2,seed", [(400, 300, 1), (1500, 800, 2), (3000, 3000, 3)])
-def test_lookahead_compose_larger(gpu_ctx, oracle, n1, n2, seed):
-    """Thousands of states per operand, 5-20 % output epsilons on fst1 (several arena growth retries, levels of
-    hundreds of arcs, pushed labels and weights on most paths)."""
-    a = _swap_labels(synth.make_transducer(n1, 3, 12, 0.2, seed=seed, p_final=0.05))
-    b = synth.make_transducer(n2, 3, 12, 0.05, seed=100 + seed, p_final=0.05)
+@pytest.mark.parametrize("n1,n2,fan2,sigma,seed", [(300, 20, 8, 8, 1), (700, 30, 10, 10, 3), (2000, 50, 12, 12, 3)])
+def test_lookahead_compose_larger(gpu_ctx, oracle, n1, n2, fan2, sigma, seed):
+    """Compositions of 7 k ... 120 k states: fst1 with 20 % output epsilons, fst2 with about as many arcs per state as
+    there are labels, so most labels match somewhere (several arena growth retries, levels of thousands of arcs, pushed
+    labels and weights on most paths)."""
+    a = _swap_labels(synth.make_transducer(n1, 3, sigma, 0.2, seed=seed, p_final=0.05))
+    b = synth.make_transducer(n2, fan2, sigma, 0.05, seed=100 + seed, p_final=0.05)
     ref, r1, r2 = to_oracle(oracle, a).compose_lookahead(to_oracle(oracle, b), want_relabeled=True)
     la = rustfst_amd.LookAhead(to_device(a))
     d2 = la.relabel(to_device(b))
     assert_flat_identical(la.fst1.to_flat(), r1.to_flat(), "relabelled fst1")
     assert_flat_identical(d2.to_flat(), r2.to_flat(), "relabelled fst2")
     out = la.compose(d2)
+    assert out.num_states > 2048  # beyond the single-wave driver: redone on the wide path
     assert_flat_identical(out.to_flat(), ref.to_flat(), f"look-ahead composition {n1}x{n2}")
     # the same handle serves further second operands (labels unseen so far get fresh indices, as in the reference)
     b2 = synth.make_transducer(50, 3, 40, 0.05, seed=500 + seed, p_final=0.1)
     out2 = la.compose(la.relabel(to_device(b2))).to_flat()
-    assert out2["n_states"] >= 0
+    assert out2["n_states"] >= 1
 
 
 def test_lookahead_compose_degenerate_and_errors(gpu_ctx, oracle):
