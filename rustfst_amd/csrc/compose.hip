@@ -1395,7 +1395,10 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
   descs[0].mode = mode;
   descs[0].filter = filter;
   const FstView v2 = view_of(f2);
-  uint64_t est_s = 4ull * std::max<uint64_t>(f1->n_states, 64) + 1024;
+  // first guess from the SMALLER operand (acceptor o transducer lattices are a few times the acceptor; the arena and its
+  // hash table are cleared per attempt, so a guess from a 5M-state operand costs tens of ms before any work): larger
+  // results retry with 4x
+  uint64_t est_s = 4ull * std::max<uint64_t>(std::min(f1->n_states, f2->n_states), 64) + 1024;
   uint64_t est_a = 4ull * est_s;
   for (int attempt = 0;; ++attempt) {
     Caps caps = make_caps(est_s, est_a);

@@ -336,9 +336,14 @@ __device__ Expand make_expand(const LaView& f1, const LaView& f2, uint64_t tlo, 
 // everything the (multi-epsilon) matcher of the searched side yields for its label (matchers/multi_eps_matcher.rs:160-210
 // over sorted_matcher.rs:124-184): an optional EpsLoop, then the arcs carrying the pushed label (fst1 side only:
 // MULTI_EPS_LIST), then the arcs with key == label (0 for NO_LABEL).  Returns the number of pairs the filter accepts;
-// with `write`, the composed arcs (add_tr :267-285) and their destination tuples go to position write_pos onwards.
+// with `write`, the composed arcs (add_tr :267-285) and their destination tuples go to position write_pos onwards;
+// without, the first accepted pair is returned in *first.
+struct Emitted {  // a composed arc and its destination tuple
+  uint4 arc;
+  uint64_t lo, hi;
+};
 __device__ uint32_t eval_item(const Reach& reach, const LaView& f2, const Expand& x, uint32_t j, bool write, uint32_t write_pos,
-                              wfst_tr* arcs, uint64_t* a_lo, uint64_t* a_hi) {
+                              wfst_tr* arcs, uint64_t* a_lo, uint64_t* a_hi, Emitted* first = nullptr) {
   const bool mi = x.mi;
   const ArcReg ab = j == 0 ? (mi ? ArcReg{0u, NO_LABEL, 0.0f, x.sb} : ArcReg{NO_LABEL, 0u, 0.0f, x.sb}) : load_arc(x.it_arcs + (j - 1));
   const uint32_t label = mi ? ab.ol : ab.il;
@@ -366,11 +371,17 @@ __device__ uint32_t eval_item(const Reach& reach, const LaView& f2, const Expand
     ArcReg a2 = mi ? aa : ab;
     FState nfs;
     if (!la_filter(reach, f2, x.c, a1, a2, &nfs)) continue;
+    const uint4 arc = make_uint4(a1.il, a2.ol, __float_as_uint(wtimes(a1.w, a2.w)), 0u);
+    const uint64_t dlo = ((uint64_t)a1.ns << 32) | a2.ns, dhi = pack_hi(nfs);
     if (write) {
       const uint32_t e = write_pos + k;
-      *reinterpret_cast<uint4*>(arcs + e) = make_uint4(a1.il, a2.ol, __float_as_uint(wtimes(a1.w, a2.w)), 0u);
-      a_lo[e] = ((uint64_t)a1.ns << 32) | a2.ns;
-      a_hi[e] = pack_hi(nfs);
+      *reinterpret_cast<uint4*>(arcs + e) = arc;
+      a_lo[e] = dlo;
+      a_hi[e] = dhi;
+    } else if (first && k == 0) {  // most items emit one arc: the counting pass keeps it, the writing pass is skipped
+      first->arc = arc;
+      first->lo = dlo;
+      first->hi = dhi;
     }
     k++;
   }
@@ -411,7 +422,8 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView
         for (uint32_t base = 0; base < n_items; base += 64) {
           const uint32_t j = base + lane;
           const bool have = j < n_items;
-          const uint32_t cnt = have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u;
+          Emitted em;
+          const uint32_t cnt = have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u;
           uint32_t total;
           const uint32_t pos = wave_excl_scan(cnt, lane, &total);
           if (total == 0) continue;
@@ -420,7 +432,13 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView
             ok = false;
             break;
           }
-          if (cnt) eval_item(reach, f2, x, j, true, n_arcs + pos, ar.arcs, ar.a_lo, ar.a_hi);
+          if (cnt == 1) {
+            *reinterpret_cast<uint4*>(ar.arcs + n_arcs + pos) = em.arc;
+            ar.a_lo[n_arcs + pos] = em.lo;
+            ar.a_hi[n_arcs + pos] = em.hi;
+          } else if (cnt) {
+            eval_item(reach, f2, x, j, true, n_arcs + pos, ar.arcs, ar.a_lo, ar.a_hi);
+          }
           n_arcs += total;
         }
       }
@@ -556,10 +574,15 @@ __global__ void __launch_bounds__(256) la_emit(LaView f1, LaView f2, Reach reach
     const uint32_t n_items = x.n_it + 1;
     // size of the segment
     uint32_t cnt0 = 0, seg_total = 0;
+    Emitted em0;
     for (uint32_t base = 0; base < n_items; base += 64) {
       const uint32_t j = base + lane;
-      const uint32_t cnt = j < n_items ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u;
-      if (base == 0) cnt0 = cnt;
+      Emitted em;
+      const uint32_t cnt = j < n_items ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u;
+      if (base == 0) {
+        cnt0 = cnt;
+        em0 = em;
+      }
       uint32_t s = cnt;
       for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
       seg_total += s;
@@ -583,10 +606,17 @@ __global__ void __launch_bounds__(256) la_emit(LaView f1, LaView f2, Reach reach
       const uint32_t j = base + lane;
       const bool have = j < n_items;
       // (the first chunk's counts are still in registers; states with more than 63 arcs on the iterated side recount)
-      const uint32_t cnt = base == 0 ? cnt0 : (have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr) : 0u);
+      Emitted em = em0;
+      const uint32_t cnt = base == 0 ? cnt0 : (have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u);
       uint32_t total;
       const uint32_t pos = wave_excl_scan(cnt, lane, &total);
-      if (cnt) eval_item(reach, f2, x, j, true, running + pos, ar.arcs, ar.a_lo, ar.a_hi);
+      if (cnt == 1) {
+        *reinterpret_cast<uint4*>(ar.arcs + running + pos) = em.arc;
+        ar.a_lo[running + pos] = em.lo;
+        ar.a_hi[running + pos] = em.hi;
+      } else if (cnt) {
+        eval_item(reach, f2, x, j, true, running + pos, ar.arcs, ar.a_lo, ar.a_hi);
+      }
       running += total;
     }
     __threadfence();

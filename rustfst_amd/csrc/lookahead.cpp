@@ -8,6 +8,9 @@
 // of the transformed FST discovers the per-label sink states, so the visit order is reproduced exactly; everything
 // works on flat CSR arrays with explicit stacks (decoding graphs have millions of states).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -218,6 +221,12 @@ void state_reachable(const Graph& g, std::vector<Intervals>& sets, std::vector<u
 // LabelReachable::compute_data (label_reachable.rs:135-150) = transform_fst (:172-248) + find_intervals (:250-273)
 void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const wfst_tr* arcs, const float* finals,
                              bool reach_input_) {
+  const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t_begin = now();
   reach_input = reach_input_;
   final_label = NO_LABEL;
   label2index.clear();
@@ -257,9 +266,11 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
   for (uint32_t s = ins; s < ons; ++s) g.is_final[s] = 1;
   g.start = start;
 
+  const auto t_graph = now();
   std::vector<Intervals> sets;
   std::vector<uint32_t> state2index;
   state_reachable(g, sets, state2index);
+  const auto t_reach = now();
 
   iv_off.assign((size_t)ins + 1, 0);
   iv.clear();
@@ -275,6 +286,9 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
     label2index[sink_label[k]] = idx;
     if (sink_label[k] == NO_LABEL) final_label = idx;
   }
+  if (timing)
+    std::fprintf(stderr, "[wfst] label reachability of %u states: graph %.1f ms, intervals %.1f ms, flatten %.1f ms\n", ins,
+                 ms(t_begin, t_graph), ms(t_graph, t_reach), ms(t_reach, now()));
 }
 
 uint32_t LabelReachData::relabel(uint32_t label) {  // label_reachable.rs:52-61
