@@ -166,6 +166,11 @@ wfst_status wfst_lookahead_create(wfst_ctx* ctx, const wfst_fst* fst1, wfst_look
 wfst_status wfst_lookahead_relabel(wfst_lookahead* la, const wfst_fst* fst2, wfst_fst** out);
 wfst_status wfst_lookahead_fst1(const wfst_lookahead* la, const wfst_fst** out);
 wfst_status wfst_compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* relabeled_fst2, wfst_fst** out);
+/* n independent look-ahead compositions against the same first operand in ONE launch (one wavefront per problem, like
+ * wfst_compose_shortest_path_batch); outs[i] == wfst_compose_lookahead(ctx, la, relabeled_fst2s[i]).  On KO no output is
+ * left allocated. */
+wfst_status wfst_compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* const* relabeled_fst2s,
+                                         size_t n, wfst_fst** outs);
 wfst_status wfst_lookahead_destroy(wfst_lookahead* la);
 /* LabelReachableData of a look-ahead handle: sizes, then the arrays (interval_offsets[n_states + 1], intervals[2 *
  * n_intervals] = half-open [begin, end) pairs over relabelled labels, labels[n_labels] ascending with their indices;

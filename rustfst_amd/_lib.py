@@ -60,6 +60,7 @@ SYMBOLS = [
     ("wfst_lookahead_relabel", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_lookahead_fst1", C.c_int, [_vp, _P(_vp)]),
     ("wfst_compose_lookahead", C.c_int, [_vp, _vp, _vp, _P(_vp)]),
+    ("wfst_compose_lookahead_batch", C.c_int, [_vp, _vp, _P(_vp), _sz, _P(_vp)]),
     ("wfst_lookahead_destroy", C.c_int, [_vp]),
     ("wfst_lookahead_info", C.c_int, [_vp, _P(_u32), _P(_u64), _P(_u32), _P(_u32)]),
     ("wfst_lookahead_download", C.c_int, [_vp, _vp, _vp, _vp, _vp]),

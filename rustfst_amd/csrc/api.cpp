@@ -385,6 +385,15 @@ wfst_status wfst_compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, cons
   });
 }
 
+wfst_status wfst_compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* const* relabeled_fst2s,
+                                         size_t n, wfst_fst** outs) {
+  return wrap([&] {
+    if (!ctx || !la || (n && (!relabeled_fst2s || !outs))) throw Error("null pointer");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    compose_lookahead_batch(ctx, la, relabeled_fst2s, n, outs);
+  });
+}
+
 wfst_status wfst_lookahead_destroy(wfst_lookahead* la) {
   return wrap([&] {
     if (!la) return;

@@ -80,6 +80,24 @@ struct LaArena {
 struct LaResult {
   uint32_t status, n_states, n_arcs, n_levels;
 };
+__host__ __device__ inline size_t la_al16(size_t x) { return (x + 15) & ~(size_t)15; }
+// one problem's arena of the single-wave kernel (a batch = `stride` bytes apart)
+__host__ __device__ inline LaArena la_carve(char* b, const LaCaps& c, size_t* bytes_out) {
+  size_t o = 0;
+  LaArena a;
+  a.t_lo = (uint64_t*)(b + o); o += la_al16((size_t)c.S * 8);
+  a.t_hi = (uint64_t*)(b + o); o += la_al16((size_t)c.S * 8);
+  a.klo = (uint64_t*)(b + o); o += la_al16((size_t)c.H * 8);
+  a.khi = (uint64_t*)(b + o); o += la_al16((size_t)c.H * 8);
+  a.hvals = (uint32_t*)(b + o); o += la_al16((size_t)c.H * 4);
+  a.arcs = (wfst_tr*)(b + o); o += la_al16((size_t)c.A * 16);
+  a.a_lo = (uint64_t*)(b + o); o += la_al16((size_t)c.A * 8);
+  a.a_hi = (uint64_t*)(b + o); o += la_al16((size_t)c.A * 8);
+  a.off = (uint32_t*)(b + o); o += la_al16((size_t)(c.S + 1) * 4);
+  a.fin = (float*)(b + o); o += la_al16((size_t)c.S * 4);
+  if (bytes_out) *bytes_out = (o + 255) & ~(size_t)255;
+  return a;
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -388,8 +406,13 @@ __device__ uint32_t eval_item(const Reach& reach, const LaView& f2, const Expand
   return k;
 }
 
-__global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, LaView f2, Reach reach, LaCaps caps, LaArena ar,
-                                                               LaResult* __restrict__ result, uint32_t switch_states) {
+// one wave = one (fst1, fst2[p]) problem; fst1 and its reachability data are shared by the batch
+__global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const LaView* __restrict__ f2s, Reach reach, LaCaps caps,
+                                                               char* __restrict__ arena_base, size_t arena_stride,
+                                                               LaResult* __restrict__ results, uint32_t switch_states) {
+  const LaView f2 = f2s[blockIdx.x];
+  const LaArena ar = la_carve(arena_base + (size_t)blockIdx.x * arena_stride, caps, nullptr);
+  LaResult* result = results + blockIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t hmask = caps.H - 1;
   LaResult res{LA_OK, 0, 0, 0};
@@ -872,66 +895,127 @@ wfst_fst* compose_lookahead_wide(wfst_ctx* ctx, const wfst_lookahead* la, const 
 
 }  // namespace
 
-wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* fst2) {
+namespace {
+void check_lookahead_operands(const wfst_lookahead* la, const wfst_fst* fst2) {
   using namespace props;
   if (!la->fst1) throw Error("compose_lookahead: the look-ahead handle has no device FST (host-only handle)");
-  const wfst_fst* f1 = la->fst1;
   // SortedMatcher(fst1, MatchOutput) and reach_init (label_reachable.rs:275-291) need the sorted bits
-  if (!(f1->props & O_LABEL_SORTED)) throw Error("compose_lookahead: the 1st FST is not sorted on output labels");
+  if (!(la->fst1->props & O_LABEL_SORTED)) throw Error("compose_lookahead: the 1st FST is not sorted on output labels");
   if (!(fst2->props & I_LABEL_SORTED)) throw Error("LabelReachable::ReachInit: Fst is not sorted");
+}
+}  // namespace
+
+// n problems (la's fst1, fst2s[i]) in one launch of the single-wave kernel, one wave each; results that outgrow it (or its
+// arena) are redone one by one: bigger arena, then the wide path
+void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* const* fst2s, size_t n, wfst_fst** outs) {
+  for (size_t i = 0; i < n; ++i) {
+    outs[i] = nullptr;
+    if (!fst2s[i]) throw Error("null pointer");
+    check_lookahead_operands(la, fst2s[i]);
+  }
+  const wfst_fst* f1 = la->fst1;
   ensure_device(const_cast<wfst_fst*>(f1));
-  ensure_device(const_cast<wfst_fst*>(fst2));
-  const bool has_start = f1->start >= 0 && fst2->start >= 0;
-  const uint64_t out_props = lookahead_result_props(f1->props, fst2->props, has_start);
-  if (!has_start) {
-    HostCsr h;
-    h.offsets.push_back(0);
-    return make_host_fst(ctx, 0, -1, out_props, std::move(h));
-  }
   hipStream_t st = ctx->stream;
-  int force = 0;  // WFST_LOOKAHEAD_PATH=wave|wide pins one driver (tests)
-  if (const char* e = std::getenv("WFST_LOOKAHEAD_PATH")) force = std::strcmp(e, "wide") == 0 ? 2 : (std::strcmp(e, "wave") == 0 ? 1 : 0);
-  uint64_t est_s = force == 1 ? 4ull * std::max<uint64_t>(std::max(f1->n_states, fst2->n_states), 64) + 1024
-                              : 2ull * WIDE_SWITCH_STATES + 256;  // the single wave stops soon after WIDE_SWITCH_STATES
-  uint64_t est_a = 4ull * est_s;
-  for (int attempt = 0; force != 2; ++attempt) {
-    if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose_lookahead: composition too large");
-    LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, next_pow2(2 * est_s + 128)};
-    size_t bytes = 0;
-    const size_t o_tlo = bytes; bytes += al16((size_t)caps.S * 8);
-    const size_t o_thi = bytes; bytes += al16((size_t)caps.S * 8);
-    const size_t o_klo = bytes; bytes += al16((size_t)caps.H * 8);
-    const size_t o_khi = bytes; bytes += al16((size_t)caps.H * 8);
-    const size_t o_hv = bytes; bytes += al16((size_t)caps.H * 4);
-    const size_t o_arcs = bytes; bytes += al16((size_t)caps.A * 16);
-    const size_t o_alo = bytes; bytes += al16((size_t)caps.A * 8);
-    const size_t o_ahi = bytes; bytes += al16((size_t)caps.A * 8);
-    const size_t o_off = bytes; bytes += al16((size_t)(caps.S + 1) * 4);
-    const size_t o_fin = bytes; bytes += al16((size_t)caps.S * 4);
-    DBuf<char> arena(*ctx->pool, bytes);
-    DBuf<LaResult> d_res(*ctx->pool, 1);
-    char* b = arena.p;
-    LaArena ar{(uint64_t*)(b + o_tlo), (uint64_t*)(b + o_thi), (uint64_t*)(b + o_klo), (uint64_t*)(b + o_khi),
-               (uint32_t*)(b + o_hv),  (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo), (uint64_t*)(b + o_ahi),
-               (uint32_t*)(b + o_off), (float*)(b + o_fin)};
-    Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
-    compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), view_of(fst2), reach, caps, ar, d_res.p, force == 1 ? 0xFFFFFFFFu : WIDE_SWITCH_STATES);
-    HIP_CHECK(hipGetLastError());
-    LaResult r;
-    HIP_CHECK(hipMemcpyAsync(&r, d_res.p, sizeof(r), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    ctx->stats.compose_states = r.n_states;
-    ctx->stats.compose_arcs = r.n_arcs;
-    if (r.status == LA_OK)
-      return adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1, out_props, ar.off, ar.arcs, ar.fin);
-    if (r.status == LA_SWITCH_WIDE) break;
-    ctx->stats.compose_retries++;
-    if (attempt > 24) throw Error("compose_lookahead: arena overflow after retries");
-    est_s *= 4;
-    est_a *= 4;
+  std::vector<size_t> todo;
+  std::vector<LaView> views;
+  std::vector<std::unique_ptr<wfst_fst>> done(n);
+  try {
+    for (size_t i = 0; i < n; ++i) {
+      ensure_device(const_cast<wfst_fst*>(fst2s[i]));
+      const bool has_start = f1->start >= 0 && fst2s[i]->start >= 0;
+      if (!has_start) {
+        HostCsr h;
+        h.offsets.push_back(0);
+        done[i].reset(make_host_fst(ctx, 0, -1, lookahead_result_props(f1->props, fst2s[i]->props, false), std::move(h)));
+      } else {
+        todo.push_back(i);
+        views.push_back(view_of(fst2s[i]));
+      }
+    }
+    int force = 0;  // WFST_LOOKAHEAD_PATH=wave|wide pins one driver (tests)
+    if (const char* e = std::getenv("WFST_LOOKAHEAD_PATH")) force = std::strcmp(e, "wide") == 0 ? 2 : (std::strcmp(e, "wave") == 0 ? 1 : 0);
+    std::vector<size_t> redo;  // indices into todo
+    if (!todo.empty() && force != 2) {
+      const uint64_t est_s = 2ull * WIDE_SWITCH_STATES + 256;  // the single wave stops soon after WIDE_SWITCH_STATES
+      const LaCaps caps{(uint32_t)est_s, (uint32_t)(4 * est_s), next_pow2(2 * est_s + 128)};
+      size_t stride = 0;
+      la_carve(nullptr, caps, &stride);
+      const size_t m = todo.size();
+      DBuf<char> arena(*ctx->pool, stride * m);
+      DBuf<LaView> d_views(*ctx->pool, m);
+      DBuf<LaResult> d_res(*ctx->pool, m);
+      HIP_CHECK(hipMemcpyAsync(d_views.p, views.data(), m * sizeof(LaView), hipMemcpyHostToDevice, st));
+      const Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
+      compose_lookahead_kernel<<<(uint32_t)m, 64, 0, st>>>(view_of(f1), d_views.p, reach, caps, arena.p, stride, d_res.p,
+                                                            force == 1 ? 0xFFFFFFFFu : WIDE_SWITCH_STATES);
+      HIP_CHECK(hipGetLastError());
+      std::vector<LaResult> res(m);
+      HIP_CHECK(hipMemcpyAsync(res.data(), d_res.p, m * sizeof(LaResult), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (size_t k = 0; k < m; ++k) {
+        const size_t i = todo[k];
+        const LaResult& r = res[k];
+        if (r.status != LA_OK) {
+          redo.push_back(k);
+          continue;
+        }
+        const LaArena ar = la_carve(arena.p + k * stride, caps, nullptr);
+        done[i].reset(adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1,
+                                   lookahead_result_props(f1->props, fst2s[i]->props, true), ar.off, ar.arcs, ar.fin));
+        ctx->stats.compose_states = r.n_states;
+        ctx->stats.compose_arcs = r.n_arcs;
+      }
+    } else {
+      for (size_t k = 0; k < todo.size(); ++k) redo.push_back(k);
+    }
+    for (size_t k : redo) {
+      const size_t i = todo[k];
+      const wfst_fst* fst2 = fst2s[i];
+      const uint64_t out_props = lookahead_result_props(f1->props, fst2->props, true);
+      if (force == 1) {  // pinned to the single wave: grow its arena until the result fits
+        uint64_t est_s = 16ull * WIDE_SWITCH_STATES;
+        for (int attempt = 0;; ++attempt) {
+          if (est_s > 0x1FFFFFF0ull) throw Error("compose_lookahead: composition too large");
+          const LaCaps caps{(uint32_t)est_s, (uint32_t)(4 * est_s), next_pow2(2 * est_s + 128)};
+          size_t stride = 0;
+          la_carve(nullptr, caps, &stride);
+          DBuf<char> arena(*ctx->pool, stride);
+          DBuf<LaView> d_view(*ctx->pool, 1);
+          DBuf<LaResult> d_res(*ctx->pool, 1);
+          const LaView v = view_of(fst2);
+          HIP_CHECK(hipMemcpyAsync(d_view.p, &v, sizeof(LaView), hipMemcpyHostToDevice, st));
+          const Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
+          compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), d_view.p, reach, caps, arena.p, stride, d_res.p, 0xFFFFFFFFu);
+          HIP_CHECK(hipGetLastError());
+          LaResult r;
+          HIP_CHECK(hipMemcpyAsync(&r, d_res.p, sizeof(r), hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+          if (r.status == LA_OK) {
+            const LaArena ar = la_carve(arena.p, caps, nullptr);
+            done[i].reset(adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1, out_props, ar.off, ar.arcs, ar.fin));
+            ctx->stats.compose_states = r.n_states;
+            ctx->stats.compose_arcs = r.n_arcs;
+            break;
+          }
+          ctx->stats.compose_retries++;
+          if (attempt > 24) throw Error("compose_lookahead: arena overflow after retries");
+          est_s *= 4;
+        }
+      } else {
+        const uint64_t ws = 8ull * std::max<uint64_t>(std::min(f1->n_states, fst2->n_states), 4096);
+        done[i].reset(compose_lookahead_wide(ctx, la, f1, fst2, out_props, ws, 4 * ws));
+      }
+    }
+  } catch (...) {
+    throw;  // (done[] frees what was built)
   }
-  const uint64_t ws = 8ull * std::max<uint64_t>(std::max(f1->n_states, fst2->n_states), 4096);
-  return compose_lookahead_wide(ctx, la, f1, fst2, out_props, ws, 4 * ws);
+  for (size_t i = 0; i < n; ++i) outs[i] = done[i].release();
+}
+
+wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* fst2) {
+  wfst_fst* out = nullptr;
+  compose_lookahead_batch(ctx, la, &fst2, 1, &out);
+  return out;
 }
 
 }  // namespace wfst

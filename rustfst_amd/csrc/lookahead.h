@@ -39,4 +39,5 @@ namespace wfst {
 wfst_lookahead* lookahead_create(wfst_ctx* ctx, const wfst_fst* fst1);
 wfst_fst* lookahead_relabel(wfst_lookahead* la, const wfst_fst* fst2);
 wfst_fst* compose_lookahead(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* fst2);
+void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst_fst* const* fst2s, size_t n, wfst_fst** outs);
 }  // namespace wfst

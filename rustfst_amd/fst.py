@@ -378,6 +378,15 @@ class LookAhead:
         check(_lib.lib().wfst_compose_lookahead(ctx._h, self._h, relabeled_fst2._h, C.byref(out)), "Error during look-ahead composition")
         return DeviceFst(out, ctx)
 
+    def compose_batch(self, relabeled_fst2s: Sequence["DeviceFst"], ctx: Optional[Context] = None) -> List["DeviceFst"]:
+        """n look-ahead compositions against this first operand in one launch (wfst_compose_lookahead_batch)."""
+        ctx = ctx or self.ctx
+        n = len(relabeled_fst2s)
+        arr = (C.c_void_p * n)(*[f._h for f in relabeled_fst2s])
+        outs = (C.c_void_p * n)()
+        check(_lib.lib().wfst_compose_lookahead_batch(ctx._h, self._h, arr, n, outs), "Error during look-ahead composition")
+        return [DeviceFst(C.c_void_p(outs[i]), ctx) for i in range(n)]
+
     def data(self) -> dict:
         """LabelReachableData: dict(final_label, label2index {label: index}, intervals [per state list of (begin, end)])."""
         n, ni, nl, fl = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()

@@ -1115,3 +1115,25 @@ def test_lookahead_compose_degenerate_and_errors(gpu_ctx, oracle):
     la1 = rustfst_amd.LookAhead(to_device(one))
     ref1 = to_oracle(oracle, one).compose_lookahead(to_oracle(oracle, b)).to_flat()
     assert_flat_identical(la1.compose(la1.relabel(to_device(b))).to_flat(), ref1, "single-state fst1")
+
+
+def test_lookahead_compose_batch(gpu_ctx, oracle):
+    """wfst_compose_lookahead_batch: 40 second operands against one look-ahead handle in a single launch (one wave per
+    problem) == the one-by-one calls == the oracle; a problem that outgrows the single wave is redone on the wide path,
+    operands without a start state give the empty FST."""
+    rng = np.random.default_rng(77)
+    a = _swap_labels(synth.make_transducer(300, 3, 8, 0.2, seed=1, p_final=0.05))
+    la = rustfst_amd.LookAhead(to_device(a))
+    oa = to_oracle(oracle, a)
+    bs = [random_fst_flat(rng, int(rng.integers(1, 12)), 3, 8, p_eps_i=0.2, p_eps_o=0.1, p_final=0.4, sort="ilabel") for _ in range(38)]
+    bs.append(synth.make_transducer(20, 8, 8, 0.05, seed=101, p_final=0.05))  # 7 k composed states: wide path
+    d2 = [la.relabel(to_device(b)) for b in bs] + [la.relabel(rustfst_amd.VectorFst().to_device())]
+    outs = la.compose_batch(d2)
+    assert len(outs) == 40 and outs[-1].num_states == 0
+    assert outs[38].num_states > 2048
+    for i, b in enumerate(bs):
+        ref = oa.compose_lookahead(to_oracle(oracle, b)).to_flat()
+        assert_flat_identical(outs[i].to_flat(), ref, f"batched look-ahead composition {i}")
+    for i in (0, 7, 38):
+        assert_flat_identical(la.compose(d2[i]).to_flat(), outs[i].to_flat(), f"single vs batch {i}")
+    assert la.compose_batch([]) == []

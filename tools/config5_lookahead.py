@@ -62,4 +62,12 @@ k = max(1, NA - 1)
 print("per acceptor (len 200), mean over %d: relabel %.3f ms, look-ahead compose %.3f ms (%d..%d composed states), n=10 %.3f ms; "
       "plain compose+connect of the same pair %.3f ms" % (k, tt["relabel"] / k * 1e3, tt["compose"] / k * 1e3, min(states), max(states),
                                                           tt["nbest"] / k * 1e3, tt["plain"] / k * 1e3))
+# the same problems as ONE batch (one wave per acceptor)
+das = [rustfst_amd.DeviceFst.from_arrays(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"], ctx) for a in accs]
+rel = [la.relabel(d) for d in das]
+outs = la.compose_batch(rel)
+ctx.synchronize()
+x0 = time.perf_counter(); outs = la.compose_batch(rel); ctx.synchronize(); x1 = time.perf_counter()
+assert [o.num_states for o in outs] == states
+print("batch of %d look-ahead compositions in one launch: %.3f ms (%.3f ms each)" % (NA, (x1 - x0) * 1e3, (x1 - x0) * 1e3 / NA))
 print("OK")
