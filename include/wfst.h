@@ -145,6 +145,13 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* ---- project: fst_project (rustfst-ffi/src/algorithms/project.rs:45-70) = rustfst::algorithms::project
+ *      (rustfst/src/algorithms/projection.rs:65-95), in place on the device-resident arcs.  project_output == 0:
+ *      ProjectType::ProjectInput (olabel := ilabel), != 0: ProjectOutput (ilabel := olabel); the property word follows
+ *      project_properties (fst_properties/mutate_properties.rs:365-445).  The usual recipe around the hot path is
+ *      compose -> project -> shortest_path (rustfst/src/lib.rs:70-82). ---- */
+wfst_status wfst_fst_project(wfst_ctx* ctx, wfst_fst* fst, int project_output);
+
 /* ---- look-ahead composition: the configuration rustfst-cli/src/cmds/compose.rs:77-181 (ComposeType::LookAhead) and
  *      rustfst/src/tests_openfst/algorithms/compose.rs:118-254 build by hand — there is no single reference entry point:
  *        graph1look = MatcherFst::new_with_relabeling(fst1, &mut fst2, true)        (compose/matcher_fst.rs:73-94)

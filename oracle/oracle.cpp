@@ -2659,6 +2659,46 @@ void oracle_label_reachable_intervals(const oracle_label_reachable* h, uint32_t 
   }
 }
 
+// project — algorithms/projection.rs:65-95 + project_properties (fst_properties/mutate_properties.rs:365-445); the per-arc
+// label bookkeeping of set_{i,o}label_unchecked is overwritten by set_properties_with_mask(.., all_properties())
+void oracle_fst_project(oracle_fst* f, int project_output) {
+  const uint64_t in = f->properties;
+  for (auto& st : f->states) {
+    for (Tr& tr : st.trs) {
+      if (project_output)
+        tr.ilabel = tr.olabel;
+      else
+        tr.olabel = tr.ilabel;
+    }
+    if (project_output)
+      st.niepsilons = st.noepsilons;
+    else
+      st.noepsilons = st.niepsilons;
+  }
+  uint64_t out = P::ACCEPTOR;
+  out |= (P::WEIGHTED | P::UNWEIGHTED | P::WEIGHTED_CYCLES | P::UNWEIGHTED_CYCLES | P::CYCLIC | P::ACYCLIC | P::INITIAL_CYCLIC |
+          P::INITIAL_ACYCLIC | P::TOP_SORTED | P::NOT_TOP_SORTED | P::ACCESSIBLE | P::NOT_ACCESSIBLE | P::COACCESSIBLE |
+          P::NOT_COACCESSIBLE | P::STRING | P::NOT_STRING) & in;
+  if (!project_output) {
+    out |= (P::I_DETERMINISTIC | P::NOT_I_DETERMINISTIC | P::I_EPSILONS | P::NO_I_EPSILONS | P::I_LABEL_SORTED | P::NOT_I_LABEL_SORTED) & in;
+    if (in & P::I_DETERMINISTIC) out |= P::O_DETERMINISTIC;
+    if (in & P::NOT_I_DETERMINISTIC) out |= P::NOT_O_DETERMINISTIC;
+    if (in & P::I_EPSILONS) out |= P::O_EPSILONS | P::EPSILONS;
+    if (in & P::NO_I_EPSILONS) out |= P::NO_O_EPSILONS | P::NO_EPSILONS;
+    if (in & P::I_LABEL_SORTED) out |= P::O_LABEL_SORTED;
+    if (in & P::NOT_I_LABEL_SORTED) out |= P::NOT_O_LABEL_SORTED;
+  } else {
+    out |= (P::O_DETERMINISTIC | P::NOT_O_DETERMINISTIC | P::O_EPSILONS | P::NO_O_EPSILONS | P::O_LABEL_SORTED | P::NOT_O_LABEL_SORTED) & in;
+    if (in & P::O_DETERMINISTIC) out |= P::I_DETERMINISTIC;
+    if (in & P::NOT_O_DETERMINISTIC) out |= P::NOT_I_DETERMINISTIC;
+    if (in & P::O_EPSILONS) out |= P::I_EPSILONS | P::EPSILONS;
+    if (in & P::NO_O_EPSILONS) out |= P::NO_I_EPSILONS | P::NO_EPSILONS;
+    if (in & P::O_LABEL_SORTED) out |= P::I_LABEL_SORTED;
+    if (in & P::NOT_O_LABEL_SORTED) out |= P::NOT_I_LABEL_SORTED;
+  }
+  f->set_properties_with_mask(out, P::ALL);
+}
+
 int oracle_connect(oracle_fst* f) {
   connect_impl(*f);
   return 0;

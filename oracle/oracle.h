@@ -11,7 +11,8 @@
  * K1 (rustfst-python/tests/algorithms/test_compose.py:13-81), K2
  * (rustfst-python/tests/algorithms/test_shortest_path.py:5-51), K3 (doctest
  * compose/compose_static.rs:282-289) and the K4 loader fixtures
- * (rustfst-tests-data/sigma-matcher-2/{left,right}.fst); the const-format loader on the
+ * (rustfst-tests-data/sigma-matcher-2/{left,right}.fst), K7 project
+ * (rustfst-python/tests/algorithms/test_project.py:5-97); the const-format loader on the
  * reference's own const files (rustfst-tests-data/fst_012, fst_014 hcl.fst.in: the stored
  * per-state epsilon counters must equal the recomputed ones).  The reference's large
  * OpenFST-generated goldens cannot be produced here (no rustc/cargo, no OpenFST,
@@ -105,6 +106,9 @@ void oracle_label_reachable_labels(const oracle_label_reachable*, uint32_t* labe
 size_t oracle_label_reachable_num_states(const oracle_label_reachable*);
 size_t oracle_label_reachable_num_intervals(const oracle_label_reachable*, uint32_t state);
 void oracle_label_reachable_intervals(const oracle_label_reachable*, uint32_t state, uint64_t* pairs);
+/* project(): algorithms/projection.rs:65-95 (in place; project_output = 0: olabel := ilabel, 1: ilabel := olabel).
+ * Pinned on rustfst-python/tests/algorithms/test_project.py:5-97. */
+void oracle_fst_project(oracle_fst*, int project_output);
 /* connect(): connect.rs:51-66 */
 int oracle_connect(oracle_fst*);
 /* shortest_path_with_config(nshortest=1): shortest_path.rs:107-133,173-282.

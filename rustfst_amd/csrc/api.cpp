@@ -349,6 +349,13 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
   });
 }
 
+wfst_status wfst_fst_project(wfst_ctx* ctx, wfst_fst* fst, int project_output) {
+  return wrap([&] {
+    if (!ctx || !fst) throw Error("null pointer");
+    project_device(ctx, fst, project_output != 0);
+  });
+}
+
 wfst_status wfst_lookahead_create(wfst_ctx* ctx, const wfst_fst* fst1, wfst_lookahead** out) {
   return wrap([&] {
     if (!ctx || !fst1 || !out) throw Error("null pointer");

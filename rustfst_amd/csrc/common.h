@@ -249,6 +249,8 @@ bool has_input_epsilons(wfst_ctx* ctx, const wfst_fst* f);
 bool detect_string(uint32_t n_states, int64_t start, const uint32_t* offsets, const wfst_tr* arcs, const float* finals);
 // tr_sort.hip
 void tr_sort_device(wfst_ctx* ctx, wfst_fst* f, bool ilabel_cmp);
+// fst_store.hip
+void project_device(wfst_ctx* ctx, wfst_fst* f, bool project_output);
 // compose.hip
 wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool connect, uint32_t filter = 0);
 void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t, bool connect,

@@ -182,6 +182,32 @@ inline uint64_t linear_path_props(bool has_path, uint32_t hops, float final_weig
   return shortest_path(p, true) & ALL;
 }
 
+// project_properties (fst_properties/mutate_properties.rs:365-445) as applied by project() with the all_properties() mask
+// (algorithms/projection.rs:91-94)
+inline uint64_t project(uint64_t in, bool project_output) {
+  uint64_t out = ACCEPTOR;
+  out |= (WEIGHTED | UNWEIGHTED | WEIGHTED_CYCLES | UNWEIGHTED_CYCLES | CYCLIC | ACYCLIC | INITIAL_CYCLIC | INITIAL_ACYCLIC |
+          TOP_SORTED | NOT_TOP_SORTED | ACCESSIBLE | NOT_ACCESSIBLE | COACCESSIBLE | NOT_COACCESSIBLE | STRING | NOT_STRING) & in;
+  if (!project_output) {
+    out |= (I_DETERMINISTIC | NOT_I_DETERMINISTIC | I_EPSILONS | NO_I_EPSILONS | I_LABEL_SORTED | NOT_I_LABEL_SORTED) & in;
+    if (in & I_DETERMINISTIC) out |= O_DETERMINISTIC;
+    if (in & NOT_I_DETERMINISTIC) out |= NOT_O_DETERMINISTIC;
+    if (in & I_EPSILONS) out |= O_EPSILONS | EPSILONS;
+    if (in & NO_I_EPSILONS) out |= NO_O_EPSILONS | NO_EPSILONS;
+    if (in & I_LABEL_SORTED) out |= O_LABEL_SORTED;
+    if (in & NOT_I_LABEL_SORTED) out |= NOT_O_LABEL_SORTED;
+  } else {
+    out |= (O_DETERMINISTIC | NOT_O_DETERMINISTIC | O_EPSILONS | NO_O_EPSILONS | O_LABEL_SORTED | NOT_O_LABEL_SORTED) & in;
+    if (in & O_DETERMINISTIC) out |= I_DETERMINISTIC;
+    if (in & NOT_O_DETERMINISTIC) out |= NOT_I_DETERMINISTIC;
+    if (in & O_EPSILONS) out |= I_EPSILONS | EPSILONS;
+    if (in & NO_O_EPSILONS) out |= NO_I_EPSILONS | NO_EPSILONS;
+    if (in & O_LABEL_SORTED) out |= I_LABEL_SORTED;
+    if (in & NOT_O_LABEL_SORTED) out |= NOT_I_LABEL_SORTED;
+  }
+  return (in & ~ALL) | out;
+}
+
 inline uint64_t compose_result(uint64_t p1, uint64_t p2, bool connected, bool has_start) {
   // start None: LazyFst::compute returns F2::new() untouched (lazy_fst.rs:229-232)
   uint64_t p = has_start ? compose(p1, p2) : NULL_PROPS;

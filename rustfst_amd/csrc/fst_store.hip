@@ -398,6 +398,46 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
   }
 }
 
+namespace {
+__global__ void project_kernel(wfst_tr* __restrict__ arcs, uint64_t n_arcs, int project_output) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_arcs; k += (uint64_t)gridDim.x * blockDim.x) {
+    if (project_output)
+      arcs[k].ilabel = arcs[k].olabel;
+    else
+      arcs[k].olabel = arcs[k].ilabel;
+  }
+}
+}  // namespace
+
+// project (algorithms/projection.rs:65-95) in place on the device-resident arcs: one label column copied over the other,
+// the per-state epsilon facts (noeps, srec) derived again, the property word from project_properties
+void project_device(wfst_ctx* ctx, wfst_fst* f, bool project_output) {
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (f->n_arcs) {
+    ensure_device(f);
+    const int blocks = (int)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
+    project_kernel<<<blocks, 256, 0, ctx->stream>>>(const_cast<wfst_tr*>(f->dev.arcs), f->n_arcs, project_output ? 1 : 0);
+    DBuf<uint32_t> err(*ctx->pool, 1);
+    HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), ctx->stream));
+    derive_noeps_kernel<<<(f->n_states + 255) / 256, 256, 0, ctx->stream>>>(f->dev.offsets, f->dev.arcs, f->dev.finals,
+                                                                             const_cast<uint32_t*>(f->dev.noeps),
+                                                                             const_cast<uint4*>(f->dev.srec), f->n_states, err.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (f->has_host) {  // the host mirror described the old labels
+      f->host = HostCsr{};
+      f->has_host = false;
+    }
+    f->rev_host.reset();  // reverse() carries labels
+    f->ieps_state = 0;
+    if (f->is_string) {  // still linear; epsilon-free on the input side only if the copied column was
+      ensure_host(f);
+      f->is_string = detect_string(f->n_states, f->start, f->host.offsets.data(), f->host.arcs.data(), f->host.finals.data());
+    }
+  }
+  f->props = props::project(f->props, project_output);
+}
+
 void ensure_device(wfst_fst* f) {
   if (f->has_dev) return;
   if (!f->has_host) throw Error("FST handle holds no data");

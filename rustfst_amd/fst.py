@@ -263,6 +263,13 @@ class DeviceFst:
         check(_lib.lib().wfst_reverse(self.ctx._h, self._h, C.byref(out)), "Error during reverse")
         return DeviceFst(out, self.ctx)
 
+    def project(self, proj_type: Optional["ProjectType"] = None) -> "DeviceFst":
+        """In-place projection on the device (algorithms/projection.rs:65-95): PROJECT_INPUT copies the input labels
+        over the output labels, PROJECT_OUTPUT the other way round."""
+        out = proj_type is not None and ProjectType(proj_type) == ProjectType.PROJECT_OUTPUT
+        check(_lib.lib().wfst_fst_project(self.ctx._h, self._h, 1 if out else 0), "Error during projection")
+        return self
+
     def tr_sort(self, ilabel_cmp: bool = True) -> "DeviceFst":
         """In-place stable per-state arc sort on the device by ilabel (ILabelCompare) or olabel
         (OLabelCompare) + the reference's property update: algorithms/tr_sort.rs:13-62,
@@ -482,6 +489,11 @@ def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
 
 
 # ------------------------------------------------------------------ configs
+class ProjectType(Enum):  # rustfst-python/rustfst/algorithms/project.py:9-24
+    PROJECT_INPUT = 0
+    PROJECT_OUTPUT = 1
+
+
 class ComposeFilter(Enum):  # rustfst-python/rustfst/algorithms/compose.py:55-62
     AUTOFILTER = 0
     NULLFILTER = 1
@@ -666,6 +678,10 @@ class VectorFst:
     def shortest_path(self, config: Union[ShortestPathConfig, None] = None) -> "VectorFst":
         return self.to_device().shortest_path(config).to_vector_fst()
 
+    def project(self, proj_type: Union["ProjectType", None] = None) -> "VectorFst":
+        """rustfst-python vector_fst.py `project` (algorithms/project.py:27-50): returns the projected FST."""
+        return self.to_device().project(proj_type).to_vector_fst()
+
 
 # ------------------------------------------------------------------ free functions
 def compose(fst: VectorFst, fst2: VectorFst) -> VectorFst:
@@ -675,6 +691,11 @@ def compose(fst: VectorFst, fst2: VectorFst) -> VectorFst:
 
 def compose_with_config(fst: VectorFst, fst2: VectorFst, config: ComposeConfig) -> VectorFst:
     return fst.compose(fst2, config)
+
+
+def project(fst: VectorFst, proj_type: ProjectType = ProjectType.PROJECT_INPUT) -> VectorFst:
+    """rustfst-python/rustfst/algorithms/project.py:27-50."""
+    return fst.project(proj_type)
 
 
 def shortestpath(fst: VectorFst) -> VectorFst:

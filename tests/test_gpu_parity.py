@@ -1137,3 +1137,31 @@ def test_lookahead_compose_batch(gpu_ctx, oracle):
     for i in (0, 7, 38):
         assert_flat_identical(la.compose(d2[i]).to_flat(), outs[i].to_flat(), f"single vs batch {i}")
     assert la.compose_batch([]) == []
+
+
+# ------------------------------------------------------------------ §8(f) N4: project around the path
+def test_project_known_answer_and_oracle(gpu_ctx, oracle):
+    """wfst_fst_project against the reference's own test vectors (test_project.py:5-97) and, on random FSTs, against the
+    oracle: arcs, per-state epsilon counters as seen by a following composition, and the property word."""
+    from rustfst_amd import ProjectType
+    g = golden("k7_project.json")
+    for ptype, key in ((ProjectType.PROJECT_INPUT, "expected_input"), (ProjectType.PROJECT_OUTPUT, "expected_output")):
+        got = vbuild(g["fst"]).project(ptype)
+        assert got == vbuild(g[key])
+    assert rustfst_amd.project(vbuild(g["fst"])) == vbuild(g["expected_input"])  # default = input projection
+    rng = np.random.default_rng(2024)
+    for k in range(12):
+        f = random_fst_flat(rng, int(rng.integers(1, 40)), 4, 4, p_eps_i=0.3, p_eps_o=0.3, p_final=0.3,
+                            sort=("ilabel", "olabel", "none")[k % 3])
+        for out in (False, True):
+            d = to_device(f).project(ProjectType.PROJECT_OUTPUT if out else ProjectType.PROJECT_INPUT)
+            ref = to_oracle(oracle, f).project(out)
+            assert_flat_identical(d.to_flat(), ref.to_flat(), f"project output={out}")
+            # the recipe of rustfst/src/lib.rs:70-82: compose -> project -> shortest path (epsilon facts re-derived)
+            if (d.to_flat()["props"] & synth.O_LABEL_SORTED) or (f["props"] & synth.I_LABEL_SORTED):
+                b = random_fst_flat(rng, 6, 3, 4, p_eps_i=0.2, p_final=0.4, sort="ilabel")
+                try:
+                    refc = ref.compose(to_oracle(oracle, b))
+                except oracle.OracleError:
+                    continue
+                assert_flat_identical(d.compose(to_device(b)).to_flat(), refc.to_flat(), "compose after project")

@@ -457,3 +457,13 @@ def test_lookahead_compose_keeps_the_best_path_on_cyclic_inputs(oracle, seed):
         p = p.to_flat()
         return None if p["n_states"] == 0 else round((float(p["arcs"]["weight"].sum()) + float(p["finals"][0])) * 1024)
     assert total(oa.compose(ob).shortest_path()) == total(la.shortest_path())
+
+
+def test_k7_project_known_answer(oracle):
+    """rustfst-python/tests/algorithms/test_project.py:5-97: input and output projection of the same 3-state FST."""
+    g = load_golden("k7_project.json")
+    flat_matches_spec(build(oracle, g["fst"]).project(False).to_flat(), g["expected_input"])
+    flat_matches_spec(build(oracle, g["fst"]).project(True).to_flat(), g["expected_output"])
+    f = build(oracle, g["fst"]).project(False)
+    from rustfst_amd import synth
+    assert f.to_flat()["props"] & synth.ACCEPTOR  # projection.rs:105-119 (the reference's proptest)
