@@ -24,6 +24,8 @@
 // Everything stays in HBM/L2 between phases: the fused pipeline (compose -> relax -> backtrace) never
 // returns to the host.
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "fst_props.h"
@@ -1019,6 +1021,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
 // covered case (more than 64 states in a level, more than STR_MAXS states in all) reports ST_NOT_A_STRING_CASE and the
 // host re-runs that problem on compose_wave_kernel.  Results are bit-identical to the general kernel's by construction and
 // by test (tests/test_gpu_parity.py: both kernels against the oracle).
+constexpr uint64_t WIDE_COMPOSE_STATES = 16384;  // compose(): results beyond this go to compose_wide.hip
 constexpr uint32_t STR_MAXS = 2048;
 constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
 
@@ -1400,6 +1403,11 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
   // results retry with 4x
   uint64_t est_s = 4ull * std::max<uint64_t>(std::min(f1->n_states, f2->n_states), 64) + 1024;
   uint64_t est_a = 4ull * est_s;
+  bool wide_ok = true;  // WFST_COMPOSE_PATH=wave pins the wave-per-problem kernel, =wide the wide driver (tests)
+  if (const char* e = std::getenv("WFST_COMPOSE_PATH")) {
+    if (std::strcmp(e, "wave") == 0) wide_ok = false;
+    if (std::strcmp(e, "wide") == 0) return compose_wide(ctx, f1, f2, mode, filter, connect, out_props, est_s);
+  }
   for (int attempt = 0;; ++attempt) {
     Caps caps = make_caps(est_s, est_a);
     BatchRun run;
@@ -1430,6 +1438,9 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
     if (attempt > 24) throw Error(std::string("compose: arena overflow (") + status_name(r.status) + ") after retries");
     est_s *= 4;
     est_a *= 4;
+    // a result that has outgrown WIDE_COMPOSE_STATES is not a job for ONE wave: the wide driver (compose_wide.hip: one
+    // wave per composed state of a BFS level) does a million states in tens of ms where this kernel needs seconds
+    if (wide_ok && est_s > WIDE_COMPOSE_STATES) return compose_wide(ctx, f1, f2, mode, filter, connect, out_props, est_s);
   }
 }
 

@@ -1165,3 +1165,41 @@ def test_project_known_answer_and_oracle(gpu_ctx, oracle):
                 except oracle.OracleError:
                     continue
                 assert_flat_identical(d.compose(to_device(b)).to_flat(), refc.to_flat(), "compose after project")
+
+
+# ------------------------------------------------------------------ compose of one large pair: the wide driver
+@pytest.mark.parametrize("flt", [ComposeFilter.AUTOFILTER] + FILTERS, ids=lambda f: f.name)
+@pytest.mark.parametrize("seed", range(5))
+def test_compose_wide_driver_matches_oracle(gpu_ctx, oracle, monkeypatch, flt, seed):
+    """compose() pinned to the wide driver (compose_wide.hip: one wave per composed state of a BFS level, device-side
+    connect) on the epsilon-rich pairs of the filter tests: ids, arc order, weights, finals, property word == oracle for
+    every filter, with and without connect, including results that trim to nothing."""
+    monkeypatch.setenv("WFST_COMPOSE_PATH", "wide")
+    rng = np.random.default_rng(9000 + seed)
+    n1, n2 = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    a = random_fst_flat(rng, n1, 4, 3, p_eps_i=0.2, p_eps_o=0.45 if seed % 2 else 0.25, p_final=0.35 if seed else 0.0, sort="olabel")
+    b = random_fst_flat(rng, n2, 4, 3, p_eps_i=0.45 if seed % 3 else 0.25, p_eps_o=0.2, p_final=0.35, sort="ilabel")
+    da, db = to_device(a), to_device(b)
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    for connect in (False, True):
+        ref = oa.compose(ob, connect=connect, compose_filter=flt.value).to_flat()
+        got = da.compose(db, ComposeConfig(flt, connect=connect)).to_flat()
+        assert_flat_identical(got, ref, f"wide compose {flt.name} connect={connect}")
+
+
+@pytest.mark.parametrize("connect", [False, True])
+def test_compose_large_pair_switches_to_wide_driver(gpu_ctx, oracle, connect):
+    """A 110 k-state composition through the default compose(): the wave kernel gives up after its first arenas and the
+    wide driver finishes; one-side-sorted operands (forced match side) go the same way."""
+    a = _swap_labels(synth.make_transducer(2000, 3, 12, 0.2, seed=3, p_final=0.05))
+    b = synth.make_transducer(50, 12, 12, 0.05, seed=103, p_final=0.05)
+    ref = to_oracle(oracle, a).compose(to_oracle(oracle, b), connect=connect).to_flat()
+    assert ref["n_states"] > 50_000
+    got = to_device(a).compose(to_device(b), ComposeConfig(connect=connect)).to_flat()
+    assert_flat_identical(got, ref, f"large compose connect={connect}")
+    assert gpu_ctx.stats()["compose_states"] > 50_000
+    b_unsorted = dict(b)
+    b_unsorted["props"] = b["props"] & ~synth.I_LABEL_SORTED | 0x0000_0000_2000_0000  # NOT_I_LABEL_SORTED: match on fst1 only
+    ref2 = to_oracle(oracle, a).compose(to_oracle(oracle, b_unsorted), connect=connect).to_flat()
+    got2 = to_device(a).compose(to_device(b_unsorted), ComposeConfig(connect=connect)).to_flat()
+    assert_flat_identical(got2, ref2, "large compose, output-side matching only")
