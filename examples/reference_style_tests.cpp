@@ -3,6 +3,8 @@
 //   K1  rustfst-python/tests/algorithms/test_compose.py:13-81          test_compose_fst
 //   K2  rustfst-python/tests/algorithms/test_shortest_path.py:5-51     test_shortest_path
 //   K3  rustfst/src/algorithms/compose/compose_static.rs:282-289       doctest of compose (fst![1,2 => 2,3] o fst![2,3 => 3,4])
+//   K7  rustfst-python/tests/algorithms/test_project.py:5-97           test_project_input / test_project_output
+//   the look-ahead recipe of rustfst-cli/src/cmds/compose.rs:77-181 on the K1 operands: same language as compose
 //   error behaviour of compose on unsorted operands (compose_fst_op.rs:169-197) and of missing states (mutable_fst.rs)
 //
 //   g++ -std=c++17 -I include examples/reference_style_tests.cpp -L rustfst_amd/lib -lwfst_amd -Wl,-rpath,$PWD/rustfst_amd/lib -o ref_tests
@@ -141,7 +143,57 @@ static void test_errors() {
   ASSERT(shortest_path(VectorFst()).num_states() == 0);  // no start state -> empty result (shortest_path.rs:185-187)
 }
 
+static VectorFst project_input_fst() {  // test_project.py:5-27
+  VectorFst f;
+  const StateId s1 = f.add_state(), s2 = f.add_state(), s3 = f.add_state();
+  f.set_start(s1);
+  f.set_final(s3);
+  f.add_tr(s1, tr(1, 2, 1.0f, s2));
+  f.add_tr(s1, tr(3, 4, 2.0f, s2));
+  f.add_tr(s2, tr(4, 5, 3.0f, s3));
+  return f;
+}
+static void test_project() {  // K7
+  for (int output = 0; output < 2; ++output) {
+    VectorFst expected;
+    const StateId s1 = expected.add_state(), s2 = expected.add_state(), s3 = expected.add_state();
+    expected.set_start(s1);
+    expected.set_final(s3);
+    expected.add_tr(s1, output ? tr(2, 2, 1.0f, s2) : tr(1, 1, 1.0f, s2));
+    expected.add_tr(s1, output ? tr(4, 4, 2.0f, s2) : tr(3, 3, 2.0f, s2));
+    expected.add_tr(s2, output ? tr(5, 5, 3.0f, s3) : tr(4, 4, 3.0f, s3));
+    VectorFst f = project_input_fst();
+    project(f, output ? ProjectType::ProjectOutput : ProjectType::ProjectInput);
+    ASSERT(f == expected);
+  }
+}
+
+static void test_lookahead_recipe() {
+  // fst![1,2 => 2,3] o fst![2,3 => 3,4] through the look-ahead configuration: one path, input 1 2, output 3 4, weight one
+  VectorFst a, b;
+  for (int i = 0; i < 3; ++i) { a.add_state(); b.add_state(); }
+  a.set_start(0); a.set_final(2);
+  b.set_start(0); b.set_final(2);
+  a.add_tr(0, tr(1, 2, 0.0f, 1)); a.add_tr(1, tr(2, 3, 0.0f, 2));
+  b.add_tr(0, tr(2, 3, 0.0f, 1)); b.add_tr(1, tr(3, 4, 0.0f, 2));
+  tr_sort(a, OLabelCompare{});
+  tr_sort(b, ILabelCompare{});
+  const VectorFst c = compose_lookahead(a, b);
+  const VectorFst p = shortest_path(c);
+  ASSERT(p.num_states() == 3);
+  std::vector<Label> il, ol;
+  StateId s = *p.start();
+  while (p.num_trs(s)) {
+    const Tr t = p.get_trs(s)[0];
+    il.push_back(t.ilabel); ol.push_back(t.olabel);
+    s = t.nextstate;
+  }
+  ASSERT((il == std::vector<Label>{1, 2}) && (ol == std::vector<Label>{3, 4}));
+}
+
 int main() {
+  test_project();
+  test_lookahead_recipe();
   test_compose_fst();
   test_shortest_path();
   test_compose_doctest();

@@ -11,6 +11,8 @@
 //   CoreFst::{start, final_weight, num_trs, get_trs},            same member names (fst_traits/fst.rs:18-250);
 //   ExpandedFst::num_states, Fst::properties                     Option<T> -> std::optional<T>
 //   tr_sort(&mut fst, ILabelCompare{} | OLabelCompare{})         tr_sort(fst, ILabelCompare{} | OLabelCompare{})
+//   project(&mut fst, ProjectType::ProjectInput)                 project(fst, ProjectType::ProjectInput)
+//   (look-ahead recipe of rustfst-cli/src/cmds/compose.rs)       LookAheadFst(fst1).compose(fst2) / compose_lookahead
 //   compose(fst1, fst2) / compose_with_config(.., ComposeConfig) compose(..) / compose_with_config(..)   compose_static.rs:166-306
 //   shortest_path(&fst) / shortest_path_with_config(..)          shortest_path(..) / shortest_path_with_config(..)  shortest_path.rs:76-133
 //   anyhow::Result<T> Err(e)                                     throws wfst_amd::Error (what() = the library's message)
@@ -174,6 +176,44 @@ inline VectorFst shortest_path_with_config(const VectorFst& ifst, const Shortest
   return detail::download(c);
 }
 inline VectorFst shortest_path(const VectorFst& ifst) { return shortest_path_with_config(ifst, ShortestPathConfig{}); }
+
+// project (algorithms/projection.rs:65-95): in place, like the reference
+enum class ProjectType { ProjectInput, ProjectOutput };  // projection.rs:7-13
+inline void project(VectorFst& fst, ProjectType project_type) {
+  detail::DeviceFst a;
+  detail::upload(fst, a);
+  check(wfst_fst_project(Context::current().get(), a.h, project_type == ProjectType::ProjectOutput ? 1 : 0));
+  fst = detail::download(a);
+}
+
+// Look-ahead composition.  The reference has no single function for it: callers assemble MatcherFst::new_with_relabeling,
+// a LabelLookAheadMatcher and the PushLabels(PushWeights(LookAhead(AltSequence))) filter by hand and call compute()
+// (rustfst-cli/src/cmds/compose.rs:77-181).  LookAheadFst is the MatcherFst of that recipe (keep it while the same first
+// operand meets further second operands); compose_lookahead is the whole recipe for one pair.  The result is not connected.
+class LookAheadFst {
+ public:
+  explicit LookAheadFst(const VectorFst& fst1) {  // MatcherFst::new, compose/matcher_fst.rs:55-71
+    detail::DeviceFst a;
+    detail::upload(fst1, a);
+    check(wfst_lookahead_create(Context::current().get(), a.h, &h_));
+  }
+  ~LookAheadFst() { if (h_) wfst_lookahead_destroy(h_); }
+  LookAheadFst(const LookAheadFst&) = delete;
+  LookAheadFst& operator=(const LookAheadFst&) = delete;
+  // LabelLookAheadRelabeler::relabel(fst2, .., true) + tr_sort(ILabelCompare), then ComposeFst::new_with_options(..).compute()
+  VectorFst compose(const VectorFst& fst2) const {
+    detail::DeviceFst b, br, c;
+    detail::upload(fst2, b);
+    check(wfst_lookahead_relabel(h_, b.h, &br.h));
+    check(wfst_compose_lookahead(Context::current().get(), h_, br.h, &c.h));
+    return detail::download(c);
+  }
+  wfst_lookahead* raw() const { return h_; }
+
+ private:
+  wfst_lookahead* h_ = nullptr;
+};
+inline VectorFst compose_lookahead(const VectorFst& fst1, const VectorFst& fst2) { return LookAheadFst(fst1).compose(fst2); }
 
 }  // namespace wfst_amd
 
