@@ -80,9 +80,20 @@ using Intervals = std::vector<std::pair<uint32_t, uint32_t>>;  // half-open [beg
 
 // IntervalSet::normalize (interval_set.rs:156-190): order by begin (longer first on ties), merge overlapping and adjacent
 void normalize(Intervals& iv) {
-  std::stable_sort(iv.begin(), iv.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+  auto less = [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
     return a.first != b.first ? a.first < b.first : a.second > b.second;
-  });
+  };
+  if (iv.size() <= 32) {  // the usual size (a state's own labels): insertion sort, no temporary buffer (equal keys are equal
+                          // pairs, so stability is moot)
+    for (size_t i = 1; i < iv.size(); ++i) {
+      const std::pair<uint32_t, uint32_t> v = iv[i];
+      size_t j = i;
+      for (; j > 0 && less(v, iv[j - 1]); --j) iv[j] = iv[j - 1];
+      iv[j] = v;
+    }
+  } else {
+    std::sort(iv.begin(), iv.end(), less);
+  }
   size_t w = 0;
   for (size_t i = 0; i < iv.size();) {
     std::pair<uint32_t, uint32_t> cur = iv[i];
@@ -121,14 +132,6 @@ struct ReachVisitor {
   }
 };
 
-struct CycleVisitor {
-  bool cyclic = false;
-  void discover(uint32_t) {}
-  void back(uint32_t, uint32_t) { cyclic = true; }
-  void cross(uint32_t, uint32_t) {}
-  void finish(uint32_t, bool, uint32_t) {}
-};
-
 // SccVisitor (visitors/scc_visitors.rs:10-180): Tarjan over the same visit; component ids are reversed at the end, so
 // they are a topological numbering of the condensation
 struct SccVisitor {
@@ -136,6 +139,7 @@ struct SccVisitor {
   std::vector<uint8_t> onstack;
   std::vector<uint32_t> stack;
   int32_t nstates = 0, nscc = 0;
+  bool cyclic = false;
   explicit SccVisitor(uint32_t n) : scc(n, -1), dfnumber(n, -1), lowlink(n, -1), onstack(n, 0) {}
   void discover(uint32_t s) {
     stack.push_back(s);
@@ -143,6 +147,7 @@ struct SccVisitor {
     onstack[s] = 1;
   }
   void back(uint32_t s, uint32_t t) {
+    cyclic = true;
     if (dfnumber[t] < lowlink[s]) lowlink[s] = dfnumber[t];
   }
   void cross(uint32_t s, uint32_t t) {
@@ -169,17 +174,17 @@ struct SccVisitor {
 // StateReachable::new (state_reachable.rs:26-76): interval sets + discovery index of the final states; cyclic inputs go
 // through their condensation (no final state may lie on a cycle)
 void state_reachable(const Graph& g, std::vector<Intervals>& sets, std::vector<uint32_t>& state2index) {
-  CycleVisitor cv;
-  depth_first(g, cv);
-  if (!cv.cyclic) {
+  // one visit answers "acyclic?" (no back arc: compute_and_update_properties(ACYCLIC), label_reachable.rs:146) and, if
+  // not, already holds the components of the condensation
+  SccVisitor sv(g.n());
+  depth_first(g, sv);
+  if (!sv.cyclic) {
     ReachVisitor rv(g);
     depth_first(g, rv);
     sets = std::move(rv.sets);
     state2index = std::move(rv.state2index);
     return;
   }
-  SccVisitor sv(g.n());
-  depth_first(g, sv);
   sv.done();
   const uint32_t nc = (uint32_t)sv.nscc;
   Graph c;  // condense (condense.rs:15-55): arcs between different components, in source-state then arc order
