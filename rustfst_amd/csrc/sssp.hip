@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   // relaxes the arcs of up to 64 states: lane i owns state i of the chunk (act, its key, its arc range)
   auto relax_chunk = [&](bool act, uint64_t my_ks, uint32_t my_b, uint32_t my_e) {
     if (profile && act) {
-      p_states += 1;
+      if (profile == 1u) p_states += 1;  // (profile == 2: the states column counts atomicMin attempts instead)
       p_arcs += my_e - my_b;
     }
     uint64_t mask = __ballot(act);
@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
         uint64_t olda = 0, oldb = 0;
         if (ta) olda = atomicMin((unsigned long long*)&key[aa.y], (unsigned long long)cka);
         if (tb) oldb = atomicMin((unsigned long long*)&key[ab.y], (unsigned long long)ckb);
+        if (profile == 2u) p_states += (ta ? 1u : 0u) + (tb ? 1u : 0u);
         activate(ta && cka < olda, aa.y, eca, ca);
         activate(tb && ckb < oldb, ab.y, ecb, cb);
         ia += GROUP;
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
       p_arcs += __shfl_xor(p_arcs, d);
       p_states += __shfl_xor(p_states, d);
     }
-    if (lane == 0 && p_states) {
+    if (lane == 0 && (p_states | p_arcs)) {
       atomicAdd(&s_prof[0], p_arcs);
       atomicAdd(&s_prof[1], p_states);
     }
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) {
     if (s_any && *improved == 0u) *improved = 1u;
     if (s_near) atomicAdd(&ctl->near[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_near);
-    if (profile && s_prof[1]) {
+    if (profile && (s_prof[0] | s_prof[1])) {
       atomicAdd(&ctl->arcs[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[0]);
       atomicAdd(&ctl->states[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[1]);
     }
@@ -782,7 +783,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
       sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
                                                 sv.improved.p, sv.ctl.p, 0u, delta, near_low, sv.shadow.p, sv.chase_cap,
-                                                sv.chase_rounds, sv.chase_low, 1u);  // counts the states / arcs it relaxes
+                                                sv.chase_rounds, sv.chase_low, std::getenv("WFST_SSSP_COUNT_ATOMICS") ? 2u : 1u);  // counts the states / arcs it relaxes
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u, nullptr);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
