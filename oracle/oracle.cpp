@@ -2011,18 +2011,17 @@ uint64_t new_properties_labels(uint64_t p, uint32_t oi, uint32_t oo, uint32_t ni
 }
 
 // LabelReachableData::relabel_fst — label_reachable.rs:63-93
+// (relabel maps epsilon to epsilon and nothing else to it: the per-state epsilon counters stay as they are)
 void relabel_fst(LabelReachableData& data, Fst& fst, bool relabel_input) {
   for (State& st : fst.states) {
     for (Tr& tr : st.trs) {
       if (relabel_input) {
         const uint32_t nl = data.relabel(tr.ilabel);
         fst.properties = new_properties_labels(fst.properties, tr.ilabel, tr.olabel, nl, tr.olabel);
-        if (tr.ilabel == EPS_LABEL && nl != EPS_LABEL) st.niepsilons--;  // (relabel keeps epsilon as epsilon)
         tr.ilabel = nl;
       } else {
         const uint32_t nl = data.relabel(tr.olabel);
         fst.properties = new_properties_labels(fst.properties, tr.ilabel, tr.olabel, tr.ilabel, nl);
-        if (tr.olabel == EPS_LABEL && nl != EPS_LABEL) st.noepsilons--;
         tr.olabel = nl;
       }
     }
@@ -2381,9 +2380,7 @@ struct LaComposeOp {
       sorted_items(trs, EPS_LABEL, by_ilabel, out);
     } else if (label == NO_LABEL) {
       if (!side2 && flabel != NO_LABEL) {  // MULTI_EPS_LIST: arcs carrying the multi-epsilon label, then the epsilon arcs
-        const size_t before = out.size();
         sorted_items(trs, flabel, by_ilabel, out);
-        (void)before;
         sorted_items(trs, NO_LABEL, by_ilabel, out);
       } else {
         sorted_items(trs, NO_LABEL, by_ilabel, out);

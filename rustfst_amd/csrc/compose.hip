@@ -49,7 +49,8 @@ constexpr uint64_t KEY_INF = ~0ull;
 enum : uint32_t { MODE_BOTH = 0, MODE_INPUT = 1, MODE_OUTPUT = 2 };  // MatchType after match_type()
 enum : uint32_t {
   ST_OK = 0, ST_OVERFLOW_STATES = 1, ST_OVERFLOW_ARCS = 2, ST_OVERFLOW_HASH = 3, ST_OVERFLOW_PATH = 4,
-  ST_NOT_A_STRING_CASE = 5  // the string o T kernel met a case it does not cover: redo on the general kernel
+  ST_NOT_A_STRING_CASE = 5,  // the string o T kernel met a case it does not cover: redo on the general kernel
+  ST_SWITCH_WIDE = 6         // a frontier too wide for one wave: compose() redoes the pair on the wide driver
 };
 enum : uint32_t { FLAG_TRIM = 1, FLAG_SP = 2 };
 
@@ -74,6 +75,7 @@ struct Caps {
   uint32_t S;  // composed states
   uint32_t A;  // composed arcs
   uint32_t H;  // hash slots (power of two)
+  uint32_t W;  // give up (ST_SWITCH_WIDE) when a BFS level adds more states than this; 0 = never
 };
 
 struct Result {
@@ -800,6 +802,11 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
         relax_states(ar, lo, hi, n_arcs);
         wave_sync();
       }
+      if (caps.W && n_new > caps.W) {
+        res.status = ST_SWITCH_WIDE;
+        ok = false;
+        break;
+      }
       lo = hi;
       hi += n_new;
       n_states = hi;
@@ -1022,6 +1029,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
 // host re-runs that problem on compose_wave_kernel.  Results are bit-identical to the general kernel's by construction and
 // by test (tests/test_gpu_parity.py: both kernels against the oracle).
 constexpr uint64_t WIDE_COMPOSE_STATES = 16384;  // compose(): results beyond this go to compose_wide.hip
+constexpr uint32_t WIDE_COMPOSE_WIDTH = 256;     // ... and so do results with a BFS level wider than this
 constexpr uint32_t STR_MAXS = 2048;
 constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
 
@@ -1230,6 +1238,7 @@ Caps make_caps(uint64_t est_states, uint64_t est_arcs) {
   c.S = (uint32_t)S;
   c.A = (uint32_t)A;
   c.H = next_pow2(2 * S + 128);
+  c.W = 0;
   return c;
 }
 
@@ -1410,6 +1419,7 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
   }
   for (int attempt = 0;; ++attempt) {
     Caps caps = make_caps(est_s, est_a);
+    if (wide_ok) caps.W = WIDE_COMPOSE_WIDTH;
     BatchRun run;
     if (connect)
       launch<FLAG_TRIM>(ctx, descs, v2, caps, run, false);
@@ -1434,6 +1444,7 @@ wfst_fst* compose(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, bool co
         return adopt_device(ctx, r.t_states, r.t_arcs, r.t_start, out_props, t_off, t_arcs, t_fin);
       return adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1, out_props, off, arcs, fin);
     }
+    if (r.status == ST_SWITCH_WIDE) return compose_wide(ctx, f1, f2, mode, filter, connect, out_props, 4 * est_s);
     ctx->stats.compose_retries++;
     if (attempt > 24) throw Error(std::string("compose: arena overflow (") + status_name(r.status) + ") after retries");
     est_s *= 4;

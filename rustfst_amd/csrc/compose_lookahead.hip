@@ -52,6 +52,7 @@ constexpr uint32_t NO_LABEL = WFST_NO_LABEL;
 constexpr uint32_t REJECT = 0xFFFFFFFFu;
 constexpr float KDELTA_F = 1.0f / 1024.0f;  // lib.rs:269
 constexpr uint32_t WIDE_SWITCH_STATES = 2048;  // results larger than this are redone on the wide path
+constexpr uint32_t WIDE_SWITCH_WIDTH = 256;    // ... and so are results with a BFS level wider than this
 
 
 struct LaView {
@@ -367,7 +368,10 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
   uint32_t n_states = 0, n_arcs = 0, n_levels = 0;
   bool ok = true;
   if (f1.start >= 0 && f2.start >= 0) {  // compute_start, compose_fst_op.rs:389-404
-    for (uint32_t i = lane; i < caps.H; i += 64) ar.klo[i] = K_EMPTY;
+    for (uint32_t i = lane; i < caps.H; i += 64) {
+      ar.klo[i] = K_EMPTY;
+      ar.khi[i] = KHI_UNSET;
+    }
     __syncthreads();
     if (lane == 0) {
       const uint64_t lo0 = ((uint64_t)(uint32_t)f1.start << 32) | (uint32_t)f2.start;
@@ -438,17 +442,16 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
           uint64_t prev = 0;
           if (!done) prev = atomicCAS((unsigned long long*)&ar.klo[slot], (unsigned long long)K_EMPTY, (unsigned long long)klo);
           const bool won = !done && prev == K_EMPTY;
-          if (won) st_l2(&ar.khi[slot], khi);
-          __threadfence();  // the winner's second word is in L2 before any lane below compares it
+          if (won) st_l2(&ar.khi[slot], khi);  // (a lane that reads it too early sees KHI_UNSET and retries the slot)
           const bool same_lo = !done && !won && prev == klo;
-          uint64_t h = 0;
+          uint64_t h = KHI_UNSET;
           if (same_lo) h = ld_l2(&ar.khi[slot]);
           if (won) {
             done = true;
           } else if (same_lo && h == khi) {
             existed = true;
             done = true;
-          } else if (!done) {
+          } else if (!done && !(same_lo && h == KHI_UNSET)) {
             slot = (slot + 1) & hmask;
           }
         }
@@ -478,7 +481,9 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
       lo = hi;
       hi += n_new;
       n_states = hi;
-      if (n_states > switch_states && lo < hi) {  // a big composition: thousands of waves do it faster
+      // a big composition, or a frontier too wide for one wave: thousands of waves do it faster (deep and narrow results,
+      // the decoding lattices, stay here: the wide path pays five launches and a read-back per level)
+      if ((n_states > switch_states || (switch_states != 0xFFFFFFFFu && n_new > WIDE_SWITCH_WIDTH)) && lo < hi) {
         res.status = LA_SWITCH_WIDE;
         ok = false;
       }
@@ -607,8 +612,8 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
   hipStream_t st = ctx->stream;
   std::vector<size_t> todo;
   std::vector<LaView> views;
-  std::vector<std::unique_ptr<wfst_fst>> done(n);
-  try {
+  std::vector<std::unique_ptr<wfst_fst>> done(n);  // (frees what was built if a later problem throws)
+  {
     for (size_t i = 0; i < n; ++i) {
       ensure_device(const_cast<wfst_fst*>(fst2s[i]));
       const bool has_start = f1->start >= 0 && fst2s[i]->start >= 0;
@@ -695,8 +700,6 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
         done[i].reset(compose_lookahead_wide(ctx, la, f1, fst2, out_props, ws, 4 * ws));
       }
     }
-  } catch (...) {
-    throw;  // (done[] frees what was built)
   }
   for (size_t i = 0; i < n; ++i) outs[i] = done[i].release();
 }

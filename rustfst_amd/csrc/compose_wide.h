@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
       }
       running += total;
     }
-    __threadfence();
+    // (the keys just written by other lanes of this wave are read back below: their stores only have to have left the CU;
+    // an agent-scope fence would write back this XCD's whole L2 — thousands of waves doing that was 10x the kernel)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // destinations: slot of the tuple + the order of its first emission in this level
     for (uint32_t base = 0; base < seg_total; base += 64) {
       const uint32_t k = base + lane;
@@ -196,8 +198,7 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
         uint64_t prev = 0;
         if (!done) prev = atomicCAS((unsigned long long*)&ar.klo[slot], (unsigned long long)K_EMPTY, (unsigned long long)klo);
         const bool won = !done && prev == K_EMPTY;
-        if (won) st_l2(&ar.khi[slot], khi);
-        __threadfence();
+        if (won) st_l2(&ar.khi[slot], khi);  // (a lane that reads it too early sees KHI_UNSET and retries the slot)
         const bool same_lo = !done && !won && prev == klo;
         uint64_t h = KHI_UNSET;
         if (same_lo) h = ld_l2(&ar.khi[slot]);
