@@ -8,7 +8,7 @@
 //             position of the arc in its segment) = the order of its first emission in this level;
 //   la_first  a tuple is new iff it has no id yet; its first emission is the arc whose order equals the table's minimum;
 //             firsts are counted per state;
-//   (rocPRIM exclusive scan over the level, one 12-byte read-back: new states, overflow status)
+//   (rocPRIM exclusive scan over the level, one 8-byte read-back: new states, overflow status)
 //   la_assign firsts are numbered hi + rank: exactly the reference's ids;   la_patch  table slot -> id in the arcs.
 // At the end the segments are gathered into CSR order.  No lane ever spins on another lane: a slot whose second key word is
 // not written yet is retried on the next iteration of a wave-uniform loop.
@@ -16,6 +16,7 @@
 // Everything here sits in an anonymous namespace: each translation unit instantiates its own copy with its policy.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -98,9 +99,13 @@ struct WideArena {
   uint32_t* fbase;     // [S+1] exclusive scan of nfirst
   float* fin;          // [S]
 };
+constexpr uint32_t MAX_PROBES = 512;  // open addressing at load <= 0.5: chains of tens at most
+constexpr uint32_t CUR_SHARDS = 64;  // reservation cursors: one per 128-B line (same-address atomics serialise at ~12 ns:
+constexpr uint32_t CUR_STRIDE = 32;  // 300 k states of one level on ONE cursor were 3.6 ms, the whole la_emit of that level)
 struct WideCtl {
   uint32_t status;
-  uint32_t cursor;  // arcs reserved so far
+  uint32_t pad[31];
+  uint32_t cursor[CUR_SHARDS * CUR_STRIDE];  // shard j reserves inside [j * A / CUR_SHARDS, (j + 1) * A / CUR_SHARDS)
 };
 
 __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t hi0, WideCtl* ctl) {
@@ -118,8 +123,8 @@ __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t h
     ar.t_lo[0] = lo0;
     ar.t_hi[0] = hi0;
     ctl->status = LA_OK;
-    ctl->cursor = 0;
   }
+  if (i < CUR_SHARDS) ctl->cursor[i * CUR_STRIDE] = i * (caps.A / CUR_SHARDS);
 }
 
 // compute_trs of every state of the level [lo, hi): arcs into a reserved segment, destinations into the table.
@@ -131,6 +136,7 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
   const uint32_t hmask = caps.H - 1;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+    if (ld_l2(&ctl->status) != LA_OK) return;  // the attempt is lost (arena or table overflow): the host retries bigger
     const typename P::Expand x = pol.make_expand(ar.t_lo[q], ar.t_hi[q]);
     const uint32_t n_items = x.n_it + 1;
     // size of the segment
@@ -149,13 +155,14 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
       seg_total += s;
     }
     uint32_t seg = 0;
+    const uint32_t shard = wave % CUR_SHARDS;
     if (lane == 0) {
-      seg = seg_total ? atomicAdd(&ctl->cursor, seg_total) : 0u;
+      seg = seg_total ? atomicAdd(&ctl->cursor[shard * CUR_STRIDE], seg_total) : 0u;
       ar.seg_base[q] = seg;
       ar.fin[q] = x.final_weight;
     }
     seg = __shfl(seg, 0);
-    const bool fits = (uint64_t)seg + seg_total <= caps.A;
+    const bool fits = (uint64_t)seg + seg_total <= (uint64_t)(shard + 1) * (caps.A / CUR_SHARDS);
     if (lane == 0) {
       ar.seg_cnt[q] = fits ? seg_total : 0u;
       if (!fits) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_ARCS);
@@ -194,6 +201,7 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
       }
       uint32_t slot = hash_128(klo, khi) & hmask;
       bool done = !have;
+      uint32_t probes = 0;
       while (__any(!done)) {  // (no lane ever spins on another: a slot whose second word is not there yet is retried)
         uint64_t prev = 0;
         if (!done) prev = atomicCAS((unsigned long long*)&ar.klo[slot], (unsigned long long)K_EMPTY, (unsigned long long)klo);
@@ -203,7 +211,15 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
         uint64_t h = KHI_UNSET;
         if (same_lo) h = ld_l2(&ar.khi[slot]);
         if (won || (same_lo && h == khi)) done = true;
-        else if (!done && !(same_lo && h == KHI_UNSET)) slot = (slot + 1) & hmask;
+        else if (!done && !(same_lo && h == KHI_UNSET)) {
+          slot = (slot + 1) & hmask;
+          // a level can hold more new tuples than the table has room for (the state count is only checked between
+          // levels): a probe sequence this long means the table is filling up -> give the attempt up, never spin
+          if (++probes > MAX_PROBES) {
+            atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_STATES);
+            done = true;
+          }
+        }
       }
       if (have) {
         atomicMin((unsigned long long*)&ar.hord[slot], ((unsigned long long)(q - lo) << 32) | k);
@@ -214,7 +230,8 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
 }
 
 // per state of the level: how many of its arcs are the first emission of a tuple that has no id yet
-__global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t lo, uint32_t hi) {
+__global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t lo, uint32_t hi, const WideCtl* ctl) {
+  if (ld_l2(&ctl->status) != LA_OK) return;  // a lost attempt left segments unwritten: nothing here is valid
   const uint32_t lane = lane_id();
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0) ar.nfirst[hi - lo] = 0;  // the scan's extra element: fbase[hi - lo] = total
@@ -304,6 +321,10 @@ struct WideOutput {
 template <class P>
 void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, WideOutput& out) {
   hipStream_t st = ctx->stream;
+  if (const char* e = std::getenv("WFST_WIDE_EST_STATES")) {  // tests: start from a tiny arena so that it has to grow
+    est_s = std::max<uint64_t>(64, (uint64_t)std::atoll(e));
+    est_a = 4 * est_s;
+  }
   for (int attempt = 0;; ++attempt) {
     if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose: composition too large");
     const LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, wide_next_pow2(2 * est_s + 128)};
@@ -332,8 +353,7 @@ void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t 
     HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)caps.S + 1, rocprim::plus<uint32_t>(), st));
     DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
     struct HostCtl {
-      WideCtl ctl;
-      uint32_t n_new;
+      uint32_t status, n_new, n_arcs;
     };
     HostCtl* hc = (HostCtl*)ctx->pinned.get(sizeof(HostCtl));
     const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
@@ -344,13 +364,13 @@ void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t 
       const uint32_t n_level = hi - lo;
       const uint32_t blocks = std::min<uint32_t>(max_blocks, (n_level + 3) / 4);
       la_emit<P><<<blocks, 256, 0, st>>>(pol, caps, ar, lo, hi, d_ctl.p);
-      la_first<<<blocks, 256, 0, st>>>(ar, lo, hi);
+      la_first<<<blocks, 256, 0, st>>>(ar, lo, hi, d_ctl.p);
       HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)n_level + 1, rocprim::plus<uint32_t>(), st));
-      HIP_CHECK(hipMemcpyAsync(&hc->ctl, d_ctl.p, sizeof(WideCtl), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(&hc->status, &d_ctl.p->status, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(&hc->n_new, ar.fbase + n_level, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       levels++;
-      if (hc->ctl.status != LA_OK || (uint64_t)hi + hc->n_new > caps.S) {
+      if (hc->status != LA_OK || (uint64_t)hi + hc->n_new > caps.S) {
         overflow = true;
         break;
       }
@@ -366,9 +386,10 @@ void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t 
       HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.seg_cnt, d_off, 0u, (size_t)n_states + 1, rocprim::plus<uint32_t>(), st));
       la_gather<<<std::min<uint32_t>(max_blocks, (n_states + 3) / 4), 256, 0, st>>>(ar, d_off, d_out, n_states);
       HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(&hc->n_arcs, d_off + n_states, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       out.n_states = n_states;
-      out.n_arcs = hc->ctl.cursor;
+      out.n_arcs = hc->n_arcs;
       out.n_levels = levels;
       out.off = d_off;
       out.arcs = d_out;

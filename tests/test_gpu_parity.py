@@ -1203,3 +1203,22 @@ def test_compose_large_pair_switches_to_wide_driver(gpu_ctx, oracle, connect):
     ref2 = to_oracle(oracle, a).compose(to_oracle(oracle, b_unsorted), connect=connect).to_flat()
     got2 = to_device(a).compose(to_device(b_unsorted), ComposeConfig(connect=connect)).to_flat()
     assert_flat_identical(got2, ref2, "large compose, output-side matching only")
+
+
+def test_wide_driver_grows_its_arena(gpu_ctx, oracle, monkeypatch):
+    """The wide driver started from a 64-state arena: levels that hold more new tuples than the table has slots (the
+    probe sequence is cut off, the attempt given up) and segments that do not fit are retried with 4x until the result
+    fits — look-ahead and plain composition still equal the oracle."""
+    monkeypatch.setenv("WFST_WIDE_EST_STATES", "64")
+    a = _swap_labels(synth.make_transducer(300, 3, 8, 0.2, seed=1, p_final=0.05))
+    b = synth.make_transducer(20, 8, 8, 0.05, seed=101, p_final=0.05)
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    gpu_ctx.reset_stats()
+    la = rustfst_amd.LookAhead(to_device(a))
+    out = la.compose(la.relabel(to_device(b)))
+    assert gpu_ctx.stats()["compose_retries"] >= 3
+    assert_flat_identical(out.to_flat(), oa.compose_lookahead(ob).to_flat(), "look-ahead, grown arena")
+    gpu_ctx.reset_stats()
+    got = to_device(a).compose(to_device(b))
+    assert gpu_ctx.stats()["compose_retries"] >= 3
+    assert_flat_identical(got.to_flat(), oa.compose(ob).to_flat(), "compose, grown arena")
