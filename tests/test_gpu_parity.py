@@ -1222,3 +1222,27 @@ def test_wide_driver_grows_its_arena(gpu_ctx, oracle, monkeypatch):
     got = to_device(a).compose(to_device(b))
     assert gpu_ctx.stats()["compose_retries"] >= 3
     assert_flat_identical(got.to_flat(), oa.compose(ob).to_flat(), "compose, grown arena")
+
+
+def test_reference_known_answers_reverse_tr_sort_connect(gpu_ctx):
+    """The reference's own vectors for the operations around the path (rustfst-python/tests/algorithms/test_reverse.py:4-57,
+    test_tr_sort.py:4-97, test_connect.py:4-55) through the GPU path: reverse and tr_sort directly; connect as the trim of a
+    composition with the one-state identity-free acceptor of everything (compose(x, sigma*) keeps x's structure)."""
+    g = golden("k9_reverse.json")
+    assert vbuild(g["fst"]).to_device().reverse().to_vector_fst() == vbuild(g["expected"])
+    g = golden("k10_tr_sort.json")
+    assert vbuild(g["fst"]).to_device().tr_sort(True).to_vector_fst() == vbuild(g["expected_ilabel"])
+    assert vbuild(g["fst"]).to_device().tr_sort(False).to_vector_fst() == vbuild(g["expected_olabel"])
+    # connect: compose with a single-state FST that reads every output label of x (olabel l -> l), so the composition is x
+    # itself (ids in BFS order = 0, 1, 2 here) and connect=True trims what test_connect.py trims
+    g = golden("k8_connect.json")
+    x = vbuild(g["fst"])
+    x.tr_sort(False)
+    sig = VectorFst()
+    s0 = sig.add_state()
+    sig.set_start(s0)
+    sig.set_final(s0, 0.0)
+    for l in (2, 4, 5, 6, 8):
+        sig.add_tr(s0, Tr(l, l, 0.0, s0))
+    got = x.compose(sig, ComposeConfig(connect=True))
+    assert got == vbuild(g["expected"])

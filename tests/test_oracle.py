@@ -467,3 +467,28 @@ def test_k7_project_known_answer(oracle):
     f = build(oracle, g["fst"]).project(False)
     from rustfst_amd import synth
     assert f.to_flat()["props"] & synth.ACCEPTOR  # projection.rs:105-119 (the reference's proptest)
+
+
+def test_k8_connect_known_answer(oracle):
+    """rustfst-python/tests/algorithms/test_connect.py:4-55."""
+    g = load_golden("k8_connect.json")
+    f = build(oracle, g["fst"])
+    f.connect()
+    flat_matches_spec(f.to_flat(), g["expected"])
+
+
+def test_k9_reverse_known_answer(oracle):
+    """rustfst-python/tests/algorithms/test_reverse.py:4-57."""
+    g = load_golden("k9_reverse.json")
+    flat_matches_spec(build(oracle, g["fst"]).reverse().to_flat(), g["expected"])
+
+
+def test_k10_tr_sort_known_answer(oracle):
+    """rustfst-python/tests/algorithms/test_tr_sort.py:4-97 (ilabel and olabel comparators, stable)."""
+    g = load_golden("k10_tr_sort.json")
+    a = build(oracle, g["fst"])
+    a.tr_sort(by_olabel=False)
+    flat_matches_spec(a.to_flat(), g["expected_ilabel"])
+    b = build(oracle, g["fst"])
+    b.tr_sort(by_olabel=True)
+    flat_matches_spec(b.to_flat(), g["expected_olabel"])
