@@ -12,7 +12,8 @@
  * (rustfst-python/tests/algorithms/test_shortest_path.py:5-51), K3 (doctest
  * compose/compose_static.rs:282-289) and the K4 loader fixtures
  * (rustfst-tests-data/sigma-matcher-2/{left,right}.fst), K7 project
- * (rustfst-python/tests/algorithms/test_project.py:5-97); the const-format loader on the
+ * (rustfst-python/tests/algorithms/test_project.py:5-97), K8 connect (test_connect.py:4-55),
+ * K9 reverse (test_reverse.py:4-57), K10 tr_sort (test_tr_sort.py:4-97); the const-format loader on the
  * reference's own const files (rustfst-tests-data/fst_012, fst_014 hcl.fst.in: the stored
  * per-state epsilon counters must equal the recomputed ones).  The reference's large
  * OpenFST-generated goldens cannot be produced here (no rustc/cargo, no OpenFST,
