@@ -145,6 +145,12 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
+/* ---- connect: fst_connect (rustfst-ffi/src/algorithms/connect.rs) = rustfst::algorithms::connect
+ *      (rustfst/src/algorithms/connect.rs:51-66): the states that are accessible from the start state and can reach a
+ *      final state, renumbered stably (del_states, vector_fst/mutable_fst.rs:132-189), arcs into deleted states dropped.
+ *      The reference trims in place; here a NEW handle is returned (the caller destroys the old one). ---- */
+wfst_status wfst_connect(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out);
+
 /* ---- project: fst_project (rustfst-ffi/src/algorithms/project.rs:45-70) = rustfst::algorithms::project
  *      (rustfst/src/algorithms/projection.rs:65-95), in place on the device-resident arcs.  project_output == 0:
  *      ProjectType::ProjectInput (olabel := ilabel), != 0: ProjectOutput (ilabel := olabel); the property word follows

@@ -261,6 +261,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint6
 void compose_shortest_path_batch_abandon(wfst_batch_job* job);
 wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 // compose_wide.hip
+wfst_fst* connect_fst(wfst_ctx* ctx, const wfst_fst* f);
 wfst_fst* compose_wide(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, uint32_t mode, uint32_t filter, bool connect,
                        uint64_t out_props, uint64_t est_s);
 }  // namespace wfst

@@ -198,20 +198,67 @@ __global__ void compact_states(const uint32_t* __restrict__ off, const wfst_tr* 
   }
 }
 
-wfst_fst* connect_and_adopt(wfst_ctx* ctx, const WideOutput& w, uint64_t out_props) {
+// accessibility from the start state (ConnectVisitor's `access`, connect.rs:106-115) by forward sweeps to a fixed point
+__global__ void access_sweep(const uint32_t* __restrict__ off, const wfst_tr* __restrict__ arcs, uint32_t* __restrict__ acc,
+                             uint32_t* __restrict__ expanded, uint32_t n, uint32_t* __restrict__ changed) {
+  bool any = false;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    if (!ld_l2(&acc[s]) || expanded[s]) continue;
+    expanded[s] = 1u;
+    for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
+      const uint32_t t = arcs[k].nextstate;
+      if (!ld_l2(&acc[t])) {
+        st_l2(&acc[t], 1u);
+        any = true;
+      }
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1u;
+}
+__global__ void and_flags(uint32_t* __restrict__ co, const uint32_t* __restrict__ acc, uint32_t n) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) co[s] = co[s] & acc[s];
+}
+
+// connect (connect.rs:51-66) of a CSR in HBM: keep = accessible AND coaccessible (every state is accessible when
+// `all_accessible`: a composition just built from its start state), stable renumbering, arcs into deleted states dropped
+wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint32_t* off, const wfst_tr* arcs, const float* fin,
+                            bool all_accessible, uint64_t out_props) {
   hipStream_t st = ctx->stream;
-  const uint32_t n = w.n_states;
+  auto empty = [&] {
+    HostCsr hc;
+    hc.offsets.push_back(0);
+    return make_host_fst(ctx, 0, -1, out_props, std::move(hc));
+  };
+  if (n == 0 || start < 0) return empty();  // no start state: nothing is accessible, del_states removes everything
   DBuf<uint32_t> co(*ctx->pool, (size_t)n + 1), new_id(*ctx->pool, (size_t)n + 1), cnt(*ctx->pool, (size_t)n + 1),
       t_off(*ctx->pool, (size_t)n + 1), changed(*ctx->pool, 1);
   const uint32_t blocks = (n + 255) / 256;
-  coaccess_init<<<blocks, 256, 0, st>>>(w.fin, co.p, n);
+  const uint32_t sweep_blocks = std::min<uint32_t>(blocks, (uint32_t)ctx->n_cus * 16);
   uint32_t* h = (uint32_t*)ctx->pinned.get(4 * sizeof(uint32_t));
+  coaccess_init<<<blocks, 256, 0, st>>>(fin, co.p, n);
   for (;;) {  // backward reachability to a fixed point: as many sweeps as the longest way to a final state at worst
     HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
-    coaccess_sweep<<<std::min<uint32_t>(blocks, (uint32_t)ctx->n_cus * 16), 256, 0, st>>>(w.off, w.arcs, co.p, n, changed.p);
+    coaccess_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, co.p, n, changed.p);
     HIP_CHECK(hipMemcpyAsync(h, changed.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (!h[0]) break;
+  }
+  if (!all_accessible) {
+    DBuf<uint32_t> acc(*ctx->pool, n), expanded(*ctx->pool, n);
+    HIP_CHECK(hipMemsetAsync(acc.p, 0, (size_t)n * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(expanded.p, 0, (size_t)n * sizeof(uint32_t), st));
+    const uint32_t one = 1;
+    HIP_CHECK(hipMemcpyAsync(acc.p + start, &one, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    for (;;) {
+      HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
+      access_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, acc.p, expanded.p, n, changed.p);
+      HIP_CHECK(hipMemcpyAsync(h, changed.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (!h[0]) break;
+    }
+    and_flags<<<blocks, 256, 0, st>>>(co.p, acc.p, n);
+    HIP_CHECK(hipStreamSynchronize(st));  // acc / expanded are released here
   }
   // stable renumbering of the survivors (del_states, mutable_fst.rs:132-158)
   HIP_CHECK(hipMemsetAsync(co.p + n, 0, sizeof(uint32_t), st));
@@ -220,25 +267,25 @@ wfst_fst* connect_and_adopt(wfst_ctx* ctx, const WideOutput& w, uint64_t out_pro
   DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, co.p, new_id.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
   HIP_CHECK(hipMemsetAsync(cnt.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
-  kept_arc_counts<<<blocks, 256, 0, st>>>(w.off, w.arcs, co.p, new_id.p, cnt.p, n);
+  kept_arc_counts<<<blocks, 256, 0, st>>>(off, arcs, co.p, new_id.p, cnt.p, n);
   HIP_CHECK(hipMemcpyAsync(h + 1, new_id.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(h + 3, new_id.p + start, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(h, co.p + start, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   const uint32_t t_states = h[1];
-  if (t_states == 0) {  // the start state reaches no final state: everything is deleted, no start (connect.rs:51-66)
-    HostCsr hc;
-    hc.offsets.push_back(0);
-    return make_host_fst(ctx, 0, -1, out_props, std::move(hc));
-  }
+  // the start state survives iff it reaches a final state; if it does not, nothing accessible does: everything goes
+  if (t_states == 0 || !h[0]) return empty();
+  const int64_t t_start = h[3];
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, cnt.p, t_off.p, 0u, (size_t)t_states + 1, rocprim::plus<uint32_t>(), st));
   HIP_CHECK(hipMemcpyAsync(h + 2, t_off.p + t_states, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   const uint32_t t_arcs_n = h[2];
   DBuf<wfst_tr> t_arcs(*ctx->pool, t_arcs_n);
   DBuf<float> t_fin(*ctx->pool, t_states);
-  compact_states<<<blocks, 256, 0, st>>>(w.off, w.arcs, w.fin, co.p, new_id.p, t_off.p, t_arcs.p, t_fin.p, n);
+  compact_states<<<blocks, 256, 0, st>>>(off, arcs, fin, co.p, new_id.p, t_off.p, t_arcs.p, t_fin.p, n);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(st));
-  return adopt_device(ctx, t_states, t_arcs_n, 0, out_props, t_off.p, t_arcs.p, t_fin.p);
+  return adopt_device(ctx, t_states, t_arcs_n, t_start, out_props, t_off.p, t_arcs.p, t_fin.p);
 }
 
 }  // namespace
@@ -251,7 +298,16 @@ wfst_fst* compose_wide(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, ui
   ctx->stats.compose_states = w.n_states;
   ctx->stats.compose_arcs = w.n_arcs;
   if (!connect) return adopt_device(ctx, w.n_states, w.n_arcs, 0, out_props, w.off, w.arcs, w.fin);
-  return connect_and_adopt(ctx, w, out_props);
+  return connect_and_adopt(ctx, w.n_states, 0, w.off, w.arcs, w.fin, /*all_accessible=*/true, out_props);
+}
+
+// connect (algorithms/connect.rs:51-66) of a resident FST: a new handle with the accessible and coaccessible states
+wfst_fst* connect_fst(wfst_ctx* ctx, const wfst_fst* f) {
+  using namespace props;
+  ensure_device(const_cast<wfst_fst*>(f));
+  // del_states -> delete_states_properties, then ACCESSIBLE | COACCESSIBLE (connect.rs:61-64)
+  const uint64_t out_props = (delete_states(f->props) & ~(ACCESSIBLE | NOT_ACCESSIBLE | COACCESSIBLE | NOT_COACCESSIBLE)) | ACCESSIBLE | COACCESSIBLE;
+  return connect_and_adopt(ctx, f->n_states, f->start, f->dev.offsets, f->dev.arcs, f->dev.finals, /*all_accessible=*/false, out_props);
 }
 
 }  // namespace wfst

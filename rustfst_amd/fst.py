@@ -263,6 +263,12 @@ class DeviceFst:
         check(_lib.lib().wfst_reverse(self.ctx._h, self._h, C.byref(out)), "Error during reverse")
         return DeviceFst(out, self.ctx)
 
+    def connect(self) -> "DeviceFst":
+        """algorithms::connect (connect.rs:51-66): a NEW FST with the accessible and coaccessible states only."""
+        out = C.c_void_p()
+        check(_lib.lib().wfst_connect(self.ctx._h, self._h, C.byref(out)), "Error during connect")
+        return DeviceFst(out, self.ctx)
+
     def project(self, proj_type: Optional["ProjectType"] = None) -> "DeviceFst":
         """In-place projection on the device (algorithms/projection.rs:65-95): PROJECT_INPUT copies the input labels
         over the output labels, PROJECT_OUTPUT the other way round."""
@@ -677,6 +683,13 @@ class VectorFst:
 
     def shortest_path(self, config: Union[ShortestPathConfig, None] = None) -> "VectorFst":
         return self.to_device().shortest_path(config).to_vector_fst()
+
+    def connect(self) -> "VectorFst":
+        """rustfst-python vector_fst.py `connect` (algorithms/connect.py): trims this FST in place and returns it."""
+        trimmed = self.to_device().connect().to_vector_fst()
+        self._p, trimmed._p = trimmed._p, self._p  # this object now owns the trimmed FST; the old one dies with `trimmed`
+        self._dev = None
+        return self
 
     def project(self, proj_type: Union["ProjectType", None] = None) -> "VectorFst":
         """rustfst-python vector_fst.py `project` (algorithms/project.py:27-50): returns the projected FST."""

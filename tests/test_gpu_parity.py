@@ -1246,3 +1246,27 @@ def test_reference_known_answers_reverse_tr_sort_connect(gpu_ctx):
         sig.add_tr(s0, Tr(l, l, 0.0, s0))
     got = x.compose(sig, ComposeConfig(connect=True))
     assert got == vbuild(g["expected"])
+
+
+def test_connect_known_answer_and_oracle(gpu_ctx, oracle):
+    """wfst_connect: the reference's test_connect.py:4-55 vector directly, then random FSTs with inaccessible and
+    non-coaccessible parts (and without start / without finals) against the oracle: survivors, stable renumbering, arc
+    compaction, start state and property word."""
+    g = golden("k8_connect.json")
+    x = vbuild(g["fst"])
+    res = x.connect()
+    assert x == vbuild(g["expected"]) and res == vbuild(g["expected"])
+    rng = np.random.default_rng(88)
+    for k in range(30):
+        f = random_fst_flat(rng, int(rng.integers(1, 80)), 3, 4, p_eps_i=0.1, p_final=(0.0, 0.05, 0.3)[k % 3],
+                            sort=("ilabel", "none")[k % 2], acyclic=(k % 4 == 0))
+        if k % 7 == 3:
+            f = dict(f)
+            f["start"] = -1
+        ref = to_oracle(oracle, f)
+        ref.connect()
+        assert_flat_identical(to_device(f).connect().to_flat(), ref.to_flat(), f"connect {k}")
+    deep = synth.make_transducer(5000, 1, 4, 0.0, seed=4, p_final=0.0005)  # a 5000-state ring: thousands of sweeps
+    ref = to_oracle(oracle, deep)
+    ref.connect()
+    assert_flat_identical(to_device(deep).connect().to_flat(), ref.to_flat(), "connect on a ring")
