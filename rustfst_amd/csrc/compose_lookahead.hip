@@ -24,15 +24,12 @@
 //  * compose_lookahead_kernel: ONE wave does the whole composition (small results: no launch per level).  Destinations
 //    are interned after each level in emission order, 64 at a time: duplicates inside a chunk are folded with shuffles,
 //    the distinct keys then probe a table of two 64-bit words per slot (the claim is one CAS on the first word, the
-//    second word is written by the winner before anybody compares it: the wave executes the two steps in program order).
-//    It gives up (LA_SWITCH_WIDE) once the result passes WIDE_SWITCH_STATES states.
-//  * the wide path (la_emit / la_first / la_assign / la_patch kernels, one launch each per BFS level, the host reads back
-//    one control block per level): one wave per composed state of the level, thousands of waves in flight.  A state's
-//    arcs go to a segment reserved with one atomicAdd; every destination tuple is inserted into the table together with
-//    atomicMin(order of the emission = position of the state in the level << 32 | position of the arc in its segment);
-//    a tuple is new iff it has no id yet, its first emission is the arc whose order equals the table's minimum; firsts
-//    are counted per state, scanned over the level, and numbered = the reference's first-touch ids.  Segments are
-//    gathered into CSR order at the end.
+//    winner writes the second; a lane that finds the first word equal but the second still "unset" retries the slot on the
+//    next iteration of the wave-uniform loop).  One launch takes a whole batch (one wave per problem:
+//    wfst_compose_lookahead_batch).  It gives up (LA_SWITCH_WIDE) once a BFS level adds more than WIDE_SWITCH_WIDTH states
+//    or the result passes WIDE_SWITCH_STATES.
+//  * the wide driver of compose_wide.h (one wave per composed state of a BFS level, one launch set per level), with the
+//    look-ahead filter stack as its policy (LaPolicy below).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
