@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "compose_filters.h"
 #include "fst_props.h"
 
 namespace wfst {
@@ -374,35 +375,8 @@ __device__ int expand_state(const FstView& f1, const FstView& f2, uint32_t mode,
   //   X: arc1.olabel == NO_LABEL (fst1 stands still, fst2 takes an input-epsilon arc)
   //   Y: arc2.ilabel == NO_LABEL (fst2 stands still, fst1 takes an output-epsilon arc)
   //   Z: both real, arc1.olabel == 0 == arc2.ilabel                 M: both real, matching non-epsilon label
-  uint32_t fsX, fsY, fsZ, fsM = 0u;
-  switch (filter) {
-    case 1:  // NullComposeFilter :122-129
-      fsX = fsY = REJECT;
-      fsZ = 0u;
-      break;
-    case 2:  // TrivialComposeFilter :122-124
-      fsX = fsY = fsZ = 0u;
-      break;
-    case 4:  // AltSequenceComposeFilter :160-181
-      fsY = alleps2 ? REJECT : (noeps2 ? 0u : 1u);
-      fsX = fs == 1u ? REJECT : 0u;
-      fsZ = REJECT;
-      break;
-    case 5:  // MatchComposeFilter :149-205
-      fsY = fs == 0u ? (noeps2 ? 0u : (alleps2 ? REJECT : 1u)) : (fs == 1u ? 1u : REJECT);
-      fsX = fs == 0u ? (noeps1 ? 0u : (alleps1 ? REJECT : 2u)) : (fs == 2u ? 2u : REJECT);
-      fsZ = fs == 0u ? 0u : REJECT;
-      break;
-    case 6:  // NoMatchComposeFilter :122-126
-      fsX = fsY = 0u;
-      fsZ = REJECT;
-      break;
-    default:  // Auto / SequenceComposeFilter :150-171
-      fsX = alleps1 ? REJECT : (noeps1 ? 0u : 1u);
-      fsY = fs != 0u ? REJECT : 0u;
-      fsZ = REJECT;
-      break;
-  }
+  const FilterOutcomes fo = filter_outcomes(filter, fs, alleps1, noeps1, alleps2, noeps2);  // compose_filters.h
+  const uint32_t fsX = fo.fsX, fsY = fo.fsY, fsZ = fo.fsZ, fsM = 0u;
   const uint32_t fs_nolabel = mi ? fsX : fsY;  // iterated arc labelled NO_LABEL (the loop pseudo-arc)
   const uint32_t fs_eps = mi ? fsY : fsX;      // iterated arc labelled 0 paired with the matcher's EpsLoop
 

@@ -7,6 +7,7 @@
 // SortedMatcher + EpsLoop (matchers/sorted_matcher.rs:124-184, matchers/mod.rs:98-105), the six filters as per-state
 // outcome classes, ComposeFstOp::{compute_trs, compute_final_weight} (compose_fst_op.rs:406-449), first-touch state ids,
 // connect + del_states (connect.rs:51-66, vector_fst/mutable_fst.rs:132-189).
+#include "compose_filters.h"
 #include "compose_wide.h"
 #include "fst_props.h"
 
@@ -72,36 +73,8 @@ struct PlainPolicy {
     x.n_se = x.mi ? n2 : n1;
     x.sa = x.mi ? s2 : s1;
     x.sb = x.mi ? s1 : s2;
-    // X: arc1.olabel == NO_LABEL, Y: arc2.ilabel == NO_LABEL, Z: real epsilon:epsilon pair, M: matching non-epsilon label
-    uint32_t fsX, fsY, fsZ;
-    switch (filter) {
-      case 1:  // NullComposeFilter, null_compose_filter.rs:122-129
-        fsX = fsY = REJECT;
-        fsZ = 0u;
-        break;
-      case 2:  // TrivialComposeFilter, trivial_compose_filter.rs:122-124
-        fsX = fsY = fsZ = 0u;
-        break;
-      case 4:  // AltSequenceComposeFilter, alt_sequence_compose_filter.rs:160-181
-        fsY = alleps2 ? REJECT : (noeps2 ? 0u : 1u);
-        fsX = fs == 1u ? REJECT : 0u;
-        fsZ = REJECT;
-        break;
-      case 5:  // MatchComposeFilter, match_compose_filter.rs:149-205
-        fsY = fs == 0u ? (noeps2 ? 0u : (alleps2 ? REJECT : 1u)) : (fs == 1u ? 1u : REJECT);
-        fsX = fs == 0u ? (noeps1 ? 0u : (alleps1 ? REJECT : 2u)) : (fs == 2u ? 2u : REJECT);
-        fsZ = fs == 0u ? 0u : REJECT;
-        break;
-      case 6:  // NoMatchComposeFilter, no_match_compose_filter.rs:122-126
-        fsX = fsY = 0u;
-        fsZ = REJECT;
-        break;
-      default:  // Auto / SequenceComposeFilter, sequence_compose_filter.rs:150-171
-        fsX = alleps1 ? REJECT : (noeps1 ? 0u : 1u);
-        fsY = fs != 0u ? REJECT : 0u;
-        fsZ = REJECT;
-        break;
-    }
+    const FilterOutcomes fo = filter_outcomes(filter, fs, alleps1, noeps1, alleps2, noeps2);  // compose_filters.h
+    const uint32_t fsX = fo.fsX, fsY = fo.fsY, fsZ = fo.fsZ;
     x.fs_nolabel = x.mi ? fsX : fsY;  // the loop pseudo-arc of the iterated side against the searched side's epsilon arcs
     x.fs_eps = x.mi ? fsY : fsX;      // an epsilon of the iterated side against the matcher's EpsLoop
     x.fsZ = fsZ;
