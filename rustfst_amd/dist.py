@@ -154,3 +154,42 @@ def interleave(gathered: np.ndarray, n_total: int) -> np.ndarray:
         idx = shard_indices(n_total, r, world)
         out[idx] = gathered[r, :len(idx)]
     return out
+
+
+def gather_fsts(local: Sequence[bytes], world: int, device=None) -> List[List[bytes]]:
+    """All-gather results that are general FSTs (n-best trees, look-ahead compositions: BASELINE configs[4]) rather than
+    linear paths: each rank passes its results serialised in the OpenFST binary format (`DeviceFst.to_bytes()` /
+    `VectorFst.to_bytes()`), every rank gets `[rank][i] -> bytes`.  Two collectives: the byte counts, then the payloads
+    padded to the largest rank (RCCL when `device` is a GPU, gloo on CPU).  Ranks may hold different numbers of results."""
+    import torch
+    import torch.distributed as dist
+
+    sizes = np.array([len(b) for b in local], dtype=np.int64)
+    kw = {} if device is None else {"device": device}
+    n_local = torch.tensor([len(local), int(sizes.sum())], dtype=torch.int64, **kw)
+    counts = torch.empty(world * 2, dtype=torch.int64, **kw)  # (concatenation layout: accepted by gloo and nccl/RCCL)
+    dist.all_gather_into_tensor(counts, n_local)
+    counts = counts.cpu().numpy().reshape(world, 2)
+    max_n, max_bytes = int(counts[:, 0].max()), int(counts[:, 1].max())
+    # one record per rank: [sizes (max_n x i64) | payload (max_bytes, padded)]
+    rec = np.zeros(8 * max_n + max_bytes, dtype=np.uint8)
+    rec[:8 * len(local)] = sizes.view(np.uint8)
+    if len(local):
+        rec[8 * max_n:8 * max_n + int(sizes.sum())] = np.frombuffer(b"".join(local), dtype=np.uint8)
+    t = torch.from_numpy(rec)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty(world * rec.shape[0], dtype=torch.uint8, **kw)
+    dist.all_gather_into_tensor(out, t)
+    out = out.cpu().numpy().reshape(world, rec.shape[0])
+    res = []
+    for r in range(world):
+        n_r = int(counts[r, 0])
+        sz = out[r, :8 * n_r].view(np.int64)
+        off = 8 * max_n
+        items = []
+        for s in sz:
+            items.append(out[r, off:off + int(s)].tobytes())
+            off += int(s)
+        res.append(items)
+    return res

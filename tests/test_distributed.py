@@ -100,3 +100,53 @@ def test_pack_unpack_roundtrip():
     assert np.array_equal(back[0]["arcs"], arcs) and np.array_equal(back[0]["finals"], p["finals"])
     assert np.array_equal(back[0]["offsets"], p["offsets"])
     assert back[1]["n_states"] == 0
+
+
+def _worker_fsts(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from oracle import oracle_py
+    from rustfst_amd import dist as wdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def tree(k):  # a small non-linear FST (what an n-best search returns), different per (rank, k); serialised by the
+            f = oracle_py.OracleFst()  # oracle here (no GPU in this container), by DeviceFst.to_bytes() on a GPU box
+            for _ in range(3 + k):
+                f.add_state()
+            f.set_start(0)
+            for s in range(1, 3 + k):
+                f.add_tr(0, s, s + rank, 0.5 * s, s)
+                f.set_final(s, float(rank))
+            return f
+        mine = [tree(k) for k in range(2 + rank)]  # ragged: rank 0 holds 2 results, rank 1 holds 3
+        blobs = [f.store() for f in mine]
+        got = wdist.gather_fsts(blobs, world, None)
+        ok = len(got) == world and [len(g) for g in got] == [2 + r for r in range(world)]
+        ok &= got[rank] == blobs
+        other = 1 - rank
+        back = oracle_py.OracleFst.load(got[other][0]).to_flat()
+        ok &= back["n_states"] == 3 and int(back["arcs"]["olabel"][0]) == 1 + other
+        ok &= wdist.gather_fsts([], world, None) == [[] for _ in range(world)]
+        if rank == 0:
+            q.put("ok" if ok else "mismatch")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_gather_general_fsts_gloo_world2():
+    """dist.gather_fsts: results that are general FSTs (n-best trees, look-ahead compositions) travel serialised in the
+    OpenFST binary format; ragged per-rank counts, empty contribution."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fsts, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == "ok"
