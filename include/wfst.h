@@ -145,7 +145,7 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
  * `distance`, shortest_path.rs:173-239) copied to host arrays of n_states entries; hops may be NULL. */
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops);
 
-/* ---- connect: fst_connect (rustfst-ffi/src/algorithms/connect.rs) = rustfst::algorithms::connect
+/* ---- connect: fst_connect (rustfst-ffi/src/algorithms/connect.rs:14-23) = rustfst::algorithms::connect
  *      (rustfst/src/algorithms/connect.rs:51-66): the states that are accessible from the start state and can reach a
  *      final state, renumbered stably (del_states, vector_fst/mutable_fst.rs:132-189), arcs into deleted states dropped.
  *      The reference trims in place; here a NEW handle is returned (the caller destroys the old one). ---- */
