@@ -172,6 +172,10 @@ inline uint64_t add_tr_properties(uint64_t in, uint32_t state, const oracle_tr& 
   return out;
 }
 inline uint64_t delete_states_properties(uint64_t in) { return in & DELETE_STATES_MASK; }  // :102-104
+// delete_arcs_properties(): properties.rs:300-316 (delete_trs_properties, mutate_properties.rs:110-112)
+constexpr uint64_t DELETE_ARCS_MASK = ACCEPTOR | I_DETERMINISTIC | O_DETERMINISTIC | NO_EPSILONS | NO_I_EPSILONS | NO_O_EPSILONS |
+                                      I_LABEL_SORTED | O_LABEL_SORTED | UNWEIGHTED | ACYCLIC | INITIAL_ACYCLIC | TOP_SORTED |
+                                      NOT_ACCESSIBLE | NOT_COACCESSIBLE | UNWEIGHTED_CYCLES;
 // mutate_properties.rs:151-184
 inline uint64_t compose_properties(uint64_t p1, uint64_t p2) {
   uint64_t out = 0;
@@ -670,9 +674,14 @@ bool compose_impl(const Fst& fst1, const Fst& fst2, bool connect, Fst& fst_out, 
 }
 
 // ---------------------------------------------------------------- dfs_visit (dfs_visit.rs:97-187)
-// AnyTrFilter keeps every arc (tr_filters.rs).
-template <class V>
-void dfs_visit(const Fst& fst, V& visitor, bool access_only) {
+struct KeepAll {  // AnyTrFilter (tr_filters.rs)
+  bool operator()(const Tr&) const { return true; }
+};
+struct KeepEpsilon {  // EpsilonTrFilter (tr_filters.rs:25-31)
+  bool operator()(const Tr& tr) const { return tr.ilabel == EPS_LABEL && tr.olabel == EPS_LABEL; }
+};
+template <class V, class K = KeepAll>
+void dfs_visit(const Fst& fst, V& visitor, bool access_only, K keep = K()) {
   visitor.init_visit(fst);
   if (!fst.has_start) {
     visitor.finish_visit();
@@ -711,6 +720,10 @@ void dfs_visit(const Fst& fst, V& visitor, bool access_only) {
         continue;
       }
       const Tr& tr = trs[ds.pos];
+      if (!keep(tr)) {  // dfs_visit.rs:146-149
+        ds.pos++;
+        continue;
+      }
       switch (color[tr.nextstate]) {
         case White:
           dfs = visitor.tree_tr(s, tr);
@@ -1010,7 +1023,8 @@ struct SccQueue : Queue {  // queues/scc_queue.rs:6-84
 
 // AutoQueue::new(fst, distance=None, AnyTrFilter) — queues/auto_queue.rs:23-157.
 // With distance=None `less` is None (:52-59) so every intra-SCC arc selects FifoQueue (:130-131).
-std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
+template <class K>
+std::unique_ptr<Queue> auto_queue_new(const Fst& fst, K keep) {
   const uint64_t props = fst.properties;
   if ((props & P::TOP_SORTED) || !fst.has_start) {
     t_queue_kind = "state_order";
@@ -1018,7 +1032,7 @@ std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
   }
   if (props & P::ACYCLIC) {
     TopOrderVisitor v;
-    dfs_visit(fst, v, false);
+    dfs_visit(fst, v, false, keep);
     // (reference panics if !acyclic, top_order_queue.rs:24-26)
     t_queue_kind = "top_order";
     return std::make_unique<TopOrderQueue>(std::move(v.order));
@@ -1028,7 +1042,7 @@ std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
     return std::make_unique<LifoQueue>();
   }
   SccVisitor sv(fst, true);
-  dfs_visit(fst, sv, false);
+  dfs_visit(fst, sv, false, keep);
   std::vector<uint32_t> sccs(sv.scc.size());
   for (size_t i = 0; i < sccs.size(); ++i) sccs[i] = (uint32_t)sv.scc[i];
   const size_t n_sccs = (size_t)sv.nscc;
@@ -1037,6 +1051,7 @@ std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
   bool all_trivial = true, unweighted = true;
   for (size_t state = 0; state < fst.num_states(); ++state) {
     for (const Tr& tr : fst.states[state].trs) {
+      if (!keep(tr)) continue;  // auto_queue.rs:123-125
       if (sccs[state] == sccs[tr.nextstate]) {
         QueueType& qt = queue_types[sccs[state]];
         qt = QueueType::Fifo;  // compare.is_none()
@@ -1065,6 +1080,7 @@ std::unique_ptr<Queue> auto_queue_new(const Fst& fst) {
   t_queue_kind = "scc";
   return q;
 }
+inline std::unique_ptr<Queue> auto_queue_new(const Fst& fst) { return auto_queue_new(fst, KeepAll()); }
 
 // ---------------------------------------------------------------- shortest path n=1 (B1,B3)
 // single_shortest_path — shortest_path.rs:173-239
@@ -1208,6 +1224,208 @@ std::vector<float> shortest_distance_impl(const Fst& fst, float delta) {
     }
   }
   return distance;
+}
+
+// ---------------------------------------------------------------- rm_epsilon (N4) — algorithms/rm_epsilon/*.rs
+// ShortestDistanceState with EpsilonTrFilter, retain = true (shortest_distance.rs:100-237): one instance serves every
+// source; entries of states not touched by the current source keep their old values and are reset lazily (`sources`).
+struct EpsSdState {
+  std::unique_ptr<Queue> queue;
+  std::vector<float> distance, adder, radder;
+  std::vector<bool> enqueued;
+  std::vector<int64_t> sources;  // Option<StateId>: -1 = None
+  int64_t source_id = 0;
+  float delta;
+  void ensure(size_t index) {
+    while (distance.size() <= index) {
+      distance.push_back(INF);
+      enqueued.push_back(false);
+      adder.push_back(INF);
+      radder.push_back(INF);
+    }
+  }
+  void ensure_source(size_t index) {
+    while (sources.size() <= index) sources.push_back(-1);
+  }
+  const std::vector<float>& shortest_distance(const Fst& fst, uint32_t src) {
+    KeepEpsilon keep;
+    queue->clear();
+    const size_t source = src;
+    ensure(source);
+    ensure_source(source);
+    sources[source] = source_id;
+    distance[source] = 0.0f;
+    adder[source] = 0.0f;
+    radder[source] = 0.0f;
+    enqueued[source] = true;
+    queue->enqueue((uint32_t)source);
+    uint32_t st;
+    while (queue->dequeue(&st)) {
+      const size_t state = st;
+      enqueued[state] = false;
+      const float r = radder[state];
+      radder[state] = INF;
+      for (const Tr& tr : fst.states[state].trs) {
+        const size_t nextstate = tr.nextstate;
+        if (!keep(tr)) continue;
+        ensure(nextstate);
+        ensure_source(nextstate);
+        if (sources[nextstate] != source_id) {
+          distance[nextstate] = INF;
+          adder[nextstate] = INF;
+          radder[nextstate] = INF;
+          enqueued[nextstate] = false;
+          sources[nextstate] = source_id;
+        }
+        const float weight = wtimes(r, tr.weight);
+        if (!approx_equal(distance[nextstate], wplus(distance[nextstate], weight), delta)) {
+          adder[nextstate] = wplus(adder[nextstate], weight);
+          distance[nextstate] = adder[nextstate];
+          radder[nextstate] = wplus(radder[nextstate], weight);
+          if (!enqueued[state]) {  // (sic) shortest_distance.rs:224
+            queue->enqueue((uint32_t)nextstate);
+            enqueued[nextstate] = true;
+          } else {
+            queue->update((uint32_t)nextstate);
+          }
+        }
+      }
+    }
+    source_id += 1;
+    return distance;
+  }
+};
+
+// rm_epsilon with the default config (connect = true, no thresholds, delta = KSHORTESTDELTA): rm_epsilon_static.rs:50-163,
+// RmEpsilonState::expand rm_epsilon_state.rs:44-119, rmepsilon_properties mutate_properties.rs:646-660
+bool rm_epsilon_impl(Fst& fst) {
+  if (!fst.has_start) return true;
+  KeepEpsilon keep;
+  const size_t n = fst.num_states();
+  // noneps_in[s]: s has a non-epsilon incoming arc or is the start state
+  std::vector<bool> noneps_in(n, false);
+  noneps_in[fst.start] = true;
+  for (const State& st : fst.states)
+    for (const Tr& tr : st.trs)
+      if (tr.ilabel != EPS_LABEL || tr.olabel != EPS_LABEL) noneps_in[tr.nextstate] = true;
+  // states in (generic) topological order of the epsilon graph
+  std::vector<uint32_t> states;
+  if (fst.properties & P::TOP_SORTED) {
+    for (size_t s = 0; s < n; ++s) states.push_back((uint32_t)s);
+  } else if (fst.properties & P::ACYCLIC) {
+    TopOrderVisitor v;
+    dfs_visit(fst, v, false, keep);
+    states.assign(v.order.size(), 0);
+    for (size_t i = 0; i < v.order.size(); ++i) states[v.order[i]] = (uint32_t)i;
+  } else {
+    SccVisitor v(fst, true);
+    dfs_visit(fst, v, false, keep);
+    const std::vector<int32_t>& scc = v.scc;
+    std::vector<int64_t> first(scc.size(), -1), next(scc.size(), -1);
+    for (size_t i = 0; i < scc.size(); ++i) {
+      if (first[scc[i]] >= 0) next[i] = first[scc[i]];
+      first[scc[i]] = (int64_t)i;
+    }
+    for (size_t c = 0; c < first.size(); ++c)
+      for (int64_t j = first[c]; j >= 0; j = next[j]) states.push_back((uint32_t)j);
+  }
+  EpsSdState sd;
+  sd.queue = auto_queue_new(fst, keep);  // AutoQueue::new(fst, None, &EpsilonTrFilter), rm_epsilon_static.rs:52
+  sd.delta = 1e-6f;                      // KSHORTESTDELTA (lib.rs:271)
+  // RmEpsilonState
+  std::vector<bool> visited;
+  std::vector<uint32_t> visited_states;
+  struct Elt {
+    uint32_t il, ol, ns;
+    bool operator==(const Elt& o) const { return il == o.il && ol == o.ol && ns == o.ns; }
+  };
+  struct EltHash {
+    size_t operator()(const Elt& e) const {
+      uint64_t h = ((uint64_t)e.il << 32) ^ ((uint64_t)e.ol << 11) ^ e.ns;
+      h *= 0x9E3779B97F4A7C15ull;
+      return (size_t)(h ^ (h >> 29));
+    }
+  };
+  std::unordered_map<Elt, std::pair<uint64_t, size_t>, EltHash> element_map;
+  uint64_t expand_id = 0;
+  for (size_t idx = states.size(); idx-- > 0;) {
+    const uint32_t state = states[idx];
+    if (!noneps_in[state]) continue;  // (connect is set)
+    // expand
+    const std::vector<float>& distance = sd.shortest_distance(fst, state);
+    std::vector<uint32_t> eps_queue{state};
+    std::vector<Tr> trs;
+    float final_weight = INF;
+    while (!eps_queue.empty()) {
+      const uint32_t q = eps_queue.back();
+      eps_queue.pop_back();
+      while (visited.size() <= q) visited.push_back(false);
+      if (visited[q]) continue;
+      visited[q] = true;
+      visited_states.push_back(q);
+      for (const Tr& tr0 : fst.states[q].trs) {
+        Tr tr = tr0;
+        tr.weight = wtimes(distance[q], tr.weight);
+        if (keep(tr)) {
+          while (visited.size() <= tr.nextstate) visited.push_back(false);
+          if (!visited[tr.nextstate]) eps_queue.push_back(tr.nextstate);
+        } else {
+          const Elt elt{tr.ilabel, tr.olabel, tr.nextstate};
+          auto it = element_map.find(elt);
+          if (it == element_map.end()) {
+            element_map.emplace(elt, std::make_pair(expand_id, trs.size()));
+            trs.push_back(tr);
+          } else if (it->second.first == expand_id) {
+            trs[it->second.second].weight = wplus(trs[it->second.second].weight, tr.weight);
+          } else {
+            it->second.first = expand_id;
+            it->second.second = trs.size();
+            trs.push_back(tr);
+          }
+        }
+      }
+      const State& qs = fst.states[q];
+      final_weight = wplus(final_weight, wtimes(distance[q], qs.has_final ? qs.final_w : INF));
+    }
+    while (!visited_states.empty()) {
+      visited[visited_states.back()] = false;
+      visited_states.pop_back();
+    }
+    expand_id += 1;
+    // pop_trs_unchecked (mutable_fst.rs:325-331: delete_trs_properties), set_trs_unchecked(reversed), final weight
+    fst.properties &= P::DELETE_ARCS_MASK;
+    std::reverse(trs.begin(), trs.end());
+    fst.set_trs_unchecked(state, std::move(trs));
+    State& st = fst.states[state];
+    if (!wis_zero(final_weight)) {  // `final_weight != zero`: the KDELTA-approximate != of the weight
+      fst.properties = P::set_final_properties(fst.properties, st.has_final ? &st.final_w : nullptr, &final_weight);
+      st.has_final = true;
+      st.final_w = final_weight;
+    } else {
+      fst.properties = P::set_final_properties(fst.properties, st.has_final ? &st.final_w : nullptr, nullptr);
+      st.has_final = false;
+      st.final_w = INF;
+    }
+  }
+  for (size_t s = 0; s < fst.num_states(); ++s) {  // (connect is set) rm_epsilon_static.rs:137-143
+    if (!noneps_in[s]) {
+      State& st = fst.states[s];
+      st.trs.clear();
+      st.niepsilons = st.noepsilons = 0;
+      fst.properties &= P::DELETE_ARCS_MASK;
+    }
+  }
+  {  // rmepsilon_properties(props, delayed = false)
+    const uint64_t in = fst.properties;
+    uint64_t out = P::NO_EPSILONS;
+    out |= (P::ACCEPTOR | P::ACYCLIC | P::INITIAL_ACYCLIC) & in;
+    if (in & P::ACCEPTOR) out |= P::NO_I_EPSILONS | P::NO_O_EPSILONS;
+    out |= P::TOP_SORTED & in;
+    out |= P::NOT_ACCEPTOR & in;
+    fst.set_properties(out);
+  }
+  connect_impl(fst);
+  return true;
 }
 
 // ---------------------------------------------------------------- reverse (B5) — reverse.rs:33-87
@@ -2694,6 +2912,12 @@ void oracle_fst_project(oracle_fst* f, int project_output) {
     if (in & P::NOT_O_LABEL_SORTED) out |= P::NOT_I_LABEL_SORTED;
   }
   f->set_properties_with_mask(out, P::ALL);
+}
+
+// rm_epsilon (default config): algorithms/rm_epsilon/rm_epsilon_static.rs:50-163, in place
+int oracle_rm_epsilon(oracle_fst* f) {
+  DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  return rm_epsilon_impl(*f) ? 0 : 1;
 }
 
 int oracle_connect(oracle_fst* f) {

@@ -61,6 +61,7 @@ def lib():
         L.oracle_compose.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_compose_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.oracle_connect.argtypes = [vp]
+        L.oracle_rm_epsilon.argtypes = [vp]
         L.oracle_fst_project.argtypes = [vp, C.c_int]
         L.oracle_compose_lookahead.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.oracle_interval_set_normalize.argtypes = [vp, C.c_size_t, C.POINTER(u64)]
@@ -237,6 +238,11 @@ class OracleFst:
 
     def connect(self):
         lib().oracle_connect(self._h)
+
+    def rm_epsilon(self):
+        if lib().oracle_rm_epsilon(self._h):
+            raise _err()
+        return self
 
     def project(self, project_output=False):
         lib().oracle_fst_project(self._h, 1 if project_output else 0)

@@ -404,7 +404,7 @@ def _successful_paths(flat, max_paths=200000):
     from collections import Counter
     off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
     out = Counter()
-    if flat["start"] < 0:
+    if flat["start"] is None or flat["start"] < 0:
         return out
     stack = [(flat["start"], (), (), 0.0)]
     while stack:
@@ -492,3 +492,36 @@ def test_k10_tr_sort_known_answer(oracle):
     b = build(oracle, g["fst"])
     b.tr_sort(by_olabel=True)
     flat_matches_spec(b.to_flat(), g["expected_olabel"])
+
+
+def test_k11_rm_epsilon_known_answer(oracle):
+    """rustfst-python/tests/algorithms/test_rm_epsilon.py:4-54 (default config: connect, no thresholds)."""
+    g = load_golden("k11_rm_epsilon.json")
+    flat_matches_spec(build(oracle, g["fst"]).rm_epsilon().to_flat(), g["expected"])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_rm_epsilon_keeps_the_weighted_relation(oracle, seed):
+    """rm_epsilon removes every epsilon:epsilon arc and keeps the weighted relation: no such arc is left, and on acyclic
+    inputs the (min,+)-combined weight of every (input string, output string) pair is unchanged; on cyclic inputs the
+    best path weight is."""
+    rng = np.random.default_rng(12_000 + seed)
+    acyclic = seed % 2 == 0
+    f = random_fst_flat(rng, int(rng.integers(1, 14)), 3, 3, p_eps_i=0.5, p_eps_o=0.5, p_final=0.35, acyclic=acyclic, sort="none")
+    o = to_oracle(oracle, f)
+    before = o.to_flat()
+    best_before = o.shortest_path().to_flat()
+    o.rm_epsilon()
+    after = o.to_flat()
+    assert not np.any((after["arcs"]["ilabel"] == 0) & (after["arcs"]["olabel"] == 0))
+
+    def total(p):
+        return None if p["n_states"] == 0 else round((float(p["arcs"]["weight"].sum()) + float(p["finals"][0])) * 1024)
+    assert total(best_before) == total(to_oracle(oracle, after).shortest_path().to_flat())
+    if acyclic:
+        def best_per_string(flat):
+            best = {}
+            for (il, ol, w), _ in _successful_paths(flat).items():
+                best[(il, ol)] = min(best.get((il, ol), 1 << 60), w)
+            return best
+        assert best_per_string(before) == best_per_string(after)
