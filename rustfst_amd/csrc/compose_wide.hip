@@ -193,6 +193,8 @@ __global__ void and_flags(uint32_t* __restrict__ co, const uint32_t* __restrict_
   if (s < n) co[s] = co[s] & acc[s];
 }
 
+}  // namespace
+
 // connect (connect.rs:51-66) of a CSR in HBM: keep = accessible AND coaccessible (every state is accessible when
 // `all_accessible`: a composition just built from its start state), stable renumbering, arcs into deleted states dropped
 wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint32_t* off, const wfst_tr* arcs, const float* fin,
@@ -260,8 +262,6 @@ wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint
   HIP_CHECK(hipStreamSynchronize(st));
   return adopt_device(ctx, t_states, t_arcs_n, t_start, out_props, t_off.p, t_arcs.p, t_fin.p);
 }
-
-}  // namespace
 
 wfst_fst* compose_wide(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, uint32_t mode, uint32_t filter, bool connect,
                        uint64_t out_props, uint64_t est_s) {
