@@ -151,6 +151,12 @@ wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* di
  *      The reference trims in place; here a NEW handle is returned (the caller destroys the old one). ---- */
 wfst_status wfst_connect(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out);
 
+/* ---- rm_epsilon: fst_rm_epsilon (rustfst-ffi/src/algorithms/rm_epsilon.rs) = rustfst::algorithms::rm_epsilon
+ *      (rustfst/src/algorithms/rm_epsilon/rm_epsilon_static.rs:50-163) with its default configuration (connect, no
+ *      thresholds): every epsilon:epsilon arc removed, the weighted relation kept, the result connected.  The reference
+ *      works in place; here a NEW handle is returned.  An FST without a start state is returned unchanged. ---- */
+wfst_status wfst_rm_epsilon(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out);
+
 /* ---- project: fst_project (rustfst-ffi/src/algorithms/project.rs:45-70) = rustfst::algorithms::project
  *      (rustfst/src/algorithms/projection.rs:65-95), in place on the device-resident arcs.  project_output == 0:
  *      ProjectType::ProjectInput (olabel := ilabel), != 0: ProjectOutput (ilabel := olabel); the property word follows

@@ -111,8 +111,7 @@ void oracle_label_reachable_intervals(const oracle_label_reachable*, uint32_t st
  * Pinned on rustfst-python/tests/algorithms/test_project.py:5-97. */
 void oracle_fst_project(oracle_fst*, int project_output);
 /* rm_epsilon() with the default config (connect, no thresholds): algorithms/rm_epsilon/rm_epsilon_static.rs:50-163,
- * rm_epsilon_state.rs:44-119 (in place).  Pinned on rustfst-python/tests/algorithms/test_rm_epsilon.py:4-54.  The
- * GPU engine does not offer rm_epsilon yet: this is the checker the next round builds against. */
+ * rm_epsilon_state.rs:44-119 (in place).  Pinned on rustfst-python/tests/algorithms/test_rm_epsilon.py:4-54 (K11). */
 int oracle_rm_epsilon(oracle_fst*);
 /* connect(): connect.rs:51-66 */
 int oracle_connect(oracle_fst*);

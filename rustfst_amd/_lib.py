@@ -57,6 +57,7 @@ SYMBOLS = [
     ("wfst_compose", C.c_int, [_vp, _vp, _vp, _P(ComposeConfig), _P(_vp)]),
     ("wfst_shortest_path", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_connect", C.c_int, [_vp, _vp, _P(_vp)]),
+    ("wfst_rm_epsilon", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_fst_project", C.c_int, [_vp, _vp, C.c_int]),
     ("wfst_lookahead_create", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_lookahead_relabel", C.c_int, [_vp, _vp, _P(_vp)]),

@@ -349,6 +349,15 @@ wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* cons
   });
 }
 
+wfst_status wfst_rm_epsilon(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out) {
+  return wrap([&] {
+    if (!ctx || !fst || !out) throw Error("null pointer");
+    *out = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    *out = rm_epsilon_fst(ctx, fst);
+  });
+}
+
 wfst_status wfst_connect(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out) {
   return wrap([&] {
     if (!ctx || !fst || !out) throw Error("null pointer");

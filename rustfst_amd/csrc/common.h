@@ -264,6 +264,8 @@ wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 wfst_fst* connect_fst(wfst_ctx* ctx, const wfst_fst* f);
 wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint32_t* off, const wfst_tr* arcs, const float* fin,
                             bool all_accessible, uint64_t out_props);
+// rm_epsilon.hip
+wfst_fst* rm_epsilon_fst(wfst_ctx* ctx, const wfst_fst* f);
 wfst_fst* compose_wide(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, uint32_t mode, uint32_t filter, bool connect,
                        uint64_t out_props, uint64_t est_s);
 }  // namespace wfst

@@ -263,6 +263,12 @@ class DeviceFst:
         check(_lib.lib().wfst_reverse(self.ctx._h, self._h, C.byref(out)), "Error during reverse")
         return DeviceFst(out, self.ctx)
 
+    def rm_epsilon(self) -> "DeviceFst":
+        """algorithms::rm_epsilon, default config (rm_epsilon_static.rs:50-163): a NEW FST without epsilon:epsilon arcs."""
+        out = C.c_void_p()
+        check(_lib.lib().wfst_rm_epsilon(self.ctx._h, self._h, C.byref(out)), "Error during rm_epsilon")
+        return DeviceFst(out, self.ctx)
+
     def connect(self) -> "DeviceFst":
         """algorithms::connect (connect.rs:51-66): a NEW FST with the accessible and coaccessible states only."""
         out = C.c_void_p()
@@ -683,6 +689,13 @@ class VectorFst:
 
     def shortest_path(self, config: Union[ShortestPathConfig, None] = None) -> "VectorFst":
         return self.to_device().shortest_path(config).to_vector_fst()
+
+    def rm_epsilon(self) -> "VectorFst":
+        """rustfst-python vector_fst.py `rm_epsilon` (algorithms/rm_epsilon.py): in place, returns this FST."""
+        res = self.to_device().rm_epsilon().to_vector_fst()
+        self._p, res._p = res._p, self._p
+        self._dev = None
+        return self
 
     def connect(self) -> "VectorFst":
         """rustfst-python vector_fst.py `connect` (algorithms/connect.py): trims this FST in place and returns it."""

@@ -1270,3 +1270,38 @@ def test_connect_known_answer_and_oracle(gpu_ctx, oracle):
     ref = to_oracle(oracle, deep)
     ref.connect()
     assert_flat_identical(to_device(deep).connect().to_flat(), ref.to_flat(), "connect on a ring")
+
+
+def test_rm_epsilon_known_answer_and_oracle(gpu_ctx, oracle):
+    """wfst_rm_epsilon: the reference's test_rm_epsilon.py:4-54 vector, then epsilon-rich random FSTs (acyclic and cyclic
+    epsilon structure, epsilon self-loops, states that are rewritten and states that only lose their arcs, weights on the
+    1/512 grid) against the oracle's restatement: states, arc ORDER (the reference rewrites states in dependency order and
+    reads the rewritten successors), combined weights, finals, property word."""
+    g = golden("k11_rm_epsilon.json")
+    x = vbuild(g["fst"])
+    res = x.rm_epsilon()
+    assert x == vbuild(g["expected"]) and res == vbuild(g["expected"])
+    rng = np.random.default_rng(4711)
+    for k in range(60):
+        f = random_fst_flat(rng, int(rng.integers(1, 40)), 3, 3, p_eps_i=(0.3, 0.6)[k % 2], p_eps_o=(0.3, 0.6)[k % 2],
+                            p_final=0.3, acyclic=(k % 3 == 0), sort=("none", "ilabel")[k % 2])
+        if k % 11 == 5:
+            f = dict(f)
+            f["start"] = -1
+        ref = to_oracle(oracle, f)
+        ref.rm_epsilon()
+        assert_flat_identical(to_device(f).rm_epsilon().to_flat(), ref.to_flat(), f"rm_epsilon {k}")
+    big = synth.make_transducer(3000, 3, 5, 0.25, seed=12, p_final=0.02)  # a quarter of the arcs epsilon:epsilon below
+    arcs = big["arcs"].copy()
+    arcs["olabel"] = np.where(arcs["ilabel"] == 0, 0, arcs["olabel"])
+    big = dict(big); big["arcs"] = arcs; big["props"] = 0
+    ref = to_oracle(oracle, big)
+    ref.rm_epsilon()
+    assert_flat_identical(to_device(big).rm_epsilon().to_flat(), ref.to_flat(), "rm_epsilon on 3000 states")
+    # one epsilon component of thousands of states: refused (a thread per state walks its closure with linear searches)
+    dense = synth.make_transducer(3000, 4, 3, 0.6, seed=12, p_final=0.02)
+    arcs = dense["arcs"].copy()
+    arcs["olabel"] = np.where(arcs["ilabel"] == 0, 0, arcs["olabel"])
+    dense = dict(dense); dense["arcs"] = arcs; dense["props"] = 0
+    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
+        to_device(dense).rm_epsilon()
