@@ -4,6 +4,8 @@
 //   K2  rustfst-python/tests/algorithms/test_shortest_path.py:5-51     test_shortest_path
 //   K3  rustfst/src/algorithms/compose/compose_static.rs:282-289       doctest of compose (fst![1,2 => 2,3] o fst![2,3 => 3,4])
 //   K7  rustfst-python/tests/algorithms/test_project.py:5-97           test_project_input / test_project_output
+//   K8  rustfst-python/tests/algorithms/test_connect.py:4-55           test_connect
+//   K11 rustfst-python/tests/algorithms/test_rm_epsilon.py:4-54        test_rm_epsilon
 //   the look-ahead recipe of rustfst-cli/src/cmds/compose.rs:77-181 on the K1 operands: same language as compose
 //   error behaviour of compose on unsorted operands (compose_fst_op.rs:169-197) and of missing states (mutable_fst.rs)
 //
@@ -168,6 +170,50 @@ static void test_project() {  // K7
   }
 }
 
+static void test_connect() {  // K8
+  VectorFst f;
+  for (int i = 0; i < 5; ++i) f.add_state();
+  f.set_start(0);
+  f.set_final(1, 0.0f);
+  f.add_tr(4, tr(1, 2, 1.0f, 0));
+  f.add_tr(0, tr(3, 4, 2.0f, 1));
+  f.add_tr(1, tr(4, 5, 3.0f, 2));
+  f.add_tr(2, tr(4, 6, 4.0f, 3));
+  f.add_tr(2, tr(7, 8, 5.0f, 0));
+  VectorFst expected;
+  for (int i = 0; i < 3; ++i) expected.add_state();
+  expected.set_start(0);
+  expected.set_final(1, 0.0f);
+  expected.add_tr(0, tr(3, 4, 2.0f, 1));
+  expected.add_tr(1, tr(4, 5, 3.0f, 2));
+  expected.add_tr(2, tr(7, 8, 5.0f, 0));
+  connect(f);
+  ASSERT(f == expected);
+}
+
+static void test_rm_epsilon() {  // K11
+  VectorFst f;
+  for (int i = 0; i < 4; ++i) f.add_state();
+  f.set_start(0);
+  f.set_final(3, 1.0f);
+  f.add_tr(0, tr(0, 0, 1.0f, 1));
+  f.add_tr(1, tr(1, 0, 2.0f, 2));
+  f.add_tr(1, tr(0, 2, 3.0f, 2));
+  f.add_tr(1, tr(0, 0, 4.0f, 2));
+  f.add_tr(2, tr(0, 0, 5.0f, 2));
+  f.add_tr(2, tr(0, 0, 5.0f, 3));
+  VectorFst expected;
+  expected.add_state();
+  expected.add_state();
+  expected.set_start(0);
+  expected.set_final(0, 11.0f);
+  expected.set_final(1, 6.0f);
+  expected.add_tr(0, tr(0, 2, 4.0f, 1));
+  expected.add_tr(0, tr(1, 0, 3.0f, 1));
+  rm_epsilon(f);
+  ASSERT(f == expected);
+}
+
 static void test_lookahead_recipe() {
   // fst![1,2 => 2,3] o fst![2,3 => 3,4] through the look-ahead configuration: one path, input 1 2, output 3 4, weight one
   VectorFst a, b;
@@ -192,6 +238,8 @@ static void test_lookahead_recipe() {
 }
 
 int main() {
+  test_connect();
+  test_rm_epsilon();
   test_project();
   test_lookahead_recipe();
   test_compose_fst();

@@ -12,6 +12,7 @@
 //   ExpandedFst::num_states, Fst::properties                     Option<T> -> std::optional<T>
 //   tr_sort(&mut fst, ILabelCompare{} | OLabelCompare{})         tr_sort(fst, ILabelCompare{} | OLabelCompare{})
 //   project(&mut fst, ProjectType::ProjectInput)                 project(fst, ProjectType::ProjectInput)
+//   connect(&mut fst) / rm_epsilon(&mut fst)                     connect(fst) / rm_epsilon(fst)
 //   (look-ahead recipe of rustfst-cli/src/cmds/compose.rs)       LookAheadFst(fst1).compose(fst2) / compose_lookahead
 //   compose(fst1, fst2) / compose_with_config(.., ComposeConfig) compose(..) / compose_with_config(..)   compose_static.rs:166-306
 //   shortest_path(&fst) / shortest_path_with_config(..)          shortest_path(..) / shortest_path_with_config(..)  shortest_path.rs:76-133
@@ -184,6 +185,20 @@ inline void project(VectorFst& fst, ProjectType project_type) {
   detail::upload(fst, a);
   check(wfst_fst_project(Context::current().get(), a.h, project_type == ProjectType::ProjectOutput ? 1 : 0));
   fst = detail::download(a);
+}
+
+// connect (algorithms/connect.rs:51-66) and rm_epsilon (algorithms/rm_epsilon/rm_epsilon_static.rs:50-163): in place
+inline void connect(VectorFst& fst) {
+  detail::DeviceFst a, c;
+  detail::upload(fst, a);
+  check(wfst_connect(Context::current().get(), a.h, &c.h));
+  fst = detail::download(c);
+}
+inline void rm_epsilon(VectorFst& fst) {
+  detail::DeviceFst a, c;
+  detail::upload(fst, a);
+  check(wfst_rm_epsilon(Context::current().get(), a.h, &c.h));
+  fst = detail::download(c);
 }
 
 // Look-ahead composition.  The reference has no single function for it: callers assemble MatcherFst::new_with_relabeling,
