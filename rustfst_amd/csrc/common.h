@@ -168,6 +168,13 @@ struct RevCsr {
   DBuf<uint32_t> off;  // [n+1]
   DBuf<uint2> arc;     // [E] {source state, position of the arc in the source's arc list}
 };
+// Message-region plan of the mailbox relaxation sweeps (sssp_mailbox.h): offsets of the region reserved for every
+// (source block, destination block) pair, sized by the number of arcs between the two blocks.
+struct MboxPlan {
+  uint32_t nb = 0;         // blocks of 4096 states
+  DBuf<uint32_t> roff;     // [nb*nb + 1] destination-major
+  DBuf<uint32_t> roff_t;   // [nb*nb]     source-major copy
+};
 }  // namespace wfst
 
 namespace wfst {
@@ -201,6 +208,8 @@ struct wfst_fst {
   // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second
   // shortest_path query of a large FST (sssp.hip reverse_csr)
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
+  // region plan of the mailbox relaxation sweeps; depends on (source, target) pairs only, built on first use
+  mutable std::shared_ptr<wfst::MboxPlan> mbox;
   // a linear, epsilon-free, single-final acceptor ("string": utils::acceptor, labels_to_fst.rs:111-132), detected at
   // upload from the host arrays; such an fst1 takes the specialised string o T kernel of the fused batch
   bool is_string = false;

@@ -103,6 +103,8 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
   return prev + delta * (float)(1u << (st - 1u));
 }
 
+#include "sssp_mailbox.h"
+
 // Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
 // +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
 // flag in buffer 0, the activity ring and the control block zeroed.
@@ -552,6 +554,13 @@ struct Solve {
   uint64_t sweep_cap = 0;
   // per-wave list of near discoveries relaxed inside the same launch, in sweeps that follow a small (< chase_low) one
   uint32_t chase_cap = 32, chase_rounds = 8, chase_low = 4096;  // chase_rounds = states a wave may chase per launch
+  // mailbox sweeps (sssp_mailbox.h): owner-computes relaxation, chosen by relax_setup for branching graphs of <= 2^20 states
+  bool mbox = false;
+  std::shared_ptr<MboxPlan> plan;
+  DBuf<uint2> mb_msgs;      // two message buffers of n_arcs entries
+  DBuf<uint32_t> mb_words;  // counts (2 x nb^2), wrote (2 x nb), pend masks, blk_pend, blk_mind
+  DBuf<unsigned long long> mb_dbg;  // WFST_SSSP_MBOX_TRACE=<file>: per-block phase stamps of the first 64 sweeps
+  MboxView mv{};
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -560,6 +569,50 @@ constexpr uint32_t MAX_BATCH = 64;
 // batch is enqueued before the host looks at the previous batch's flags (two batches in flight), so the device never
 // idles on a host round trip.  A sweep that changes nothing leaves an empty frontier: everything enqueued behind it is
 // a ~3 us no-op.
+bool mbox_eligible(const wfst_fst* f) {
+  return f->n_states <= (MB_NBMAX << MB_LOG) && f->n_arcs > 0 && f->n_arcs < 0x7FFFFFFFull && !f->has_negative;
+}
+
+// Region plan of the mailbox sweeps: arcs between every pair of blocks, scanned into region offsets.  Depends only on
+// the (source, target) pairs of the arcs, so tr_sort leaves it valid; cached on the handle (owner's pool).
+std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
+  if (f->mbox) return f->mbox;
+  const uint32_t n = f->n_states, nb = (n + MB_B - 1) >> MB_LOG;
+  hipStream_t st = ctx->stream;
+  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
+  auto p = std::make_shared<MboxPlan>();
+  p->nb = nb;
+  const size_t cells = (size_t)nb * nb;
+  p->roff = DBuf<uint32_t>(owner_pool, cells + 1);
+  p->roff_t = DBuf<uint32_t>(owner_pool, cells);
+  DBuf<uint32_t> hist(*ctx->pool, cells + 1);
+  mbox_hist_kernel<<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
+  HIP_CHECK(hipMemsetAsync(hist.p + cells, 0, sizeof(uint32_t), st));
+  size_t temp_bytes = 0;
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  mbox_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roff.p, nb, p->roff_t.p);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));  // hist / temp are released here
+  f->mbox = p;
+  return p;
+}
+
+// one relaxation sweep on the stream: `j` = position inside the batch (static flag / message parity), `off` = sweep
+// index relative to the device-side base, `abs_sweep` = the absolute index (what the host has queued so far)
+void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint32_t j, uint32_t off, uint32_t abs_sweep,
+                  uint32_t profile) {
+  if (sv.mbox)
+    sssp_mbox_kernel<<<sv.mv.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, j & 1u, n, sv.improved.p,
+                                                      sv.ctl.p, abs_sweep, sv.delta, sv.near_low, profile);
+  else
+    sssp_relax_kernel<<<sv.blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u], sv.fl[(j & 1u) ^ 1u], n,
+                                                 sv.improved.p, sv.ctl.p, off, sv.delta, sv.near_low, sv.shadow.p, sv.chase_cap,
+                                                 sv.chase_rounds, sv.chase_low, profile);
+}
+
 // relax_setup allocates and initialises the state of a solve (keys, frontier flags, control block) and fixes its schedule parameters
 void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   const uint32_t n = f->n_states;
@@ -586,9 +639,46 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   float tau0_mult = 1.0f;  // first band = tau0_mult x delta
   if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
   static_assert(sizeof(Ctl) % 4 == 0, "Ctl is cleared word by word");
-  sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
-                                               sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
-                                               delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  // mailbox sweeps where they pay: branching graphs (the near-far case) whose state ids fit the message format
+  bool want_mbox = delta < INF && mbox_eligible(f);
+  if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) want_mbox = std::atoi(e) != 0 && mbox_eligible(f);
+  if (want_mbox) {
+    sv.plan = mbox_plan(ctx, f);
+    const uint32_t nb = sv.plan->nb;
+    sv.mbox = true;
+    sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
+    const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
+    sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 2 * nb);
+    MboxView& mv = sv.mv;
+    mv.roff = sv.plan->roff.p;
+    mv.roff_t = sv.plan->roff_t.p;
+    mv.msgs[0] = sv.mb_msgs.p;
+    mv.msgs[1] = sv.mb_msgs.p + f->n_arcs;
+    uint32_t* w = sv.mb_words.p;
+    mv.cnt[0] = w;
+    mv.cnt[1] = w + w_cnt;
+    w += 2 * w_cnt;
+    mv.wrote[0] = w;
+    mv.wrote[1] = w + nb;
+    w += 2 * nb;
+    mv.pend = w;
+    w += w_pend;
+    mv.blk_pend = w;
+    mv.blk_mind = w + nb;
+    mv.nb = nb;
+    mv.dbg = nullptr;
+    if (std::getenv("WFST_SSSP_MBOX_TRACE")) {
+      sv.mb_dbg = DBuf<unsigned long long>(pool, (size_t)MB_DBG_SWEEPS * nb * 16);
+      HIP_CHECK(hipMemsetAsync(sv.mb_dbg.p, 0, (size_t)MB_DBG_SWEEPS * nb * 16 * 8, st));
+      mv.dbg = sv.mb_dbg.p;
+    }
+    sssp_mbox_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
+                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  } else {
+    sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
+                                                 sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
+                                                 delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  }
   HIP_CHECK(hipGetLastError());
   sv.sweep_cap = 4ull * n + 64;
   if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
@@ -623,10 +713,10 @@ struct SweepDriver {
     h_imp = (uint32_t*)ctx->pinned_flags.get(3 * IMP_RING * sizeof(uint32_t));
     if (const char* e = std::getenv("WFST_SSSP_GRAPH")) use_graphs = std::atoi(e) != 0;
     // A batch boundary costs ~14 us of idle GPU (profiles/r01d), so the FIRST batch of a solve is sized to what the
-    // previous solve of this FST needed (+1 sweep to see the quiet one, rounded up to a multiple of 4; batch sizes stay
+    // previous solve of this FST needed (+1 sweep to see the quiet one, rounded up to an even count; batch sizes stay
     // even because the flag parity of a sweep inside a batch is static).
     const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 3) & ~3u);
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 1) & ~1u);
     predicted = last_sweeps != 0 && last_sweeps < first_count;
     evs[0] = ctx->ev0;
     evs[1] = ctx->ev1;
@@ -702,15 +792,12 @@ struct SweepDriver {
     SweepBatch b{next_sweep, 8u, 1};
     if (next_sweep == 0) b = SweepBatch{0u, first_count, 0};
     else if (next_sweep >= 64) b = SweepBatch{next_sweep, MAX_BATCH, 2};
-    if (use_graphs) {
+    if (use_graphs && !sv->mbox) {
       HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
     } else {
       // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
       // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
-      for (uint32_t j = 0; j < b.count; ++j)
-        sssp_relax_kernel<<<sv->blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv->key.p, sv->fl[j & 1u], sv->fl[(j & 1u) ^ 1u],
-                                                      n, sv->improved.p, sv->ctl.p, j, sv->delta, sv->near_low, sv->shadow.p,
-                                                      sv->chase_cap, sv->chase_rounds, sv->chase_low, 0u);
+      for (uint32_t j = 0; j < b.count; ++j) launch_sweep(f, *sv, n, st, j, j, b.first + j, 0u);
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
       HIP_CHECK(hipGetLastError());
     }
@@ -754,14 +841,28 @@ struct SweepDriver {
   }
 };
 
+// tuning aid: the phase stamps of a mailbox solve go to the file named by WFST_SSSP_MBOX_TRACE (u64 [64][nb][16])
+void mbox_dump_trace(wfst_ctx* ctx, Solve& sv) {
+  const char* path = std::getenv("WFST_SSSP_MBOX_TRACE");
+  if (!sv.mbox || !sv.mb_dbg.p || !path) return;
+  std::vector<unsigned long long> h((size_t)MB_DBG_SWEEPS * sv.mv.nb * 16);
+  HIP_CHECK(hipMemcpyAsync(h.data(), sv.mb_dbg.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (FILE* fp = std::fopen(path, "wb")) {
+    const uint32_t hdr[2] = {MB_DBG_SWEEPS, sv.mv.nb};
+    std::fwrite(hdr, 4, 2, fp);
+    std::fwrite(h.data(), 8, h.size(), fp);
+    std::fclose(fp);
+  }
+}
+
 // Runs the relaxation to its fixed point. f must have a device copy and a start state.
 void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   relax_setup(ctx, f, sv);
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   uint8_t* const* fl = sv.fl;
-  const uint32_t blocks = sv.blocks, near_low = sv.near_low;
-  const float delta = sv.delta;
+  const uint32_t blocks = sv.blocks;
   const uint64_t sweep_cap = sv.sweep_cap;
   ctx->stats.sweeps = 0;
 
@@ -781,9 +882,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       if (k > sweep_cap) throw Error("shortest_path: relaxation did not converge (negative-weight cycle?)");
       sssp_nop_kernel<<<blocks, 256, 0, st>>>(fl[k & 1u], n, sv.improved.p);
       HIP_CHECK(hipEventRecord(ctx->ev0, st));
-      sssp_relax_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, fl[k & 1u], fl[(k & 1u) ^ 1u], n,
-                                                sv.improved.p, sv.ctl.p, 0u, delta, near_low, sv.shadow.p, sv.chase_cap,
-                                                sv.chase_rounds, sv.chase_low, std::getenv("WFST_SSSP_COUNT_ATOMICS") ? 2u : 1u);  // counts the states / arcs it relaxes
+      launch_sweep(f, sv, n, st, k, 0u, k, std::getenv("WFST_SSSP_COUNT_ATOMICS") ? 2u : 1u);  // counts the states / arcs it relaxes
       HIP_CHECK(hipEventRecord(ctx->ev1, st));
       sssp_advance_kernel<<<1, 64, 0, st>>>(sv.ctl.p, sv.improved.p, 1u, nullptr);
       HIP_CHECK(hipMemcpyAsync(h_imp, sv.improved.p + (k % IMP_RING), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -812,6 +911,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
   f->last_sweeps.store(sweeps_done, std::memory_order_relaxed);
+  mbox_dump_trace(ctx, sv);
 }
 
 // Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
@@ -971,6 +1071,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     sv.sweeps = j->drv.sweeps_done;
     ctx->stats.sweeps = sv.sweeps;
     f->last_sweeps.store(sv.sweeps, std::memory_order_relaxed);
+    mbox_dump_trace(ctx, sv);
   }
   if (j->tail_queued && j->drv.extended) {  // the speculative tail ran on unfinished distances: once more
     HIP_CHECK(hipMemsetAsync(&sv.ctl.p->best, 0xFF, sizeof(unsigned long long), st));
@@ -979,6 +1080,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   if (!j->tail_queued) queue_tail(j.get());
   HIP_CHECK(hipStreamSynchronize(st));
   const Ctl* hc = j->hc;
+  if (hc->pad) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
   if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
   const uint32_t hops = hc->hops;
   const float final_weight = hc->final_weight;

@@ -462,6 +462,33 @@ def test_chasing_does_not_change_results(oracle, monkeypatch, cap, budget, low, 
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"chase small {k}")
 
 
+@pytest.mark.parametrize("mailbox", ["1", "0"])
+@pytest.mark.parametrize("delta", [None, "0", "0.7", "1000"])
+def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delta):
+    """The owner-computes (mailbox) sweeps and the atomic sweeps reach the same fixed point: distances, hop counts and
+    the path are bit-identical to the canonical oracle on graphs of less than one block, a partial last block, many
+    blocks, a sparse deep graph, epsilons, ties everywhere, and whatever the near-far band width is."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox)
+    if delta is not None:
+        monkeypatch.setenv("WFST_SSSP_DELTA", delta)
+    ctx = rustfst_amd.Context(0)
+    for n, fan, p_eps, seed in ((70_000, 8, 0.02, 1), (3_000, 20, 0.0, 2), (30_000, 2, 0.3, 3), (4_096, 6, 0.0, 4),
+                                (4_097, 6, 0.0, 5), (150_000, 10, 0.0, 6)):
+        t = synth.make_transducer(n, fan, 64, p_eps, seed=seed)
+        d = to_device(t, ctx)
+        can = to_oracle(oracle, t).shortest_path_canonical()
+        for q in range(2):
+            dist, hops = d.shortest_distance(want_hops=True)
+            np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+            np.testing.assert_array_equal(hops, can.hops)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"mailbox={mailbox} delta={delta} n={n} q={q}")
+    rng = np.random.default_rng(77)
+    for k in range(8):  # small cyclic FSTs with epsilons and ties (integer weights)
+        f = random_fst_flat(rng, int(rng.integers(2, 300)), 5, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2, weight_grid=1, max_w=4)
+        ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
+        assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"mailbox small {k}")
+
+
 # ------------------------------------------------------------------ n > 1 shortest paths (B4-B6)
 def test_nshortest_known_graph(gpu_ctx, oracle):
     """The K2 graph (test_shortest_path.py:5-30) asked for 2 and 3 paths."""

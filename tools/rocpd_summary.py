@@ -66,8 +66,31 @@ def pmc(fetch_db, write_db):
           "the 8-B gathers of this kernel are uncalibrated, so read the column as an upper bound and the raw column as a lower bound).")
 
 
+def timeline(path, which=-1):
+    """Kernels of one solve (default: the last) in launch order: duration and the idle gap before each."""
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    setups = [i for i, r in enumerate(rows) if "setup_kernel" in r[0]]
+    if not setups:
+        return
+    i0 = setups[which]
+    i1 = next((i for i in range(i0, len(rows)) if "sssp_header_kernel" in rows[i][0]), len(rows) - 1)
+    print("| # | kernel | us | gap before (us) |")
+    print("|---:|---|---:|---:|")
+    tot = gaps = 0
+    for k in range(i0, i1 + 1):
+        name, s, e = rows[k]
+        gap = (s - rows[k - 1][2]) / 1e3 if k > i0 else 0.0
+        tot += e - s
+        gaps += max(0.0, gap)
+        print(f"| {k - i0} | `{short(name, 40)}` | {(e - s) / 1e3:.2f} | {gap:.2f} |")
+    print(f"\nsolve: first start -> last end {(rows[i1][2] - rows[i0][1]) / 1e3:.1f} us; kernel time {tot / 1e3:.1f} us; gaps {gaps:.1f} us")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else -1)
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3])

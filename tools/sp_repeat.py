@@ -1,0 +1,15 @@
+"""N un-profiled shortest_path(T) solves on the C3 graph (for rocprofv3 --kernel-trace timelines and PMC passes)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustfst_amd
+from rustfst_amd import synth
+
+states = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+t = synth.make_transducer(states, 10, 256, 0.0, seed=3)
+ctx = rustfst_amd.Context(0)
+d = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+best = 1e9
+for _ in range(reps):
+    t0 = time.perf_counter(); d.shortest_path(); best = min(best, time.perf_counter() - t0)
+print(f"best of {reps}: {best*1e3:.3f} ms, sweeps {ctx.stats()['sweeps']}")
