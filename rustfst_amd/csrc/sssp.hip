@@ -104,6 +104,7 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
 }
 
 #include "sssp_mailbox.h"
+#include "sssp_mailbox_async.h"
 
 // Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
 // +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
@@ -561,6 +562,12 @@ struct Solve {
   DBuf<uint32_t> mb_words;  // counts (2 x nb^2), wrote (2 x nb), pend masks, blk_pend, blk_mind
   DBuf<unsigned long long> mb_dbg;  // WFST_SSSP_MBOX_TRACE=<file>: per-block phase stamps of the first 64 sweeps
   MboxView mv{};
+  // multi-round mailbox launches (sssp_mailbox_async.h), WFST_SSSP_MAILBOX=2
+  bool mboxa = false;
+  std::shared_ptr<MboxPlanA> plana;
+  DBuf<MboxGlobal> ma_g;
+  MboxAView mav{};
+  uint32_t ma_rounds = MA_MAX_ROUNDS_DEFAULT;
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -600,11 +607,42 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   return p;
 }
 
+std::shared_ptr<MboxPlanA> mboxa_plan(wfst_ctx* ctx, const wfst_fst* f) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
+  if (f->mboxa) return f->mboxa;
+  const uint32_t n = f->n_states, nb = (n + MB_B - 1) >> MB_LOG;
+  hipStream_t st = ctx->stream;
+  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
+  auto p = std::make_shared<MboxPlanA>();
+  p->nb = nb;
+  const size_t cells = (size_t)nb * nb;
+  p->rinfo = DBuf<uint2>(owner_pool, cells);
+  p->sinfo = DBuf<uint4>(owner_pool, cells);
+  DBuf<uint32_t> hist(*ctx->pool, cells + 1), caps(*ctx->pool, cells + 1), roff(*ctx->pool, cells + 1);
+  mbox_hist_kernel<<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
+  mboxa_caps_kernel<<<(uint32_t)((cells + 256) / 256), 256, 0, st>>>(hist.p, (uint32_t)cells, caps.p);
+  size_t temp_bytes = 0;
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, caps.p, roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, caps.p, roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  mboxa_info_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(hist.p, caps.p, roff.p, nb, p->rinfo.p, p->sinfo.p);
+  uint32_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, roff.p + cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+  p->slots = total;
+  f->mboxa = p;
+  return p;
+}
+
 // one relaxation sweep on the stream: `j` = position inside the batch (static flag / message parity), `off` = sweep
 // index relative to the device-side base, `abs_sweep` = the absolute index (what the host has queued so far)
 void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint32_t j, uint32_t off, uint32_t abs_sweep,
                   uint32_t profile) {
-  if (sv.mbox)
+  if (sv.mboxa)
+    sssp_mboxa_kernel<<<sv.mav.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mav, n, sv.improved.p, sv.ctl.p,
+                                                        abs_sweep, sv.delta, sv.ma_rounds, profile);
+  else if (sv.mbox)
     sssp_mbox_kernel<<<sv.mv.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, j & 1u, n, sv.improved.p,
                                                       sv.ctl.p, abs_sweep, sv.delta, sv.near_low, profile);
   else
@@ -641,8 +679,37 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   static_assert(sizeof(Ctl) % 4 == 0, "Ctl is cleared word by word");
   // mailbox sweeps where they pay: branching graphs (the near-far case) whose state ids fit the message format
   bool want_mbox = delta < INF && mbox_eligible(f);
-  if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) want_mbox = std::atoi(e) != 0 && mbox_eligible(f);
-  if (want_mbox) {
+  int mbox_mode = want_mbox ? 1 : 0;
+  if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) mbox_mode = mbox_eligible(f) ? std::atoi(e) : 0;
+  if (mbox_mode == 2 && f->n_arcs < 0x3FFFFFFFull) {
+    sv.plana = mboxa_plan(ctx, f);
+    const uint32_t nb = sv.plana->nb;
+    sv.mboxa = true;
+    sv.mbox = true;  // (plain launches, no sweep graphs, absolute sweep index: same driver path)
+    if (const char* e = std::getenv("WFST_SSSP_MBOX_ROUNDS")) sv.ma_rounds = std::max(1, std::atoi(e));
+    sv.mb_msgs = DBuf<uint2>(pool, sv.plana->slots);
+    const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
+    sv.mb_words = DBuf<uint32_t>(pool, 4 * w_cnt + w_pend + 2 * nb);
+    sv.ma_g = DBuf<MboxGlobal>(pool, 1);
+    MboxAView& mv = sv.mav;
+    mv.rinfo = sv.plana->rinfo.p;
+    mv.sinfo = sv.plana->sinfo.p;
+    mv.msgs = sv.mb_msgs.p;
+    uint32_t* w = sv.mb_words.p;
+    mv.head_r = w;
+    mv.tail_s = w + w_cnt;
+    mv.cur_s = w + 2 * w_cnt;
+    mv.tail_r = w + 3 * w_cnt;
+    w += 4 * w_cnt;
+    mv.pend = w;
+    w += w_pend;
+    mv.blk_pend = w;
+    mv.blk_mind = w + nb;
+    mv.g = sv.ma_g.p;
+    mv.nb = nb;
+    sssp_mboxa_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
+                                                       delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+  } else if (mbox_mode >= 1) {
     sv.plan = mbox_plan(ctx, f);
     const uint32_t nb = sv.plan->nb;
     sv.mbox = true;
@@ -844,7 +911,7 @@ struct SweepDriver {
 // tuning aid: the phase stamps of a mailbox solve go to the file named by WFST_SSSP_MBOX_TRACE (u64 [64][nb][16])
 void mbox_dump_trace(wfst_ctx* ctx, Solve& sv) {
   const char* path = std::getenv("WFST_SSSP_MBOX_TRACE");
-  if (!sv.mbox || !sv.mb_dbg.p || !path) return;
+  if (!sv.mbox || sv.mboxa || !sv.mb_dbg.p || !path) return;
   std::vector<unsigned long long> h((size_t)MB_DBG_SWEEPS * sv.mv.nb * 16);
   HIP_CHECK(hipMemcpyAsync(h.data(), sv.mb_dbg.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));

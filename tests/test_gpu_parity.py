@@ -462,13 +462,15 @@ def test_chasing_does_not_change_results(oracle, monkeypatch, cap, budget, low, 
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"chase small {k}")
 
 
-@pytest.mark.parametrize("mailbox", ["1", "0"])
+@pytest.mark.parametrize("mailbox", ["2", "2:1", "2:3", "1", "0"])
 @pytest.mark.parametrize("delta", [None, "0", "0.7", "1000"])
 def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delta):
     """The owner-computes (mailbox) sweeps and the atomic sweeps reach the same fixed point: distances, hop counts and
     the path are bit-identical to the canonical oracle on graphs of less than one block, a partial last block, many
     blocks, a sparse deep graph, epsilons, ties everywhere, and whatever the near-far band width is."""
-    monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox)
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox.split(":")[0])  # 2 = several rounds per launch, 2:k = at most k rounds
+    if ":" in mailbox:
+        monkeypatch.setenv("WFST_SSSP_MBOX_ROUNDS", mailbox.split(":")[1])
     if delta is not None:
         monkeypatch.setenv("WFST_SSSP_DELTA", delta)
     ctx = rustfst_amd.Context(0)
