@@ -1669,6 +1669,22 @@ void canonical_sssp(const Fst& f, Canon& c) {
       }
     }
   }
+  // Fallback (class 1 of the engine's predecessor rule, sssp.hip parent_class): with inexact f32 sums a state may keep
+  // a hop count derived from a label of its predecessor that was later improved in the distance, so that no arc is
+  // tight in the hop count.  Then: first arc (s, pos ascending) that is tight in the distance and whose source label
+  // is lexicographically below the target's.
+  for (size_t s = 0; s < n; ++s) {
+    if (!(c.d[s] < INF)) continue;
+    const State& st = f.states[s];
+    for (size_t pos = 0; pos < st.trs.size(); ++pos) {
+      const Tr& tr = st.trs[pos];
+      uint32_t t = tr.nextstate;
+      if (c.parent[t].some || (f.has_start && t == f.start)) continue;
+      float cand = (c.d[s] + tr.weight) + 0.0f;
+      if (!(cand < INF)) continue;
+      if (cand == c.d[t] && key_less(c.d[s], c.h[s], c.d[t], c.h[t])) c.parent[t] = Parent{true, (uint32_t)s, pos};
+    }
+  }
 }
 
 // count path positions with >1 (unlayered) tight incoming arcs, plus a final-state tie

@@ -51,7 +51,9 @@ enum : uint32_t { MODE_BOTH = 0, MODE_INPUT = 1, MODE_OUTPUT = 2 };  // MatchTyp
 enum : uint32_t {
   ST_OK = 0, ST_OVERFLOW_STATES = 1, ST_OVERFLOW_ARCS = 2, ST_OVERFLOW_HASH = 3, ST_OVERFLOW_PATH = 4,
   ST_NOT_A_STRING_CASE = 5,  // the string o T kernel met a case it does not cover: redo on the general kernel
-  ST_SWITCH_WIDE = 6         // a frontier too wide for one wave: compose() redoes the pair on the wide driver
+  ST_SWITCH_WIDE = 6,        // a frontier too wide for one wave: compose() redoes the pair on the wide driver
+  ST_TIE_ORDER = 7           // fused shortest path: a state of the path has no predecessor tight in the hop count (inexact
+                             // f32 sums, sssp.hip parent_class): the host redoes the problem as compose + shortest_path
 };
 enum : uint32_t { FLAG_TRIM = 1, FLAG_SP = 2 };
 
@@ -925,9 +927,13 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
               const ArcReg a = load_arc(ar.arcs + i);
               const float c = (d + a.w) + 0.0f;
               if (!(c < INF)) continue;
-              const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
-              if (ck == ld_l2(&ar.skey[a.ns]))
+              const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1, kt = ld_l2(&ar.skey[a.ns]);
+              // class 0: tight in distance and hop count; class 1 (top bit): tight in the distance only, from a state
+              // with a smaller key (sssp.hip parent_class)
+              if (ck == kt)
                 atomicMin((unsigned long long*)&ar.parent[a.ns], ((unsigned long long)q << 32) | (i - b));
+              else if ((ck >> 32) == (kt >> 32) && kq < kt)
+                atomicMin((unsigned long long*)&ar.parent[a.ns], (1ull << 63) | ((unsigned long long)q << 32) | (i - b));
             }
           }
         }
@@ -939,7 +945,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       uint32_t* jb = ar.lvl;
       for (uint32_t i = lane; i < n_states; i += 64) {
         const uint64_t pr = ld_l2(&ar.parent[i]);
-        ja[i] = pr == KEY_INF ? i : (uint32_t)(pr >> 32);
+        ja[i] = pr == KEY_INF ? i : ((uint32_t)(pr >> 32) & 0x7FFFFFFFu);
         ar.aux[i] = i == fp ? 1u : 0u;
       }
       wave_sync();
@@ -959,7 +965,13 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
       uint32_t poff = 0;
       if (lane == 0) poff = atomicAdd(path_cursor, hops);
       poff = __shfl(poff, 0);
-      if ((uint64_t)poff + hops > path_cap) {
+      // a marked state without a class-0 predecessor: positions cannot be read off the hop counts
+      bool tie = false;
+      for (uint32_t i = lane; i < n_states; i += 64)
+        if (ld_l2(&ar.aux[i]) && (uint32_t)ld_l2(&ar.skey[i]) >= 1u && (ld_l2(&ar.parent[i]) >> 63)) tie = true;
+      if (__any(tie)) {
+        res.status = ST_TIE_ORDER;
+      } else if ((uint64_t)poff + hops > path_cap) {
         res.status = ST_OVERFLOW_PATH;
       } else {
         res.path_off = poff;
@@ -1438,6 +1450,10 @@ struct wfst_batch_job {
   size_t n = 0;
   wfst::FstView v2{};
   std::vector<wfst::ProblemDesc> descs;
+  std::vector<const wfst_fst*> accs;  // the operands (borrowed): problems the fused kernel hands back (ST_TIE_ORDER)
+  const wfst_fst* t = nullptr;
+  uint32_t filter = 0;
+  std::vector<size_t> slow;           // ... are redone as compose + shortest_path at the end
   std::vector<size_t> todo;
   uint64_t est_s = 0, est_a = 0;
   wfst::BatchRun run;
@@ -1457,6 +1473,9 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   if (n == 0) return job.release();
   ensure_device(const_cast<wfst_fst*>(t));
   job->v2 = view_of(t);
+  job->accs.assign(accs, accs + n);
+  job->t = t;
+  job->filter = filter;
   job->descs.resize(n);
   job->todo.resize(n);
   uint64_t max_states = 64;
@@ -1531,7 +1550,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
       for (size_t k = 0; k < job->todo_s.size(); ++k) {
         const Result& r = job->run_s.results[k];
         if (r.status != ST_OK) {
-          more.push_back(job->todo_s[k]);
+          (r.status == ST_TIE_ORDER ? job->slow : more).push_back(job->todo_s[k]);
           continue;
         }
         tot_arcs += r.n_arcs;
@@ -1546,7 +1565,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
           for (size_t k = 0; k < job->todo.size(); ++k) {
             const Result& r = job->run.results[k];
             if (r.status != ST_OK) {
-              again.push_back(job->todo[k]);
+              (r.status == ST_TIE_ORDER ? job->slow : again).push_back(job->todo[k]);
               continue;
             }
             tot_arcs += r.n_arcs;
@@ -1571,7 +1590,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
       for (size_t k = 0; k < job->todo.size(); ++k) {
         const Result& r = job->run.results[k];
         if (r.status != ST_OK) {
-          again.push_back(job->todo[k]);
+          (r.status == ST_TIE_ORDER ? job->slow : again).push_back(job->todo[k]);
           continue;
         }
         tot_arcs += r.n_arcs;
@@ -1589,6 +1608,12 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
       for (size_t k = 0; k < job->todo.size(); ++k) cur[k] = job->descs[job->todo[k]];
       job->run = BatchRun{};
       launch_begin<FLAG_SP>(ctx, cur, job->v2, make_caps(job->est_s, job->est_a), job->run, true);
+    }
+    for (size_t idx : job->slow) {  // handed back by the fused kernel: the two-step route (always applicable)
+      std::unique_ptr<wfst_fst> c(compose(ctx, job->accs[idx], job->t, true, job->filter));
+      tot_arcs += c->n_arcs;
+      tot_states += c->n_states;
+      outs[idx] = shortest_path_n1(ctx, c.get());
     }
   } catch (...) {
     for (size_t i = 0; i < n; ++i) {

@@ -413,7 +413,21 @@ __global__ void __launch_bounds__(256) sssp_final_kernel(const float* __restrict
   }
 }
 
-// parent[t] = min (s,pos) over arcs with (d[s]+w, hops[s]+1) == (d[t], hops[t])
+// Predecessor rule.  Class 0: the arc is tight in both halves of the key, (d[s] (x) w, hops[s] + 1) ==
+// (d[t], hops[t]) — on weights whose f32 sums are exact every reached state but the start has such an arc.  Class 1, the
+// fallback: the arc is tight in the distance and the source's key is lexicographically below the target's.  With
+// inexact sums a state can keep a hop count it got from a label of its predecessor that was later improved in the
+// distance (two different distances of the source can round to the same sum): then no arc is tight in the hop count,
+// but the arc that produced the label is still tight in the distance and, for non-negative weights, its source's key is
+// smaller, so a class-1 arc exists.  Keys strictly decrease along either class: the predecessor graph is acyclic.
+constexpr unsigned long long PARENT_NONE = ~0ull;
+__device__ __forceinline__ unsigned long long parent_class(uint64_t cand_key, uint64_t key_s, uint64_t key_t) {
+  if (cand_key == key_t) return 0ull;
+  if ((cand_key >> 32) == (key_t >> 32) && key_s < key_t) return 1ull << 63;
+  return PARENT_NONE;
+}
+
+// parent[t] = min (class, s, pos) over the arcs parent_class admits
 __global__ void __launch_bounds__(256) sssp_parent_kernel(const uint32_t* __restrict__ offsets,
                                                           const uint2* __restrict__ wn,
                                                           const uint64_t* __restrict__ key,
@@ -431,8 +445,9 @@ __global__ void __launch_bounds__(256) sssp_parent_kernel(const uint32_t* __rest
       const uint2 a = wn[i];
       const float c = (d + __uint_as_float(a.x)) + 0.0f;
       if (!(c < INF)) continue;
-      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1;
-      if (ck == key[a.y]) atomicMin(&parent[a.y], ((unsigned long long)s << 32) | (i - b));
+      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | h1, kt = key[a.y];
+      const unsigned long long cls = parent_class(ck, ks, kt);
+      if (cls != PARENT_NONE) atomicMin(&parent[a.y], cls | ((unsigned long long)s << 32) | (i - b));
     }
   }
 }
@@ -455,19 +470,26 @@ __global__ void sssp_header_kernel(const float* __restrict__ finals, const uint6
 // single_shortest_path_backtrace (shortest_path.rs:241-282): walk parent[] from f_parent; the arc of the
 // k-th created state (k >= 1) is ifst.trs(parent state)[pos] re-targeted to state k-1.
 __global__ void sssp_backtrace_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
-                                      const unsigned long long* __restrict__ parent, const Ctl* __restrict__ ctl,
-                                      wfst_tr* __restrict__ out) {
+                                      const uint64_t* __restrict__ key, const unsigned long long* __restrict__ parent,
+                                      Ctl* __restrict__ ctl, wfst_tr* __restrict__ out, uint32_t out_cap) {
   if (threadIdx.x || blockIdx.x) return;
-  uint32_t cur = ctl->f_parent;
-  const uint32_t hops = ctl->hops;
-  for (uint32_t k = 0; k < hops; ++k) {
+  uint32_t cur = ctl->f_parent, k = 0;
+  // the walk ends at the start state, the only one whose key has no arcs in it (with class-1 predecessors its length
+  // need not be the hop count of the final state's key)
+  while ((uint32_t)key[cur] != 0u) {
     const unsigned long long p = parent[cur];
-    const uint32_t s = (uint32_t)(p >> 32), pos = (uint32_t)p;
+    if (p == PARENT_NONE || k >= out_cap) {  // no admissible predecessor (inexact sums with negative weights)
+      ctl->pad |= 4u;
+      return;
+    }
+    const uint32_t s = (uint32_t)(p >> 32) & 0x7FFFFFFFu, pos = (uint32_t)p;
     wfst_tr tr = arcs[offsets[s] + pos];
     tr.nextstate = k;
     out[k] = tr;
     cur = s;
+    ++k;
   }
+  ctl->hops = k;
 }
 
 // ---- transpose of the CSR, cached on the FST handle once it is queried again: with it the
@@ -500,11 +522,18 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
                                                                wfst_tr* __restrict__ out, uint32_t out_cap) {
   const uint32_t lane = threadIdx.x;
   if (!ctl->has_path) return;
-  uint32_t cur = ctl->f_parent;
-  const uint32_t hops = ctl->hops;
-  if (hops > out_cap) return;  // the host falls back to the parent pass
-  for (uint32_t k = 0; k < hops; ++k) {
+  uint32_t cur = ctl->f_parent, k = 0;
+  if (ctl->hops > out_cap) {  // the host falls back to the parent pass
+    if (lane == 0) ctl->pad |= 8u;
+    return;
+  }
+  for (;; ++k) {
     const uint64_t kt = key[cur];
+    if ((uint32_t)kt == 0u) break;  // the start state
+    if (k >= out_cap) {
+      if (lane == 0) ctl->pad |= 8u;
+      return;
+    }
     unsigned long long best = ~0ull;
     for (uint32_t j = rev_off[cur] + lane; j < rev_off[cur + 1]; j += 64) {
       const uint2 ra = rev_arc[j];
@@ -513,8 +542,9 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
       const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(wn[offsets[ra.x] + ra.y].x)) + 0.0f;
       if (!(c < INF)) continue;
       const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
-      if (ck == kt) {
-        const unsigned long long cand = ((unsigned long long)ra.x << 32) | ra.y;
+      const unsigned long long cls = parent_class(ck, ks, kt);
+      if (cls != PARENT_NONE) {
+        const unsigned long long cand = cls | ((unsigned long long)ra.x << 32) | ra.y;
         best = cand < best ? cand : best;
       }
     }
@@ -522,7 +552,11 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
       const unsigned long long o = __shfl_xor(best, d);
       best = o < best ? o : best;
     }
-    const uint32_t s = (uint32_t)(best >> 32), pos = (uint32_t)best;
+    if (best == PARENT_NONE) {  // no admissible predecessor: reported, not followed
+      if (lane == 0) ctl->pad |= 4u;
+      return;
+    }
+    const uint32_t s = (uint32_t)(best >> 32) & 0x7FFFFFFFu, pos = (uint32_t)best;
     if (lane == 0) {
       wfst_tr tr = arcs[offsets[s] + pos];
       tr.nextstate = k;
@@ -530,6 +564,7 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
     }
     cur = s;
   }
+  if (lane == 0) ctl->hops = k;  // the real length of the walk
 }
 
 __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __restrict__ dist, uint32_t* __restrict__ hops,
@@ -1147,23 +1182,31 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   if (!j->tail_queued) queue_tail(j.get());
   HIP_CHECK(hipStreamSynchronize(st));
   const Ctl* hc = j->hc;
-  if (hc->pad) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
+  if (hc->pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
+  if (hc->pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
   if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
   const uint32_t hops = hc->hops;
   const float final_weight = hc->final_weight;
-  if (j->rev && hops <= PATH_PINNED) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
-  std::vector<wfst_tr> path(hops);
-  if (hops) {
+  if (j->rev && !(hc->pad & 8u)) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
+  // the parent pass (first query of an FST, or a path longer than the pinned buffer): a path has at most n - 1 arcs
+  std::vector<wfst_tr> path;
+  uint32_t len = 0;
+  {
     DBuf<unsigned long long> parent(*ctx->pool, n);
     HIP_CHECK(hipMemsetAsync(parent.p, 0xFF, (size_t)n * sizeof(unsigned long long), st));
+    HIP_CHECK(hipMemsetAsync(&sv.ctl.p->pad, 0, sizeof(uint32_t), st));
     const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
     sssp_parent_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, parent.p, n);
-    DBuf<wfst_tr> out(*ctx->pool, hops);
-    sssp_backtrace_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, parent.p, sv.ctl.p, out.p);
-    HIP_CHECK(hipMemcpyAsync(path.data(), out.p, (size_t)hops * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
+    DBuf<wfst_tr> out(*ctx->pool, n);
+    sssp_backtrace_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, sv.key.p, parent.p, sv.ctl.p, out.p, n);
+    HIP_CHECK(hipMemcpyAsync(j->hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (hc->pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
+    len = hc->hops;
+    path.resize(len);
+    if (len) HIP_CHECK(hipMemcpy(path.data(), out.p, (size_t)len * sizeof(wfst_tr), hipMemcpyDeviceToHost));
   }
-  return build_path_fst(ctx, true, hops, final_weight, path.data());
+  return build_path_fst(ctx, true, len, final_weight, path.data());
 }
 
 void shortest_path_n1_abandon(wfst_sp_job* job) {

@@ -32,6 +32,9 @@ constexpr uint32_t MB_NBMAX = 256;       // blocks (n <= 2^20)
 constexpr uint32_t MB_THREADS = 1024;
 constexpr uint32_t MB_HOP_BITS = 32 - MB_LOG;
 constexpr uint32_t MB_UNROLL = 8;  // active states a 16-lane group relaxes at once (independent load chains per lane)
+#ifndef MB_WT
+#define MB_WT 0  // staged messages leave with write-through (sc1) stores: nothing is left dirty in the L2 for the end of the kernel
+#endif
 constexpr uint32_t MB_STG = 24;    // messages per destination staged in LDS between two flushes (the rest is stored directly)
 
 struct MboxView {
@@ -341,7 +344,11 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
     if (reg < nb) {
       const uint32_t b0 = l_base[reg], cnt = min(l_cur[reg] - b0, MB_STG), ro = l_roff_out[reg] + b0;
-      for (uint32_t k = q; k < cnt; k += 4) msgs_out[ro + k] = l_stage[reg * MB_STG + k];
+      for (uint32_t k = q; k < cnt; k += 4) {
+        const uint2 sm = l_stage[reg * MB_STG + k];
+        if (MB_WT) __hip_atomic_store((unsigned long long*)&msgs_out[ro + k], ((unsigned long long)sm.y << 32) | sm.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else msgs_out[ro + k] = sm;
+      }
     }
     if (r0 + ROUND < an) {  // another round: its messages are staged from the current cursors on
       __syncthreads();
