@@ -31,14 +31,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def kernel_sources_sha256():
+    """hash of the relaxation sources: profiles/pmc_relax_traffic.json records it, so that a PMC figure taken at another
+    state of the kernel is flagged stale in the bench line"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_mailbox_async.h"):
+        with open(os.path.join(ROOT, "rustfst_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default: ~0.5 s of steps)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--states", type=int, default=1_000_000)
     ap.add_argument("--fanout", type=int, default=10)
     ap.add_argument("--sigma", type=int, default=256)
@@ -46,6 +57,9 @@ def parse_args():
     ap.add_argument("--acc-len", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra legs (first-query times, the single-string case of configs[1], the "
+                         "all-cores CPU batch leg)")
     ap.add_argument("--serial", action="store_true",
                     help="run S1 then S2 of a step on ONE stream.  Default: S2's batch is enqueued asynchronously on a "
                          "second context / HIP stream (wfst_compose_shortest_path_batch_begin), S1 runs on the first, "
@@ -55,6 +69,8 @@ def parse_args():
                          "context gets the rest; hipExtStreamCreateWithCUMask).  0 = no partitioning (default: with the "
                          "string o T kernel the batch is 0.19 ms and partitioning only takes CUs from shortest_path; it "
                          "paid, 1.04 -> 0.88 ms, while the batch ran on the general 0.7 ms kernel).")
+    ap.add_argument("--order", choices=["s2-first", "s1-first"], default="s2-first",
+                    help="which request of a step is enqueued first when they overlap")
     args = ap.parse_args()
     args.overlap = not args.serial
     return args
@@ -83,7 +99,7 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    stream = torch.cuda.Stream(device=device)
+    stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("WFST_BENCH_PRIO1", "0")))
     if args.overlap and args.batch_cus > 0:
         # Two contexts on DISJOINT compute units: the batch kernel is 64 lone waves chasing dependent loads, and a
         # load issued from a CU that also hosts streaming relaxation waves waits 2-4x longer in that CU's memory
@@ -101,7 +117,7 @@ def main():
     else:
         ctx = rustfst_amd.Context(local_rank, stream=stream.cuda_stream)
         # second context (own HIP stream + pools) for the batch pipeline: S1 and S2 are independent requests
-        stream2 = torch.cuda.Stream(device=device, priority=-1)
+        stream2 = torch.cuda.Stream(device=device, priority=int(os.environ.get("WFST_BENCH_PRIO2", "-1")))
         ctx2 = ctx if (not args.overlap) else rustfst_amd.Context(local_rank, stream=stream2.cuda_stream)
     rustfst_amd.set_default_context(ctx)
 
@@ -116,6 +132,20 @@ def main():
     dt2 = dt  # T is read-only for both pipelines: one HBM copy serves both contexts
     e_t = int(t["offsets"][-1])
     gen_s = time.time() - t0
+
+    # ------------------------------------------------------------------ cold queries (untimed setup, reported)
+    # a FRESH handle of T, HBM-resident: the first shortest_path builds the mailbox region plan and takes the parent
+    # pass; the second builds the transpose for the backtrace; from the third on the solve is one predicted batch
+    cold = None
+    if rank == 0 and not args.no_extras:
+        dcold = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+        torch.cuda.synchronize(device)
+        cold = []
+        for _ in range(4):
+            c0 = time.perf_counter()
+            dcold.shortest_path()
+            cold.append(round(1e3 * (time.perf_counter() - c0), 4))
+        del dcold
 
     last = {}
 
@@ -140,9 +170,13 @@ def main():
             # S2 first: its one long, narrow kernel (one wave per acceptor) must be in flight BEFORE the chain of
             # GPU-wide relaxation sweeps is queued, or the hardware runs the chain to its end first
             # (tools/ubench_concurrency.hip: 623 us overlapped vs 904 us serialised).
-            job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
-            # S1 asynchronously too: the host builds the batch's 64 result FSTs while the sweeps are still running
-            sp_job = dt.shortest_path_begin()
+            if args.order == "s2-first":
+                job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
+                # S1 asynchronously too: the host builds the batch's 64 result FSTs while the sweeps are still running
+                sp_job = dt.shortest_path_begin()
+            else:
+                sp_job = dt.shortest_path_begin()
+                job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
             outs, n_arcs = job.finish()
             sp = sp_job.finish()
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
@@ -180,8 +214,13 @@ def main():
         barrier()
         t_start = time.perf_counter()
         arcs = 0
-        for _ in range(args.steps):
+        step_s = np.empty(args.steps, dtype=np.float64)  # host clock per step (a step ends with both results on the host)
+        prev = t_start
+        for k in range(args.steps):
             arcs += step()
+            now = time.perf_counter()
+            step_s[k] = now - prev
+            prev = now
         drain()
         barrier()
         elapsed = time.perf_counter() - t_start
@@ -209,6 +248,26 @@ def main():
         ms_sp_t = alone(lambda: dt.shortest_path())
         ms_batch = alone(lambda: rustfst_amd.compose_shortest_path_batch(daccs, dt2, ctx=ctx2))
         sweeps = ctx.stats()["sweeps"]
+        relax_kernel = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mboxa_kernel")[int(ctx.stats()["relax_kernel"])]
+
+        # ------------------------------------------------------------------ configs[1]: ONE 1000-arc string against a
+        # 100k-state T (the case a lone dependent chain makes the GPU lose to one CPU core; reported, not timed above)
+        config2 = None
+        if rank == 0 and not args.no_extras:
+            t2 = synth.make_transducer(100_000, args.fanout, args.sigma, 0.0, seed=2)
+            a2 = synth.make_acceptors(t2, 1, 1000, seed0=2)
+            d2 = rustfst_amd.DeviceFst.from_arrays(t2["n_states"], t2["start"], t2["offsets"], t2["arcs"], t2["finals"], t2["props"], ctx)
+            da2 = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(a2, ctx))
+            for _ in range(3):
+                rustfst_amd.compose_shortest_path_batch(da2, d2, ctx=ctx)
+            best = float("inf")
+            for _ in range(10):
+                torch.cuda.synchronize(device)
+                c0 = time.perf_counter()
+                o2, n2 = rustfst_amd.compose_shortest_path_batch(da2, d2, ctx=ctx)
+                best = min(best, time.perf_counter() - c0)
+            config2 = {"workload": "configs[1]: one 1000-arc linear acceptor o T(100k states / 1M arcs) -> shortest path (fused call)",
+                       "gpu_ms": round(1e3 * best, 4), "composed_arcs": int(n2), "_t2": t2, "_a2": a2}
 
         # ------------------------------------------------------------------ roofline of the relaxation kernel
         # HIP events bracket every sssp_relax_kernel launch on ctx's stream (wfst_ctx_set_profiling);
@@ -224,7 +283,7 @@ def main():
                 algo_bytes = 20.0 * st["relax_arcs"] + 12.0 * st["relax_states"]
                 achieved = algo_bytes / (st["relax_ms"] * 1e-3) / 1e9
                 roofline = {
-                    "kernel": "sssp_relax_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                    "kernel": relax_kernel, "bound": "hbm", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "launches": int(st["relax_launches"]),
                     "avg_launch_us": round(1e3 * st["relax_ms"] / max(1, st["relax_launches"]), 2),
@@ -248,7 +307,17 @@ def main():
                         pmc = json.load(fh)
                     roofline["traffic"] = round(pmc["traffic_bytes_per_solve"] / max(1, st["relax_launches"]))
                     roofline["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / algo_bytes, 2)
+                    roofline["traffic_over_solve_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / (20.0 * e_t + 12.0 * args.states), 2)
                     roofline["traffic_source"] = pmc["source"] + "; " + pmc["correction"]
+                    # the PMC file is a committed measurement, not a live one: say what it was taken at, and whether
+                    # the relaxation sources have changed since
+                    roofline["traffic_commit"] = pmc.get("commit")
+                    roofline["traffic_kernel"] = pmc.get("kernel")
+                    roofline["traffic_stale"] = bool(pmc.get("kernel_sources_sha256") != kernel_sources_sha256()
+                                                     or pmc.get("kernel") != relax_kernel)
+                    for k in ("l2_hit_rate", "tcc_ea_atomic_per_solve", "counters_file"):
+                        if k in pmc:
+                            roofline[k] = pmc[k]
 
         # the other kernel of the step, for completeness: the fused batch kernel is LATENCY bound (one wave per
         # problem walking ~200 dependent BFS levels), so its fraction of the HBM peak is tiny by construction;
@@ -296,6 +365,22 @@ def main():
             cpu_s += (c1 - c0) + o_sec
             cpu_steps += 1
         cpu_arcs = cpu_steps * (e_t + 2 * o_arcs)
+        # the batch leg on every host core (the reference's algorithms are single-threaded; independent acceptors are the
+        # only parallelism a CPU deployment has): threads of the C++ restatement, one acceptor at a time each
+        all_cores = None
+        n_cores = min(os.cpu_count() or 1, len(oaccs))  # one acceptor per thread at most
+        if not args.no_extras and n_cores > 1:
+            _, o_arcs_mt, sec_mt = oracle_py.compose_shortest_path_batch(oaccs, ot, n_threads=n_cores)
+            reps = max(1, min(50, int(2.0 / max(sec_mt, 1e-4))))
+            sec_mt = min(oracle_py.compose_shortest_path_batch(oaccs, ot, n_threads=n_cores)[2] for _ in range(reps))
+            all_cores = {"cores": n_cores, "host_cores": os.cpu_count(), "ms_batch": round(1e3 * sec_mt, 3), "batch_arcs_per_s": round(2 * o_arcs_mt / sec_mt, 1),
+                         "note": "batch leg only (compose -> shortest_path of the acceptors, one thread per acceptor); "
+                                 "shortest_path(T) is one sequential search on any number of cores"}
+        if config2 is not None:
+            ot2 = oracle_py.OracleFst.from_flat(*(config2["_t2"][k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props")))
+            oa2 = [oracle_py.OracleFst.from_flat(*(a[k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props"))) for a in config2["_a2"]]
+            config2["cpu_ms"] = round(1e3 * min(oracle_py.compose_shortest_path_batch(oa2, ot2, n_threads=1)[2] for _ in range(10)), 4)
+            config2["cpu_cores"] = 1
         # parity spot-check of what was just timed (cheap): total weights agree
         gw = last["sp"].to_flat()
         gpu_total = float(np.float32(np.add.reduce(gw["arcs"]["weight"][::-1].astype(np.float32), dtype=np.float32) + gw["finals"][0])) if gw["n_states"] else float("inf")
@@ -308,14 +393,26 @@ def main():
             "ms_batch": round(1e3 * t_batch / cpu_steps, 2), "queue_kind": osp.queue_kind,
             "shortest_path_T_weight_cpu": osp.total_weight, "shortest_path_T_weight_gpu": gpu_total,
             "composed_arcs_match": bool(o_arcs == last["n_arcs"]),
+            "all_cores": all_cores,
         }
 
     if rank == 0:
         value = arcs / elapsed
+        if config2 is not None:
+            config2 = {k: v for k, v in config2.items() if not k.startswith("_")}
+        rccl_world = 1
+        if world > 1 or force_dist:
+            import torch.distributed as dist
+            rccl_world = dist.get_world_size()
+        ms = 1e3 * step_s
         out = {
             "metric": "arcs relaxed/sec (compose -> shortest_path, 1M-state / 10M-arc FST)",
             "value": round(value, 1), "unit": "arcs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_stats": {"mean": round(float(ms.mean()), 4), "std": round(float(ms.std()), 4), "min": round(float(ms.min()), 4),
+                                  "p50": round(float(np.percentile(ms, 50)), 4), "p99": round(float(np.percentile(ms, 99)), 4),
+                                  "timed_seconds": round(elapsed, 3), "clock": "host perf_counter per step on rank 0"},
+            "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist),
             "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -330,6 +427,10 @@ def main():
             "ms_per_compose_shortest_path": round(ms_batch / max(1, len(mine)), 5),
             "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(last["n_arcs"]),
             "setup_seconds": round(gen_s, 2), "priming_steps": 3,
+            "cold_query_ms": None if cold is None else {"first": cold[0], "second": cold[1], "third": cold[2], "fourth": cold[3],
+                                                        "note": "shortest_path(T) on a fresh HBM-resident handle: 1st builds the "
+                                                                "mailbox region plan + parent pass, 2nd builds the transpose"},
+            "config2_single_string": config2,
             "roofline": roofline, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -296,6 +296,8 @@ typedef struct {
   double compose_ms;       /* device time of the last compose / fused-batch kernel */
   uint64_t string_problems; /* problems of the last fused batch that took the string o T kernel (fst1 a linear,
                                epsilon-free acceptor, fst2 without input epsilons) */
+  uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
+                               (owner-computes mailbox sweeps), 2 sssp_mboxa_kernel (several rounds per launch) */
 } wfst_stats;
 /* profiling on: relaxation launches are bracketed by HIP events (adds sync; never on in timed runs) */
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on);

@@ -782,6 +782,7 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
                                                  delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
   }
   HIP_CHECK(hipGetLastError());
+  ctx->stats.relax_kernel = sv.mboxa ? 2u : sv.mbox ? 1u : 0u;
   sv.sweep_cap = 4ull * n + 64;
   if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
   if (const char* e = std::getenv("WFST_SSSP_CHASE_ROUNDS")) sv.chase_rounds = (uint32_t)std::atol(e);

@@ -87,8 +87,25 @@ def timeline(path, which=-1):
     print(f"\nsolve: first start -> last end {(rows[i1][2] - rows[i0][1]) / 1e3:.1f} us; kernel time {tot / 1e3:.1f} us; gaps {gaps:.1f} us")
 
 
+def window(path, which=-2):
+    """every kernel (all streams) between two consecutive setup kernels: start offset, duration"""
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    setups = [i for i, r in enumerate(rows) if "setup_kernel" in r[0]]
+    i0 = setups[which]
+    t0 = min(rows[i0][1], min(r[1] for r in rows[max(0, i0 - 3):i0 + 1]))
+    i1 = setups[which + 1] if which + 1 < 0 and which + 1 + len(setups) < len(setups) else len(rows)
+    print("| start_us | dur_us | kernel |")
+    print("|---:|---:|---|")
+    for k in range(max(0, i0 - 3), min(i1, len(rows))):
+        name, s, e = rows[k]
+        print(f"| {(s - t0) / 1e3:8.1f} | {(e - s) / 1e3:7.2f} | `{short(name, 36)}` |")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "timeline":
+    if sys.argv[1] == "window":
+        window(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else -2)
+    elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else -1)
     elif sys.argv[1] == "trace":
         trace(sys.argv[2])
