@@ -123,10 +123,20 @@ def main():
 
     # ------------------------------------------------------------------ synthetic workload (identical on all ranks)
     t0 = time.time()
-    t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
     n_total = args.batch_per_gpu * world
-    accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
     mine = wdist.shard_indices(n_total, rank, world)
+    if world > 1 or force_dist:
+        # rank 0 builds T and the global batch of acceptors once; the other ranks receive the bytes over RCCL (one payload
+        # broadcast) and keep T plus their own shard
+        flats = None
+        if rank == 0:
+            t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
+            flats = [t] + synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
+        flats = wdist.broadcast_flat_fsts(flats, 0, device)
+        t, accs_all = flats[0], flats[1:]
+    else:
+        t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
+        accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
     dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
     daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx2))
     dt2 = dt  # T is read-only for both pipelines: one HBM copy serves both contexts

@@ -193,3 +193,64 @@ def gather_fsts(local: Sequence[bytes], world: int, device=None) -> List[List[by
             off += int(s)
         res.append(items)
     return res
+
+
+# ---- workload distribution: rank 0 builds the shared transducer and the acceptors ONCE, the other ranks receive them
+_FLAT_KEYS = ("offsets", "arcs", "finals")
+
+
+def broadcast_flat_fsts(flats, src: int = 0, device=None):
+    """Broadcasts a list of flat FST dicts (n_states, start, offsets, arcs, finals, props) from rank `src` to every rank
+    of the default group: one small header broadcast (shapes) and ONE payload broadcast of the concatenated arrays
+    (RCCL when `device` is a GPU, gloo on CPU).  On rank `src` pass the list; elsewhere pass None.  Returns the list."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank()
+    kw = {} if device is None else {"device": device}
+    if rank == src:
+        hdr = []
+        for f in flats:
+            hdr += [int(f["n_states"]), -1 if f["start"] is None else int(f["start"]), int(f["props"]), len(f["arcs"])]
+        hdr_t = torch.tensor([len(flats)] + hdr, dtype=torch.int64, **kw)
+        n_hdr = torch.tensor([hdr_t.numel()], dtype=torch.int64, **kw)
+    else:
+        n_hdr = torch.zeros(1, dtype=torch.int64, **kw)
+    dist.broadcast(n_hdr, src)
+    if rank != src:
+        hdr_t = torch.zeros(int(n_hdr.item()), dtype=torch.int64, **kw)
+    dist.broadcast(hdr_t, src)
+    hdr = hdr_t.cpu().numpy()
+    n = int(hdr[0])
+    meta = hdr[1:].reshape(n, 4)
+    # payload: per FST offsets (n_states + 1 u32) | arcs (16 B each) | finals (n_states f32), as bytes
+    sizes = [4 * (int(m[0]) + 1) + 16 * int(m[3]) + 4 * int(m[0]) for m in meta]
+    total = int(sum(sizes))
+    if rank == src:
+        buf = np.empty(total, dtype=np.uint8)
+        o = 0
+        for f in flats:
+            for k, dt in (("offsets", np.uint32), ("arcs", TR_DTYPE), ("finals", np.float32)):
+                b = np.ascontiguousarray(f[k], dtype=dt).view(np.uint8).reshape(-1)
+                buf[o:o + b.size] = b
+                o += b.size
+        payload = torch.from_numpy(buf)
+        if device is not None:
+            payload = payload.to(device)
+    else:
+        payload = torch.empty(total, dtype=torch.uint8, **kw)
+    dist.broadcast(payload, src)
+    if rank == src:
+        return list(flats)
+    raw = payload.cpu().numpy()
+    out, o = [], 0
+    for m in meta:
+        ns, start, props, na = int(m[0]), int(m[1]), int(m[2]), int(m[3])
+        offsets = raw[o:o + 4 * (ns + 1)].view(np.uint32).copy()
+        o += 4 * (ns + 1)
+        arcs = raw[o:o + 16 * na].view(TR_DTYPE).copy()
+        o += 16 * na
+        finals = raw[o:o + 4 * ns].view(np.float32).copy()
+        o += 4 * ns
+        out.append(dict(n_states=ns, start=None if start < 0 else start, offsets=offsets, arcs=arcs, finals=finals, props=props))
+    return out

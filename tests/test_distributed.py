@@ -150,3 +150,85 @@ def test_gather_general_fsts_gloo_world2():
         p.join(timeout=240)
         assert p.exitcode == 0
     assert q.get(timeout=10) == "ok"
+
+
+def _worker_bcast(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from rustfst_amd import dist as wdist
+    from rustfst_amd import synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = synth.make_transducer(300, 5, 16, 0.05, seed=21)
+        accs = synth.make_acceptors(t, 5, 9, seed0=40)
+        empty = dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=accs[0]["arcs"][:0], finals=np.zeros(0, np.float32), props=0)
+        want = [t] + accs + [empty]
+        got = wdist.broadcast_flat_fsts(want if rank == 0 else None, 0, None)
+        ok = len(got) == len(want)
+        for a, b in zip(got, want):
+            ok &= a["n_states"] == b["n_states"] and a["start"] == b["start"] and int(a["props"]) == int(b["props"])
+            ok &= np.array_equal(a["offsets"], b["offsets"]) and np.array_equal(a["arcs"], b["arcs"])
+            ok &= np.array_equal(a["finals"].view(np.uint32), b["finals"].view(np.uint32))
+        q.put((rank, "ok" if ok else "mismatch"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_broadcast_workload_gloo_world2():
+    """dist.broadcast_flat_fsts: rank 0 builds the transducer and the acceptors once, the other rank receives identical
+    arrays (one header + one payload broadcast), including an empty FST."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bcast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_gather_of_hip_results():
+    """The N > 1 plumbing on the hardware that exists here: a 1-rank nccl (= RCCL) process group carries the results of the
+    HIP batch path through the same calls bench.py --gpus N uses (broadcast of the workload, pack_device_paths, the
+    asynchronous all-gather, interleave), and the gathered paths equal the local ones."""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import rustfst_amd
+from rustfst_amd import dist as wdist, synth
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+ctx = rustfst_amd.Context(0)
+t = synth.make_transducer(20000, 8, 64, 0.0, seed=5)
+flats = wdist.broadcast_flat_fsts([t] + synth.make_acceptors(t, 6, 30, seed0=7), 0, dev)
+t, accs = flats[0], flats[1:]
+dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+outs, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs, ctx), dt)
+packed = wdist.pack_device_paths(outs, 30 + 8)
+g1 = wdist.gather_paths(packed, 1, dev)
+g2 = wdist.gather_paths_async(packed, 1, dev).result()
+assert g1.shape == (1,) + packed.shape and np.array_equal(g1, g2) and np.array_equal(g1[0], packed)
+back = wdist.unpack_paths(wdist.interleave(g1, 6))
+for o, b in zip(outs, back):
+    f = o.to_flat()
+    assert f["n_states"] == b["n_states"] == 31 and np.array_equal(f["arcs"], b["arcs"]) and f["finals"][0] == b["finals"][0]
+blobs = [o.to_bytes() for o in outs[:2]]
+assert wdist.gather_fsts(blobs, 1, dev) == [blobs]
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-1 OK")
+''' % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL-1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -39,78 +39,36 @@ def golden(name):
         return json.load(fh)
 
 
-# ------------------------------------------------------------------ the reference's own python tests, verbatim shape
+# ------------------------------------------------------------------ the reference's own python tests, from their vectors
+def vector_fst_from_golden(g):
+    """a VectorFst built through the MutableFst calls the reference's tests use (add_state / set_start / set_final /
+    add_tr), from a fixture {n_states, start, arcs [[state, ilabel, olabel, weight, nextstate] ...], finals [[state, w] ...]}"""
+    f = VectorFst()
+    for _ in range(g["n_states"]):
+        f.add_state()
+    if g["start"] is not None:
+        f.set_start(g["start"])
+    for s, w in g["finals"]:
+        f.set_final(s, w)
+    for s, il, ol, w, nxt in g["arcs"]:
+        f.add_tr(s, Tr(il, ol, w, nxt))
+    return f
+
+
 def test_compose_fst(gpu_ctx):
-    """rustfst-python/tests/algorithms/test_compose.py:13-81"""
-    fst1 = VectorFst()
-    s1 = fst1.add_state()
-    s2 = fst1.add_state()
-    s3 = fst1.add_state()
-    fst1.set_start(s1)
-    fst1.set_final(s2)
-    fst1.set_final(s3)
-    fst1.add_tr(s1, Tr(1, 2, 1.0, s2))
-    fst1.add_tr(s1, Tr(1, 4, 2.0, s3))
-    fst1.add_tr(s2, Tr(3, 5, 2.0, s2))
-
-    fst2 = VectorFst()
-    s1 = fst2.add_state()
-    s2 = fst2.add_state()
-    s3 = fst2.add_state()
-    fst2.set_start(s1)
-    fst2.set_final(s3)
-    fst2.add_tr(s1, Tr(2, 6, 1.0, s2))
-    fst2.add_tr(s2, Tr(5, 7, 2.5, s3))
-    fst2.add_tr(s3, Tr(5, 8, 1.5, s3))
-    fst2.add_tr(s1, Tr(4, 9, 3.0, s3))
-
-    expected_fst = VectorFst()
-    s1 = expected_fst.add_state()
-    s2 = expected_fst.add_state()
-    s3 = expected_fst.add_state()
-    s4 = expected_fst.add_state()
-    expected_fst.set_start(s1)
-    expected_fst.set_final(s3)
-    expected_fst.set_final(s4)
-    expected_fst.add_tr(s1, Tr(1, 6, 2.0, s2))
-    expected_fst.add_tr(s1, Tr(1, 9, 5.0, s3))
-    expected_fst.add_tr(s2, Tr(3, 7, 4.5, s4))
-    expected_fst.add_tr(s4, Tr(3, 8, 3.5, s4))
-
-    fst3 = fst1.compose(fst2)
-    assert fst3 == expected_fst
+    """K1: the vectors of rustfst-python/tests/algorithms/test_compose.py:13-81 (tests/golden/k1_compose.json)"""
+    g = golden("k1_compose.json")
+    fst1, fst2, expected_fst = (vector_fst_from_golden(g[k]) for k in ("fst1", "fst2", "expected"))
+    assert fst1.compose(fst2) == expected_fst
     # explicit Sequence filter + connect (compose_with_config) gives the same machine
-    fst4 = fst1.compose(fst2, ComposeConfig(ComposeFilter.SEQUENCEFILTER, True))
-    assert fst4 == expected_fst
+    assert fst1.compose(fst2, ComposeConfig(ComposeFilter.SEQUENCEFILTER, True)) == expected_fst
 
 
 def test_shortest_path(gpu_ctx):
-    """rustfst-python/tests/algorithms/test_shortest_path.py:5-51"""
-    fst1 = VectorFst()
-    s1 = fst1.add_state()
-    s2 = fst1.add_state()
-    s3 = fst1.add_state()
-    s4 = fst1.add_state()
-    fst1.set_start(s1)
-    fst1.set_final(s4, 2.0)
-    fst1.add_tr(s1, Tr(1, 1, 3.0, s2))
-    fst1.add_tr(s2, Tr(2, 2, 2.0, s2))
-    fst1.add_tr(s2, Tr(3, 3, 4.0, s4))
-    fst1.add_tr(s1, Tr(4, 4, 5.0, s3))
-    fst1.add_tr(s3, Tr(5, 5, 4.0, s4))
-
-    expected_fst = VectorFst()
-    s1 = expected_fst.add_state()
-    s2 = expected_fst.add_state()
-    s3 = expected_fst.add_state()
-    expected_fst.set_start(s3)
-    expected_fst.set_final(s1, 2.0)
-    expected_fst.add_tr(s3, Tr(1, 1, 3.0, s2))
-    expected_fst.add_tr(s2, Tr(3, 3, 4.0, s1))
-
-    config = ShortestPathConfig(1, True)
-    shortes_path = fst1.shortest_path(config)
-    assert shortes_path == expected_fst
+    """K2: the vectors of rustfst-python/tests/algorithms/test_shortest_path.py:5-51 (tests/golden/k2_shortest_path.json)"""
+    g = golden("k2_shortest_path.json")
+    fst1, expected_fst = vector_fst_from_golden(g["fst"]), vector_fst_from_golden(g["expected"])
+    assert fst1.shortest_path(ShortestPathConfig(1, True)) == expected_fst
     assert fst1.shortest_path() == expected_fst
 
 
@@ -412,6 +370,48 @@ def test_config3_properties_1m_states(gpu_ctx, oracle):
         if i < 2:
             can = to_oracle(oracle, a).compose(ot).shortest_path_canonical()
             assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")
+
+
+def test_config3_512_acceptors_and_one_long_string_against_1m_states(gpu_ctx, oracle):
+    """BASELINE configs[3] in its one-GPU form: all 512 linear acceptors (len 200) of the batch against the shared
+    1M-state / 10M-arc T in one fused call — every path spells its acceptor, a random 16 are bit-identical to the oracle —
+    and the single-string case of SURVEY §8(d) (C3-S2): ONE acceptor of length 1000 against the same T, composition and
+    shortest path bit-identical to the oracle, through the two-step route and through the fused call."""
+    t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
+    accs = synth.make_acceptors(t, 512, 200, seed0=1000)
+    long_acc = synth.make_acceptors(t, 1, 1000, seed0=31)[0]
+    dt, ot = to_device(t), to_oracle(oracle, t)
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs), dt)
+    assert len(outs) == 512 and n_arcs >= 512 * 200
+    flats = [o.to_flat() for o in outs]
+    for a, f in zip(accs, flats):
+        assert f["n_states"] == 201
+        np.testing.assert_array_equal(f["arcs"]["ilabel"][::-1], a["arcs"]["ilabel"])
+    for i in np.random.default_rng(5).choice(512, 16, replace=False):
+        can = to_oracle(oracle, accs[i]).compose(ot).shortest_path_canonical()
+        assert_flat_identical(flats[i], can.to_flat(), f"512-batch item {i}")
+    # one long string
+    oc = to_oracle(oracle, long_acc).compose(ot)
+    dc = to_device(long_acc).compose(dt)
+    assert_flat_identical(dc.to_flat(), oc.to_flat(), "A(1000) o T(1M)")
+    can = oc.shortest_path_canonical().to_flat()
+    assert can["n_states"] == 1001
+    assert_flat_identical(dc.shortest_path().to_flat(), can, "shortest_path(A(1000) o T(1M))")
+    one, _ = rustfst_amd.compose_shortest_path_batch([to_device(long_acc)], dt)
+    assert_flat_identical(one[0].to_flat(), can, "fused A(1000) o T(1M)")
+
+
+def test_config5_lookahead_compose_and_nbest_at_scale():
+    """BASELINE configs[4] end to end (tools/config5_lookahead.py): the 5M-state / 50M-arc HCLG-shaped FST with 5 %
+    epsilons as the look-ahead operand (reachability data built once), 64 linear acceptors of 200 labels — relabel,
+    look-ahead composition (one by one and as ONE batch), n = 10 shortest paths of every result.  Checked without an
+    oracle at this size: the 10 best path weights equal those of the plain composition (+ connect) of the same pair,
+    the best path spells the acceptor, the batch gives the same state counts as the one-by-one calls."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5_lookahead.py"), "5000000", "64"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("delta", ["0", "0.7", "3", "1000"])
