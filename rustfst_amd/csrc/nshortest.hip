@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <cstdlib>
 
@@ -44,12 +45,23 @@ __global__ void rev_place_kernel(const uint32_t* __restrict__ offsets, const wfs
       tmp[slot] = make_uint2(i, s);
     }
 }
-// per target: sort the segment by arc index (insertion sort; segments are in-degree sized), emit reversed arcs
+// per target: put the segment back into arc-index order and emit the reversed arcs.  Segments of up to REV_SMALL in-arcs
+// (all but hub states) are insertion-sorted by one lane; a longer one — a hub with 1e5..1e6 in-arcs would cost
+// in-degree^2 dependent memory operations in that lane — is only LISTED here and sorted by rocPRIM's segmented radix
+// sort on the arc index (the low word of the {arc index, source} pair), then emitted by rev_emit_big_kernel.
+constexpr uint32_t REV_SMALL = 48;
 __global__ void rev_emit_kernel(const wfst_tr* __restrict__ arcs, const uint32_t* __restrict__ roff, uint2* __restrict__ tmp,
-                                uint32_t n_states, wfst_tr* __restrict__ rarcs) {
+                                uint32_t n_states, wfst_tr* __restrict__ rarcs, uint32_t* __restrict__ big_count,
+                                uint32_t* __restrict__ big_begin, uint32_t* __restrict__ big_end) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_states) return;
   const uint32_t b = roff[t], e = roff[t + 1];
+  if (e - b > REV_SMALL) {
+    const uint32_t k = atomicAdd(big_count, 1u);
+    big_begin[k] = b;
+    big_end[k] = e;
+    return;
+  }
   for (uint32_t i = b + 1; i < e; ++i) {
     const uint2 v = tmp[i];
     uint32_t j = i;
@@ -65,6 +77,19 @@ __global__ void rev_emit_kernel(const wfst_tr* __restrict__ arcs, const uint32_t
     a.nextstate = v.y + 1;  // state i -> i + 1 (super-initial state 0)
     rarcs[i] = a;
   }
+}
+// the listed segments, already sorted: one workgroup per segment
+__global__ void __launch_bounds__(256) rev_emit_big_kernel(const wfst_tr* __restrict__ arcs, const uint2* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ big_begin,
+                                                          const uint32_t* __restrict__ big_end, uint32_t n_big,
+                                                          wfst_tr* __restrict__ rarcs) {
+  for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x)
+    for (uint32_t i = big_begin[k] + threadIdx.x; i < big_end[k]; i += blockDim.x) {
+      const uint2 v = sorted[i];
+      wfst_tr a = arcs[v.x];
+      a.nextstate = v.y + 1;
+      rarcs[i] = a;
+    }
 }
 
 // one in-arc segment (state t of the original FST) -> pinned host memory: {count, arcs[min(count, cap)]}
@@ -117,8 +142,32 @@ std::shared_ptr<RevFst> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
     DBuf<uint2> d_tmp(pool, E);
     HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, (size_t)n * sizeof(uint32_t), st));
     rev_place_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.arcs, n, rev->d_roff.p, d_cursor.p, d_tmp.p);
-    rev_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.arcs, rev->d_roff.p, d_tmp.p, n, rev->d_arcs.p);
+    // (a segment longer than REV_SMALL exists at most E / REV_SMALL times)
+    const size_t big_cap = (size_t)(E / (REV_SMALL + 1)) + 1;
+    DBuf<uint32_t> d_big(pool, 1 + 2 * big_cap);
+    HIP_CHECK(hipMemsetAsync(d_big.p, 0, sizeof(uint32_t), st));
+    rev_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(f->dev.arcs, rev->d_roff.p, d_tmp.p, n, rev->d_arcs.p, d_big.p, d_big.p + 1,
+                                                     d_big.p + 1 + big_cap);
     HIP_CHECK(hipGetLastError());
+    uint32_t n_big = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_big, d_big.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (n_big) {  // hub states: segmented radix sort of the {arc index, source} pairs on the arc index
+      if (E >= 0x7FFFFFFFull) throw Error("reverse: too many arcs for the segmented sort");
+      DBuf<uint2> d_sorted(pool, E);
+      uint64_t* kin = (uint64_t*)d_tmp.p;
+      uint64_t* kout = (uint64_t*)d_sorted.p;
+      size_t temp_bytes = 0;
+      HIP_CHECK(rocprim::segmented_radix_sort_keys(nullptr, temp_bytes, kin, kout, (unsigned)E, n_big, d_big.p + 1,
+                                                   d_big.p + 1 + big_cap, 0u, 32u, st));
+      DBuf<uint8_t> temp(pool, temp_bytes);
+      HIP_CHECK(rocprim::segmented_radix_sort_keys(temp.p, temp_bytes, kin, kout, (unsigned)E, n_big, d_big.p + 1,
+                                                   d_big.p + 1 + big_cap, 0u, 32u, st));
+      rev_emit_big_kernel<<<std::min<uint32_t>(n_big, (uint32_t)ctx->n_cus * 8), 256, 0, st>>>(
+          f->dev.arcs, d_sorted.p, d_big.p + 1, d_big.p + 1 + big_cap, n_big, rev->d_arcs.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(st));  // d_sorted / temp are released here
+    }
     if (rev->on_host) {
       rev->h_arcs.resize(E);
       HIP_CHECK(hipMemcpyAsync(rev->h_arcs.data(), rev->d_arcs.p, E * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));

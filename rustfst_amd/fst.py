@@ -705,8 +705,14 @@ class VectorFst:
         return self
 
     def project(self, proj_type: Union["ProjectType", None] = None) -> "VectorFst":
-        """rustfst-python vector_fst.py `project` (algorithms/project.py:27-50): returns the projected FST."""
-        return self.to_device().project(proj_type).to_vector_fst()
+        """rustfst-python vector_fst.py:525-538 `project` (algorithms/project.py:27-50): projects THIS FST in place and
+        returns it (the reference returns self).  The device copy is projected and becomes this object's host data; the
+        cached device handle is dropped so that trs(), equality and later compose / shortest_path calls all see the
+        projected labels."""
+        projected = self.to_device().project(proj_type).to_vector_fst()
+        self._p, projected._p = projected._p, self._p
+        self._dev = None
+        return self
 
 
 # ------------------------------------------------------------------ free functions

@@ -980,6 +980,30 @@ def test_reverse_matches_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
     assert_flat_identical(d.reverse().reverse().to_flat(), o.reverse().reverse().to_flat(), f"reverse twice seed {seed}")
 
 
+@pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
+def test_reverse_and_nbest_with_hub_states(gpu_ctx, oracle, lazy, monkeypatch):
+    """Hub states (a final sink every state points at, a back-off state half of them point at: in-degrees of 1e5, the
+    shape of LM / HCLG graphs): the in-arc segments of such states are put back into the reference's order by a segmented
+    radix sort, not by the one-lane insertion sort of ordinary segments.  reverse() and the n-best search built on it stay
+    bit-identical to the oracle, and quick."""
+    import time
+    monkeypatch.setenv("WFST_NBEST_LAZY", lazy)
+    t = synth.make_transducer(120_000, 4, 32, 0.0, seed=11)
+    arcs = t["arcs"].copy()
+    n, f = t["n_states"], 4
+    arcs["nextstate"][0::f] = 7                                    # every state -> hub 7
+    arcs["nextstate"][1:n * f // 2:f] = 12345                      # half of the states -> hub 12345
+    t["arcs"] = arcs
+    t["finals"][:] = np.inf
+    t["finals"][7] = np.float32(0.25)
+    d, o = to_device(t), to_oracle(oracle, t)
+    t0 = time.perf_counter()
+    got = d.reverse().to_flat()
+    assert time.perf_counter() - t0 < 5.0
+    assert_flat_identical(got, o.reverse().to_flat(), "reverse with hub states")
+    assert_flat_identical(d.shortest_path(ShortestPathConfig(nshortest=5)).to_flat(), o.shortest_path_n(5).to_flat(), "n-best with hub states")
+
+
 # ------------------------------------------------------------------ the string o T kernel of the fused batch
 @pytest.mark.parametrize("kernel", ["1", "0"], ids=["string_kernel", "general_kernel"])
 @pytest.mark.parametrize("seed", range(10))
@@ -1195,6 +1219,18 @@ def test_project_known_answer_and_oracle(gpu_ctx, oracle):
         got = vbuild(g["fst"]).project(ptype)
         assert got == vbuild(g[key])
     assert rustfst_amd.project(vbuild(g["fst"])) == vbuild(g["expected_input"])  # default = input projection
+    # in place, like the reference (vector_fst.py:525-538 returns self): the object itself is projected, and what a later
+    # composition sees agrees with what trs() shows
+    f = vbuild(g["fst"])
+    f.to_device()  # a cached device copy must not survive the projection unprojected (or be the only projected one)
+    assert f.project(ProjectType.PROJECT_OUTPUT) is f and f == vbuild(g["expected_output"])
+    assert all(tr.ilabel == tr.olabel for s in range(f.num_states()) for tr in f.trs(s))
+    same = vbuild(g["expected_output"])
+    same.tr_sort(False)
+    f.tr_sort(False)
+    other = vbuild(g["expected_output"])
+    other.tr_sort(True)
+    assert f.compose(other) == same.compose(other)
     rng = np.random.default_rng(2024)
     for k in range(12):
         f = random_fst_flat(rng, int(rng.integers(1, 40)), 4, 4, p_eps_i=0.3, p_eps_o=0.3, p_final=0.3,
