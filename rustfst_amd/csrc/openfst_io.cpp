@@ -5,6 +5,7 @@
 // rustfst/src/fst_impls/vector_fst/serializable_fst.rs:45-168 (body, store()),
 // rustfst/src/parsers/bin_fst/utils_parsing.rs:10-44 (start / final / arc),
 // rustfst/src/parsers/bin_symt/nom_parser.rs:14-45 (symbol tables; skipped: they never reach the device).
+#include <algorithm>
 #include "common.h"
 #include "fst_props.h"
 
@@ -66,6 +67,13 @@ wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len)
   if (flags & 1u) skip_symt(c);
   if (flags & 2u) skip_symt(c);
   if (num_states < 0 || num_states >= 0x7FFFFFFF) throw Error("Error while parsing binary VectorFst: bad num_states");
+  // the header is untrusted: every state costs at least 12 bytes of body in a vector file (final weight + arc count) and
+  // 20 in a const file, so a state count the remaining bytes cannot hold is refused BEFORE anything is reserved for it
+  {
+    const uint64_t per_state = is_const ? 20u : 12u;
+    if ((uint64_t)num_states > (len - std::min(c.off, len)) / per_state)
+      throw Error("Error while parsing binary Fst: num_states exceeds what the file can hold");
+  }
   HostCsr h;
   h.offsets.reserve((size_t)num_states + 1);
   h.finals.reserve((size_t)num_states);

@@ -22,6 +22,12 @@
 // increasing id order inside their component, which is the reference's order (rm_epsilon_static.rs:108-127 reversed).
 // The epsilon graph, its components and depths are computed on the host (one pass over the arcs, like the reference's
 // own DFS).  States without a non-epsilon incoming arc lose their arcs; then connect.
+// A state whose closure outgrows 64 states is redone by rm_expand_wave: ONE WAVE per state, closure membership and the
+// (ilabel, olabel, nextstate) -> arc lookup through open-addressing tables in the state's scratch slice, the closure
+// distances by wave-parallel label correcting, the depth-first walk itself sequential (it defines the arc order) with a
+// visited state's arcs handled 64 at a time — no limit on the closure size, work linear in it (redone with four times
+// the room on overflow, like the one-thread kernel).  Finished arcs are copied into compact per-batch arenas and the
+// scratch of every attempt is released at once, so memory follows the size of the output.
 // The reference relaxes only improvements larger than delta = 1e-6 (approx_equal, shortest_distance.rs:216); d[] here is
 // the exact minimum of the left-folded f32 path sums, the same whenever weights differ by more than 1e-6 (any 1/512-grid
 // input) — the deviation already documented for shortest_distance.
@@ -36,7 +42,6 @@ namespace wfst {
 
 namespace {
 
-constexpr uint32_t RM_MAX_CLOSURE = 1024;
 struct RmCaps {
   uint32_t C;  // closure states
   uint32_t K;  // depth-first stack entries
@@ -159,6 +164,259 @@ __global__ void rm_expand(RmView v, const uint32_t* __restrict__ list, uint32_t 
   status[i] = 0u;
 }
 
+// ---- big closures: one wave per state -----------------------------------------------------------------------------
+struct RmBigCaps {
+  uint32_t C;   // closure states (table of 2C slots)
+  uint32_t K;   // depth-first stack entries
+  uint32_t A;   // arcs of the rewritten state (table of 2A slots)
+};
+__host__ __device__ inline uint32_t rm_pow2_at_least(uint32_t x) {
+  uint32_t p = 16;
+  while (p < x) p <<= 1;
+  return p;
+}
+__host__ __device__ inline size_t rm_big_arcs_offset(const RmBigCaps& c) {
+  const size_t words = (size_t)c.C * 3 + 2ull * rm_pow2_at_least(c.C) + c.K + 2ull * rm_pow2_at_least(c.A) + 16;
+  return (words * 4 + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t rm_big_slice_bytes(const RmBigCaps& c) { return rm_big_arcs_offset(c) + (size_t)c.A * 16; }
+
+__device__ __forceinline__ uint32_t rm_hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rm_enc(float f) {  // order-preserving bits (weights may be negative)
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float rm_dec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+
+// closure index of state t (0xFFFFFFFF if absent); the table holds index + 1
+__device__ __forceinline__ uint32_t rm_cl_find(const uint32_t* __restrict__ htab, uint32_t hmask, const uint32_t* __restrict__ cl, uint32_t t) {
+  for (uint32_t p = rm_hash32(t) & hmask;; p = (p + 1) & hmask) {
+    const uint32_t v = __hip_atomic_load(&htab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (v == 0u) return 0xFFFFFFFFu;
+    if (v != 0xFFFFFFFFu && cl[v - 1] == t) return v - 1;
+  }
+}
+
+// RmEpsilonState::expand for the listed states, one wave each; status[i]: 0 done, 1 slice too small
+__global__ void __launch_bounds__(64) rm_expand_wave(RmView v, const uint32_t* __restrict__ list, uint32_t n_list, RmBigCaps caps,
+                                                     char* __restrict__ scratch, uint32_t* __restrict__ new_cnt,
+                                                     float* __restrict__ new_fin, unsigned long long* __restrict__ new_ptr,
+                                                     const float* __restrict__ fin, uint32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n_list) return;
+  const uint32_t s = list[i];
+  char* slice = scratch + (size_t)i * rm_big_slice_bytes(caps);
+  const uint32_t H = 2u * rm_pow2_at_least(caps.C), hmask = H - 1u, HA = 2u * rm_pow2_at_least(caps.A), amask = HA - 1u;
+  uint32_t* cl = (uint32_t*)slice;          // closure states
+  uint32_t* dist = cl + caps.C;             // ordered bits of the closure distances
+  uint32_t* vis = dist + caps.C;
+  uint32_t* htab = vis + caps.C;            // state -> closure index + 1 (0 empty, ~0 being filled)
+  uint32_t* stack = htab + H;
+  uint32_t* otab = stack + caps.K;          // (ilabel, olabel, nextstate) -> arc index + 1
+  uint32_t* hdr = otab + HA;                // [0] closure size, [1] "changed" flag
+  wfst_tr* out = (wfst_tr*)(slice + rm_big_arcs_offset(caps));
+  if (lane == 0) status[i] = 1u;  // (until done)
+  for (uint32_t k = lane; k < caps.C; k += 64) {
+    dist[k] = 0xFFFFFFFFu;
+    vis[k] = 0u;
+  }
+  for (uint32_t k = lane; k < H; k += 64) htab[k] = 0u;
+  for (uint32_t k = lane; k < HA; k += 64) otab[k] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  if (lane == 0) {
+    cl[0] = s;
+    dist[0] = rm_enc(0.0f);
+    htab[rm_hash32(s) & hmask] = 1u;
+    hdr[0] = 1u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  // 1. closure and distances: label correcting over the epsilon arcs as they are now; every lane takes closure entries
+  bool overflow = false;
+  for (uint32_t iter = 0;; ++iter) {
+    const uint32_t n0 = __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    bool changed = false;
+    for (uint32_t base = 0; base < n0; base += 64) {
+      const uint32_t k = base + lane;
+      uint32_t nq = 0;
+      const wfst_tr* tq = nullptr;
+      float dk = INF;
+      if (k < n0) {
+        tq = v.trs(cl[k], &nq);
+        dk = rm_dec(__hip_atomic_load(&dist[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+      }
+      uint32_t a = 0;
+      // a lane that must insert a new closure state claims a table slot; the loop is wave-uniform so that nobody spins on
+      // a lane that cannot run
+      uint32_t pend_t = 0xFFFFFFFFu;  // target waiting for its closure index
+      float pend_w = 0.0f;
+      while (__any(a < nq || pend_t != 0xFFFFFFFFu)) {
+        if (pend_t == 0xFFFFFFFFu && a < nq) {
+          const wfst_tr tr = tq[a++];
+          if (is_eps(tr)) {
+            pend_t = tr.nextstate;
+            pend_w = tr.weight;
+          }
+        }
+        if (pend_t != 0xFFFFFFFFu) {
+          // find or insert pend_t
+          uint32_t j = 0xFFFFFFFFu;
+          for (uint32_t p = rm_hash32(pend_t) & hmask;; p = (p + 1) & hmask) {
+            uint32_t hv = __hip_atomic_load(&htab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (hv == 0u) {
+              uint32_t expect = 0u;
+              if (__hip_atomic_compare_exchange_strong(&htab[p], &expect, 0xFFFFFFFFu, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WAVEFRONT)) {
+                const uint32_t idx = __hip_atomic_fetch_add(&hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (idx >= caps.C) {
+                  overflow = true;
+                  __hip_atomic_store(&htab[p], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  j = 0xFFFFFFFEu;  // give up on this arc
+                } else {
+                  cl[idx] = pend_t;
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __hip_atomic_store(&htab[p], idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  j = idx;
+                  changed = true;
+                }
+                break;
+              }
+              hv = expect;  // somebody else took the slot: look at what is in it
+            }
+            if (hv == 0xFFFFFFFFu) break;  // being filled by another lane: retry on the next trip of the uniform loop
+            if (cl[hv - 1u] == pend_t) {
+              j = hv - 1u;
+              break;
+            }
+          }
+          if (j != 0xFFFFFFFFu) {
+            if (j != 0xFFFFFFFEu) {
+              const uint32_t cand = rm_enc(wtimes(dk, pend_w));
+              if (cand < __hip_atomic_fetch_min(&dist[j], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)) changed = true;
+            }
+            pend_t = 0xFFFFFFFFu;
+          }
+        }
+      }
+    }
+    if (__any(overflow)) return;
+    if (!__any(changed)) break;
+    if (iter > __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + 1u) break;  // negative epsilon cycle
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  // 2. the depth-first walk of the closure (sequential: it defines the arc order); a visited state's arcs 64 at a time
+  uint32_t sp = 0, na = 0;  // wave-uniform
+  if (lane == 0) stack[0] = 0u;
+  sp = 1;
+  float final_w = INF;
+  while (sp) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t k = stack[sp - 1];
+    --sp;
+    if (vis[k]) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) vis[k] = 1u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t q = cl[k];
+    const float dq = rm_dec(dist[k]);
+    uint32_t nq;
+    const wfst_tr* tq = v.trs(q, &nq);
+    for (uint32_t a0 = 0; a0 < nq; a0 += 64) {
+      const bool live = a0 + lane < nq;
+      wfst_tr tr{};
+      if (live) {
+        tr = tq[a0 + lane];
+        tr.weight = wtimes(dq, tr.weight);
+      }
+      const bool eps = live && is_eps(tr);
+      // epsilon arcs: unvisited targets go onto the stack in arc order
+      uint32_t j = 0;
+      bool push = false;
+      if (eps) {
+        j = rm_cl_find(htab, hmask, cl, tr.nextstate);  // (in the closure since step 1)
+        push = vis[j] == 0u;
+      }
+      const unsigned long long pm = __ballot(push);
+      if (pm) {
+        const uint32_t cnt = (uint32_t)__popcll(pm);
+        if (sp + cnt > caps.K) return;
+        if (push) stack[sp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = j;
+        sp += cnt;
+      }
+      // other arcs: (+)-combined at the first arc with the same (ilabel, olabel, nextstate), appended otherwise — one
+      // distinct new key per trip of the loop, in arc order (the lowest waiting lane leads)
+      bool wait = live && !eps;
+      while (const unsigned long long wm = __ballot(wait)) {
+        const int lead = __ffsll((unsigned long long)wm) - 1;
+        const uint32_t il = __shfl(tr.ilabel, lead), ol = __shfl(tr.olabel, lead), ns = __shfl(tr.nextstate, lead);
+        const bool same = wait && tr.ilabel == il && tr.olabel == ol && tr.nextstate == ns;
+        // the group's weight: min over its lanes
+        uint32_t wbits = same ? rm_enc(tr.weight) : 0xFFFFFFFFu;
+        for (int d = 32; d >= 1; d >>= 1) wbits = min(wbits, (uint32_t)__shfl_xor(wbits, d));
+        uint32_t found = 0xFFFFFFFFu;  // index of this key's arc after the leader's step
+        if ((int)lane == lead) {
+          uint32_t p = (rm_hash32(il) ^ rm_hash32(ol * 0x9E3779B9u + ns)) & amask;
+          uint32_t ov;
+          for (;; p = (p + 1) & amask) {
+            ov = otab[p];
+            if (ov == 0u) break;
+            const wfst_tr o = out[ov - 1u];
+            if (o.ilabel == il && o.olabel == ol && o.nextstate == ns) break;
+          }
+          const float w = rm_dec(wbits);
+          if (ov) {
+            if (w < out[ov - 1u].weight) out[ov - 1u].weight = w;  // plus_assign at the first occurrence
+            found = ov - 1u;
+          } else if (na < caps.A) {
+            otab[p] = na + 1u;
+            out[na] = wfst_tr{il, ol, w, ns};
+            found = na;
+          }
+        }
+        found = __shfl(found, lead);
+        if (found == 0xFFFFFFFFu) return;  // no room for the arc: redone with a larger slice
+        if (found == na) na += 1;          // (an existing arc has a smaller index)
+        wait = wait && !same;
+      }
+    }
+    const float f = wtimes(dq, fin[q]);
+    final_w = f < final_w ? f : final_w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (uint32_t a = lane; a < na / 2; a += 64) {  // trs.into_iter().rev() (rm_epsilon_static.rs:125)
+    const wfst_tr t = out[a];
+    out[a] = out[na - 1 - a];
+    out[na - 1 - a] = t;
+  }
+  if (lane == 0) {
+    new_cnt[i] = na;
+    new_fin[i] = final_w;
+    new_ptr[i] = (unsigned long long)out;
+    status[i] = 0u;
+  }
+}
+
+// finished states of an attempt: their arcs move from the scratch slices into a compact arena
+__global__ void rm_compact(const uint32_t* __restrict__ status, const uint32_t* __restrict__ new_cnt,
+                           unsigned long long* __restrict__ new_ptr, const uint32_t* __restrict__ arena_off,
+                           wfst_tr* __restrict__ arena, uint32_t n_list) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n_list || status[i]) return;
+  const wfst_tr* src = (const wfst_tr*)new_ptr[i];
+  wfst_tr* dst = arena + arena_off[i];
+  for (uint32_t k = threadIdx.x; k < new_cnt[i]; k += blockDim.x) dst[k] = src[k];
+  __syncthreads();
+  if (threadIdx.x == 0) new_ptr[i] = (unsigned long long)dst;
+}
+
 // makes the rewritten states of a finished launch visible to the next ones
 __global__ void rm_publish(const uint32_t* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ status,
                            const uint32_t* __restrict__ new_cnt, const float* __restrict__ new_fin,
@@ -195,7 +453,8 @@ __global__ void rm_write(const uint32_t* __restrict__ off, const uint32_t* __res
 
 // schedule of the rewrites: batches of mutually independent states, in an order in which every batch only depends on
 // earlier ones (see the header)
-void rm_schedule(const wfst_fst* f, const std::vector<uint8_t>& noneps_in, std::vector<std::vector<uint32_t>>& batches) {
+void rm_schedule(const wfst_fst* f, const std::vector<uint8_t>& noneps_in, std::vector<std::vector<uint32_t>>& batches,
+                 std::vector<uint32_t>& closure_hint) {
   const HostCsr& h = f->host;
   const uint32_t n = f->n_states;
   // epsilon graph
@@ -285,9 +544,15 @@ void rm_schedule(const wfst_fst* f, const std::vector<uint8_t>& noneps_in, std::
     }
   }
   for (uint32_t d = 0; d <= max_depth; ++d) {
-    if (!plain[d].empty()) batches.push_back(std::move(plain[d]));
+    if (!plain[d].empty()) {
+      batches.push_back(std::move(plain[d]));
+      closure_hint.push_back(0);
+    }
     for (int32_t c : cyc_at[d])
-      for (uint32_t s : cyc_members[c]) batches.push_back(std::vector<uint32_t>{s});
+      for (uint32_t s : cyc_members[c]) {
+        batches.push_back(std::vector<uint32_t>{s});
+        closure_hint.push_back(size[c]);  // the closure holds at least the state's own epsilon component
+      }
   }
 }
 
@@ -307,7 +572,8 @@ wfst_fst* rm_epsilon_fst(wfst_ctx* ctx, const wfst_fst* f) {
   for (const wfst_tr& tr : f->host.arcs)
     if (tr.ilabel != 0 || tr.olabel != 0) noneps_in[tr.nextstate] = 1;
   std::vector<std::vector<uint32_t>> batches;
-  rm_schedule(f, noneps_in, batches);
+  std::vector<uint32_t> closure_hint;  // per batch: a lower bound of its closures (0 = unknown, start small)
+  rm_schedule(f, noneps_in, batches, closure_hint);
 
   DBuf<uint32_t> done(*ctx->pool, n), cnt(*ctx->pool, (size_t)n + 1), off(*ctx->pool, (size_t)n + 1), facts(*ctx->pool, 1);
   DBuf<float> fin(*ctx->pool, n);
@@ -317,34 +583,69 @@ wfst_fst* rm_epsilon_fst(wfst_ctx* ctx, const wfst_fst* f) {
   HIP_CHECK(hipMemsetAsync(facts.p, 0, 4, st));
   HIP_CHECK(hipMemcpyAsync(fin.p, f->dev.finals, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   const RmView view{f->dev.offsets, f->dev.arcs, done.p, cnt.p, arc_ptr.p};
-  std::vector<std::unique_ptr<DBuf<char>>> scratches;  // the new arcs live here until rm_write has copied them
-  for (const std::vector<uint32_t>& batch : batches) {
+  // the new arcs of every finished attempt live in a compact arena until rm_write has copied them into CSR order; the
+  // scratch slices of an attempt (832 B per state at the first size, four times more per retry) are released at once
+  std::vector<std::unique_ptr<DBuf<wfst_tr>>> arenas;
+  uint64_t total_new_arcs = 0;
+  for (size_t bi = 0; bi < batches.size(); ++bi) {
+    const std::vector<uint32_t>& batch = batches[bi];
     std::vector<uint32_t> todo = batch;
     RmCaps caps{16, 32, 32};
+    RmBigCaps big{1024, 1024, 1024};
+    if (closure_hint[bi] > 64) {  // a member of a large epsilon cycle: straight to the wave kernel, sized for the component
+      caps.C = 65;
+      const uint32_t c = rm_pow2_at_least(2 * closure_hint[bi]);
+      big = RmBigCaps{std::max(1024u, c), std::max(1024u, 2 * c), std::max(1024u, 4 * c)};
+    }
     for (int attempt = 0; !todo.empty(); ++attempt) {
-      // one thread walks a closure with linear searches: fine for the handful of states closures have in practice,
-      // quadratic beyond; a closure of more than RM_MAX_CLOSURE states is refused rather than ground through
-      if (caps.C > RM_MAX_CLOSURE) throw Error("unsupported: rm_epsilon with an epsilon closure of more than 1024 states");
+      // closures of more than 64 states: one wave per state, hashed lookups (rm_expand_wave) — the one-thread kernel
+      // searches its closure linearly and would spend closure^2 dependent loads before giving up
+      const bool wave = caps.C > 64;
       const size_t m = todo.size();
-      scratches.emplace_back(new DBuf<char>(*ctx->pool, m * rm_slice_bytes(caps)));
-      DBuf<uint32_t> list(*ctx->pool, m), status(*ctx->pool, m), new_cnt(*ctx->pool, m);
+      const size_t slice = wave ? rm_big_slice_bytes(big) : rm_slice_bytes(caps);
+      if (slice * m > (64ull << 30)) throw Error("rm_epsilon: scratch for the epsilon closures exceeds 64 GiB");
+      DBuf<char> scratch(*ctx->pool, m * slice);
+      DBuf<uint32_t> list(*ctx->pool, m), status(*ctx->pool, m), new_cnt(*ctx->pool, m), arena_off(*ctx->pool, m);
       DBuf<float> new_fin(*ctx->pool, m);
       DBuf<unsigned long long> new_ptr(*ctx->pool, m);
       HIP_CHECK(hipMemcpyAsync(list.p, todo.data(), m * 4, hipMemcpyHostToDevice, st));
       const uint32_t blocks = (uint32_t)((m + 63) / 64);
-      rm_expand<<<blocks, 64, 0, st>>>(view, list.p, (uint32_t)m, caps, scratches.back()->p, new_cnt.p, new_fin.p, new_ptr.p, fin.p,
-                                       status.p);
+      if (wave)
+        rm_expand_wave<<<(uint32_t)m, 64, 0, st>>>(view, list.p, (uint32_t)m, big, scratch.p, new_cnt.p, new_fin.p, new_ptr.p, fin.p,
+                                                   status.p);
+      else
+        rm_expand<<<blocks, 64, 0, st>>>(view, list.p, (uint32_t)m, caps, scratch.p, new_cnt.p, new_fin.p, new_ptr.p, fin.p,
+                                         status.p);
+      HIP_CHECK(hipGetLastError());
+      std::vector<uint32_t> h_status(m), h_cnt(m);
+      HIP_CHECK(hipMemcpyAsync(h_status.data(), status.p, m * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(h_cnt.data(), new_cnt.p, m * 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<uint32_t> again, h_off(m, 0);
+      uint64_t arena_arcs = 0;
+      for (size_t i = 0; i < m; ++i) {
+        if (h_status[i]) {
+          again.push_back(todo[i]);
+        } else {
+          h_off[i] = (uint32_t)arena_arcs;
+          arena_arcs += h_cnt[i];
+        }
+      }
+      total_new_arcs += arena_arcs;
+      if (arena_arcs > 0xFFFFFFFFull || total_new_arcs > 0xFFFFFFFFull) throw Error("rm_epsilon: the result has more than 2^32 arcs");
+      if (arena_arcs) {
+        arenas.emplace_back(new DBuf<wfst_tr>(*ctx->pool, arena_arcs));
+        HIP_CHECK(hipMemcpyAsync(arena_off.p, h_off.data(), m * 4, hipMemcpyHostToDevice, st));
+        rm_compact<<<(uint32_t)m, 64, 0, st>>>(status.p, new_cnt.p, new_ptr.p, arena_off.p, arenas.back()->p, (uint32_t)m);
+      }
       rm_publish<<<blocks, 64, 0, st>>>(list.p, (uint32_t)m, status.p, new_cnt.p, new_fin.p, new_ptr.p, done.p, cnt.p, fin.p,
                                         arc_ptr.p);
       HIP_CHECK(hipGetLastError());
-      std::vector<uint32_t> h_status(m);
-      HIP_CHECK(hipMemcpyAsync(h_status.data(), status.p, m * 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      std::vector<uint32_t> again;
-      for (size_t i = 0; i < m; ++i)
-        if (h_status[i]) again.push_back(todo[i]);
+      HIP_CHECK(hipStreamSynchronize(st));  // the scratch and the per-attempt lists are released here
       todo.swap(again);
-      caps = RmCaps{caps.C * 4, caps.K * 4, caps.A * 4};
+      if (wave) big = RmBigCaps{big.C * 4, big.K * 4, big.A * 4};
+      else caps = RmCaps{caps.C * 4, caps.K * 4, caps.A * 4};
+      if (attempt > 24) throw Error("rm_epsilon: scratch overflow after retries");
     }
   }
   // states that were not rewritten lose their arcs (rm_epsilon_static.rs:137-143): cnt is 0 for them already.

@@ -834,6 +834,13 @@ def test_loader_rejects_damaged_files(gpu_ctx, oracle):
         wrong_type = data.replace(b"standard", b"log\x00\x00\x00\x00\x00", 1)
         with pytest.raises(rustfst_amd.WfstError):
             rustfst_amd.DeviceFst.from_bytes(wrong_type)
+    # a 100-byte file whose header claims 2^31 - 2 states must be refused from the header alone (no 16-GB reservation)
+    for name in ("fst_014_hcl.fst", "fst_014_g.fst"):
+        data = bytearray(open(os.path.join(GOLDEN, name), "rb").read()[:100])
+        hdr = data.find(b"standard") + 8 + 4 + 4 + 8 + 8  # after arc type: version, flags, properties, start -> num_states
+        data[hdr:hdr + 8] = (2 ** 31 - 2).to_bytes(8, "little")
+        with pytest.raises(rustfst_amd.WfstError, match="num_states exceeds"):
+            rustfst_amd.DeviceFst.from_bytes(bytes(data))
     # a const file whose state records point outside the arc array
     data = bytearray(open(os.path.join(GOLDEN, "fst_014_hcl.fst"), "rb").read())
     states_at = 80  # 65 header bytes, aligned to 16 (version 1)
@@ -1380,10 +1387,48 @@ def test_rm_epsilon_known_answer_and_oracle(gpu_ctx, oracle):
     ref = to_oracle(oracle, big)
     ref.rm_epsilon()
     assert_flat_identical(to_device(big).rm_epsilon().to_flat(), ref.to_flat(), "rm_epsilon on 3000 states")
-    # one epsilon component of thousands of states: refused (a thread per state walks its closure with linear searches)
-    dense = synth.make_transducer(3000, 4, 3, 0.6, seed=12, p_final=0.02)
+    # one epsilon component of a few hundred states (every rewrite walks a closure of that size: the one-wave-per-state
+    # kernel with hashed lookups; rewrites inside an epsilon cycle are sequential, in the reference's order)
+    dense = synth.make_transducer(400, 4, 3, 0.6, seed=12, p_final=0.02)
     arcs = dense["arcs"].copy()
     arcs["olabel"] = np.where(arcs["ilabel"] == 0, 0, arcs["olabel"])
     dense = dict(dense); dense["arcs"] = arcs; dense["props"] = 0
-    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
-        to_device(dense).rm_epsilon()
+    ref = to_oracle(oracle, dense)
+    ref.rm_epsilon()
+    assert_flat_identical(to_device(dense).rm_epsilon().to_flat(), ref.to_flat(), "rm_epsilon, one large epsilon component")
+
+
+def test_rm_epsilon_closure_of_100k_states(gpu_ctx, oracle):
+    """An epsilon closure of 131 071 states: a binary tree of epsilon:epsilon arcs under the start state whose inner nodes
+    have no other incoming arc (so they are never rewritten themselves), 65 536 leaves with one labelled arc each to a
+    final sink.  The start state's rewrite walks the whole tree depth first; its 65 536 new arcs, their order, the combined
+    weights and the final weight are the oracle's (the scratch slice is regrown until closure, stack and arcs fit)."""
+    depth = 16
+    n_tree = 2 ** (depth + 1) - 1
+    first_leaf = 2 ** depth - 1
+    sink = n_tree
+    n = n_tree + 1
+    rng = np.random.default_rng(99)
+    deg = np.zeros(n, dtype=np.uint32)
+    deg[:first_leaf] = 2
+    deg[first_leaf:n_tree] = 1
+    offsets = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint32)
+    arcs = np.zeros(int(offsets[-1]), dtype=rustfst_amd.TR_DTYPE)
+    inner = np.arange(first_leaf)
+    arcs["nextstate"][offsets[inner]] = 2 * inner + 1
+    arcs["nextstate"][offsets[inner] + 1] = 2 * inner + 2
+    leaves = np.arange(first_leaf, n_tree)
+    arcs["ilabel"][offsets[leaves]] = 1 + (leaves - first_leaf) % 50000  # some labels repeat: those arcs are (+)-combined
+    arcs["olabel"][offsets[leaves]] = arcs["ilabel"][offsets[leaves]]
+    arcs["nextstate"][offsets[leaves]] = sink
+    arcs["weight"] = (rng.integers(0, 2048, len(arcs)) / 512.0).astype(np.float32)
+    finals = np.full(n, np.inf, dtype=np.float32)
+    finals[sink] = 0.5
+    finals[first_leaf + 7] = 1.25  # a final state inside the closure
+    flat = dict(n_states=n, start=0, offsets=offsets, arcs=arcs, finals=finals, props=0)
+    ref = to_oracle(oracle, flat)
+    ref.rm_epsilon()
+    want = ref.to_flat()
+    got = to_device(flat).rm_epsilon().to_flat()
+    assert want["n_states"] == 2 and len(want["arcs"]) == 50000  # start + sink survive connect
+    assert_flat_identical(got, want, "rm_epsilon with a 131k-state closure")
