@@ -130,16 +130,24 @@ __global__ void coaccess_init(const float* __restrict__ fin, uint32_t* __restric
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < n) co[s] = fin[s] != INF ? 1u : 0u;
 }
+// One backward sweep.  A thread walks SWEEP_RUN consecutive states in DESCENDING order and marks made in this very sweep
+// count at once, so a chain numbered in path order (linear acceptors, lattices, reversed paths: the common deep inputs)
+// advances SWEEP_RUN states per sweep and thread instead of one; the host looks at the result every SWEEP_BATCH sweeps.
+constexpr uint32_t SWEEP_RUN = 16, SWEEP_BATCH = 4;
 __global__ void coaccess_sweep(const uint32_t* __restrict__ off, const wfst_tr* __restrict__ arcs, uint32_t* __restrict__ co,
                                uint32_t n, uint32_t* __restrict__ changed) {
   bool any = false;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-    if (ld_l2(&co[s])) continue;
-    for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
-      if (ld_l2(&co[arcs[k].nextstate])) {  // (marks of this very sweep count too: fewer sweeps)
-        st_l2(&co[s], 1u);
-        any = true;
-        break;
+  const uint32_t n_runs = (n + SWEEP_RUN - 1) / SWEEP_RUN;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += gridDim.x * blockDim.x) {
+    const uint32_t lo = r * SWEEP_RUN, hi = min(n, lo + SWEEP_RUN);
+    for (uint32_t s = hi; s-- > lo;) {
+      if (ld_l2(&co[s])) continue;
+      for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
+        if (ld_l2(&co[arcs[k].nextstate])) {
+          st_l2(&co[s], 1u);
+          any = true;
+          break;
+        }
       }
     }
   }
@@ -175,14 +183,18 @@ __global__ void compact_states(const uint32_t* __restrict__ off, const wfst_tr* 
 __global__ void access_sweep(const uint32_t* __restrict__ off, const wfst_tr* __restrict__ arcs, uint32_t* __restrict__ acc,
                              uint32_t* __restrict__ expanded, uint32_t n, uint32_t* __restrict__ changed) {
   bool any = false;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-    if (!ld_l2(&acc[s]) || expanded[s]) continue;
-    expanded[s] = 1u;
-    for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
-      const uint32_t t = arcs[k].nextstate;
-      if (!ld_l2(&acc[t])) {
-        st_l2(&acc[t], 1u);
-        any = true;
+  const uint32_t n_runs = (n + SWEEP_RUN - 1) / SWEEP_RUN;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += gridDim.x * blockDim.x) {
+    const uint32_t lo = r * SWEEP_RUN, hi = min(n, lo + SWEEP_RUN);
+    for (uint32_t s = lo; s < hi; ++s) {  // ascending: a forward chain advances SWEEP_RUN states per sweep
+      if (!ld_l2(&acc[s]) || expanded[s]) continue;
+      expanded[s] = 1u;
+      for (uint32_t k = off[s]; k < off[s + 1]; ++k) {
+        const uint32_t t = arcs[k].nextstate;
+        if (!ld_l2(&acc[t])) {
+          st_l2(&acc[t], 1u);
+          any = true;
+        }
       }
     }
   }
@@ -209,12 +221,14 @@ wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint
   DBuf<uint32_t> co(*ctx->pool, (size_t)n + 1), new_id(*ctx->pool, (size_t)n + 1), cnt(*ctx->pool, (size_t)n + 1),
       t_off(*ctx->pool, (size_t)n + 1), changed(*ctx->pool, 1);
   const uint32_t blocks = (n + 255) / 256;
-  const uint32_t sweep_blocks = std::min<uint32_t>(blocks, (uint32_t)ctx->n_cus * 16);
+  const uint32_t sweep_blocks = std::max(1u, std::min<uint32_t>((n / SWEEP_RUN + 255) / 256, (uint32_t)ctx->n_cus * 16));
   uint32_t* h = (uint32_t*)ctx->pinned.get(4 * sizeof(uint32_t));
   coaccess_init<<<blocks, 256, 0, st>>>(fin, co.p, n);
-  for (;;) {  // backward reachability to a fixed point: as many sweeps as the longest way to a final state at worst
-    HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
-    coaccess_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, co.p, n, changed.p);
+  for (;;) {  // backward reachability to a fixed point: SWEEP_BATCH sweeps per look at the flag of the LAST one
+    for (uint32_t k = 0; k < SWEEP_BATCH; ++k) {
+      HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
+      coaccess_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, co.p, n, changed.p);
+    }
     HIP_CHECK(hipMemcpyAsync(h, changed.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (!h[0]) break;
@@ -226,8 +240,10 @@ wfst_fst* connect_and_adopt(wfst_ctx* ctx, uint32_t n, int64_t start, const uint
     const uint32_t one = 1;
     HIP_CHECK(hipMemcpyAsync(acc.p + start, &one, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     for (;;) {
-      HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
-      access_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, acc.p, expanded.p, n, changed.p);
+      for (uint32_t k = 0; k < SWEEP_BATCH; ++k) {
+        HIP_CHECK(hipMemsetAsync(changed.p, 0, sizeof(uint32_t), st));
+        access_sweep<<<sweep_blocks, 256, 0, st>>>(off, arcs, acc.p, expanded.p, n, changed.p);
+      }
       HIP_CHECK(hipMemcpyAsync(h, changed.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       if (!h[0]) break;

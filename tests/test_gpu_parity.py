@@ -1361,6 +1361,41 @@ def test_connect_known_answer_and_oracle(gpu_ctx, oracle):
     assert_flat_identical(to_device(deep).connect().to_flat(), ref.to_flat(), "connect on a ring")
 
 
+def test_connect_on_a_deep_chain(gpu_ctx, oracle):
+    """connect on a chain of 200 000 states (a long linear acceptor with dead-end side branches, numbered in path order and,
+    a second time, in REVERSE path order): the reachability sweeps walk runs of consecutive states in path order, so the
+    fixed point needs diameter / 16 sweeps at worst, not one per state.  Result identical to the oracle's."""
+    import time
+    n = 200_000
+    for reverse_ids in (False, True):
+        ids = np.arange(n, dtype=np.uint32)[::-1] if reverse_ids else np.arange(n, dtype=np.uint32)
+        # state k of the path: one arc to state k + 1; every 10th also has an arc to a dead end (state n + k // 10)
+        n_dead = n // 10
+        src, dst = [], []
+        src.append(ids[:-1]); dst.append(ids[1:])
+        dead_from = ids[:n - 1:10][:n_dead]
+        src.append(dead_from); dst.append(np.arange(n, n + len(dead_from), dtype=np.uint32))
+        src, dst = np.concatenate(src), np.concatenate(dst)
+        total = n + n_dead
+        order = np.argsort(src, kind="stable")
+        src, dst = src[order], dst[order]
+        arcs = np.zeros(len(src), dtype=rustfst_amd.TR_DTYPE)
+        arcs["ilabel"] = arcs["olabel"] = 1 + (np.arange(len(src)) % 7)
+        arcs["weight"] = 0.5
+        arcs["nextstate"] = dst
+        offsets = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=total))]).astype(np.uint32)
+        finals = np.full(total, np.inf, dtype=np.float32)
+        finals[ids[-1]] = 1.0
+        flat = dict(n_states=total, start=int(ids[0]), offsets=offsets, arcs=arcs, finals=finals, props=0)
+        ref = to_oracle(oracle, flat)
+        ref.connect()
+        t0 = time.perf_counter()
+        got = to_device(flat).connect().to_flat()
+        assert time.perf_counter() - t0 < 20.0
+        assert got["n_states"] == n
+        assert_flat_identical(got, ref.to_flat(), f"connect on a chain, reverse_ids={reverse_ids}")
+
+
 def test_rm_epsilon_known_answer_and_oracle(gpu_ctx, oracle):
     """wfst_rm_epsilon: the reference's test_rm_epsilon.py:4-54 vector, then epsilon-rich random FSTs (acyclic and cyclic
     epsilon structure, epsilon self-loops, states that are rewritten and states that only lose their arcs, weights on the
