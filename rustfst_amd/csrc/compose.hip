@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
 // host re-runs that problem on compose_wave_kernel.  Results are bit-identical to the general kernel's by construction and
 // by test (tests/test_gpu_parity.py: both kernels against the oracle).
 constexpr uint64_t WIDE_COMPOSE_STATES = 16384;  // compose(): results beyond this go to compose_wide.hip
-constexpr uint32_t WIDE_COMPOSE_WIDTH = 256;     // ... and so do results with a BFS level wider than this
+constexpr uint32_t WIDE_COMPOSE_WIDTH = 64;      // ... and so do results with a BFS level wider than this (one wave's worth)
 constexpr uint32_t STR_MAXS = 2048;
 constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
 

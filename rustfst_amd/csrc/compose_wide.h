@@ -105,7 +105,8 @@ constexpr uint32_t CUR_STRIDE = 32;  // 300 k states of one level on ONE cursor 
 struct WideCtl {
   uint32_t status;
   uint32_t pad[31];
-  uint32_t cursor[CUR_SHARDS * CUR_STRIDE];  // shard j reserves inside [j * A / CUR_SHARDS, (j + 1) * A / CUR_SHARDS)
+  uint32_t cursor[CUR_SHARDS * CUR_STRIDE];  // shard j reserves inside [its start, limit[j]): a slice of the arc arena
+  uint32_t limit[CUR_SHARDS];
 };
 
 __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t hi0, WideCtl* ctl) {
@@ -124,7 +125,41 @@ __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t h
     ar.t_hi[0] = hi0;
     ctl->status = LA_OK;
   }
-  if (i < CUR_SHARDS) ctl->cursor[i * CUR_STRIDE] = i * (caps.A / CUR_SHARDS);
+  if (i < CUR_SHARDS) {
+    ctl->cursor[i * CUR_STRIDE] = i * (caps.A / CUR_SHARDS);
+    ctl->limit[i] = (i + 1) * (caps.A / CUR_SHARDS);
+  }
+}
+
+// after the arena has grown: an empty table gets the tuples numbered so far back (ids [0, n)), the reservation cursors
+// move to the new part [a_old, a_new) of the arc arena
+__global__ void la_wide_regrow(WideArena ar, LaCaps caps, uint32_t n, uint32_t a_old, WideCtl* ctl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t hmask = caps.H - 1;
+  for (uint32_t id = i; id < n; id += gridDim.x * blockDim.x) {
+    const uint64_t lo = ar.t_lo[id], hi = ar.t_hi[id];
+    for (uint32_t slot = hash_128(lo, hi) & hmask;; slot = (slot + 1) & hmask) {  // distinct keys: first empty slot wins
+      if (atomicCAS((unsigned long long*)&ar.klo[slot], (unsigned long long)K_EMPTY, (unsigned long long)lo) == K_EMPTY) {
+        ar.khi[slot] = hi;
+        ar.hid[slot] = id;
+        break;
+      }
+    }
+  }
+  if (i == 0) ctl->status = LA_OK;
+  if (i < CUR_SHARDS) {
+    const uint32_t per = (caps.A - a_old) / CUR_SHARDS;
+    ctl->cursor[i * CUR_STRIDE] = a_old + i * per;
+    ctl->limit[i] = a_old + (i + 1) * per;
+  }
+}
+__global__ void la_wide_clear_table(WideArena ar, LaCaps caps) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < caps.H; k += gridDim.x * blockDim.x) {
+    ar.klo[k] = K_EMPTY;
+    ar.khi[k] = KHI_UNSET;
+    ar.hord[k] = ~0ull;
+    ar.hid[k] = ID_UNSET;
+  }
 }
 
 // compute_trs of every state of the level [lo, hi): arcs into a reserved segment, destinations into the table.
@@ -162,7 +197,7 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
       ar.fin[q] = x.final_weight;
     }
     seg = __shfl(seg, 0);
-    const bool fits = (uint64_t)seg + seg_total <= (uint64_t)(shard + 1) * (caps.A / CUR_SHARDS);
+    const bool fits = (uint64_t)seg + seg_total <= (uint64_t)ctl->limit[shard];
     if (lane == 0) {
       ar.seg_cnt[q] = fits ? seg_total : 0u;
       if (!fits) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_ARCS);
@@ -317,92 +352,121 @@ struct WideOutput {
   const float* fin = nullptr;
 };
 
-// runs the level loop for policy `pol` from the start tuple (lo0, hi0); grows the arena (x4) until the result fits
+// runs the level loop for policy `pol` from the start tuple (lo0, hi0).  When a level does not fit (states, arcs or a
+// table filling up) the arena GROWS (x4, x2 beyond a million states) and the search goes on from that level: the numbered tuples, their
+// segments and final weights are copied, the table is rebuilt from the ids, the level is emitted again — nothing that
+// was finished is redone (restarting from scratch cost up to one full composition per overflow).
+struct WideBuffers {
+  DBuf<char> arena;
+  WideArena ar{};
+  uint32_t* d_off = nullptr;
+  wfst_tr* d_out = nullptr;
+  LaCaps caps{};
+};
+inline void wide_alloc(wfst_ctx* ctx, uint64_t est_s, uint64_t est_a, WideBuffers& w) {
+  if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose: composition too large");
+  const LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, wide_next_pow2(2 * est_s + 128)};
+  size_t bytes = 0;
+  auto take = [&](size_t n) {
+    const size_t o = bytes;
+    bytes += wide_al16(n);
+    return o;
+  };
+  const size_t o_tlo = take((size_t)caps.S * 8), o_thi = take((size_t)caps.S * 8), o_klo = take((size_t)caps.H * 8),
+               o_khi = take((size_t)caps.H * 8), o_hord = take((size_t)caps.H * 8), o_hid = take((size_t)caps.H * 4),
+               o_arcs = take((size_t)caps.A * 16), o_alo = take((size_t)caps.A * 8), o_ahi = take((size_t)caps.A * 8),
+               o_sb = take((size_t)caps.S * 4), o_sc = take(((size_t)caps.S + 1) * 4), o_nf = take(((size_t)caps.S + 1) * 4),
+               o_fb = take(((size_t)caps.S + 1) * 4), o_fin = take((size_t)caps.S * 4), o_off = take(((size_t)caps.S + 1) * 4),
+               o_out = take((size_t)caps.A * 16);
+  w.arena = DBuf<char>(*ctx->pool, bytes);
+  char* b = w.arena.p;
+  w.ar = WideArena{(uint64_t*)(b + o_tlo), (uint64_t*)(b + o_thi), (uint64_t*)(b + o_klo),  (uint64_t*)(b + o_khi),
+                   (uint64_t*)(b + o_hord), (uint32_t*)(b + o_hid), (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo),
+                   (uint64_t*)(b + o_ahi), (uint32_t*)(b + o_sb),  (uint32_t*)(b + o_sc),  (uint32_t*)(b + o_nf),
+                   (uint32_t*)(b + o_fb),  (float*)(b + o_fin)};
+  w.d_off = (uint32_t*)(b + o_off);
+  w.d_out = (wfst_tr*)(b + o_out);
+  w.caps = caps;
+}
+
 template <class P>
 void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, WideOutput& out) {
   hipStream_t st = ctx->stream;
   if (const char* e = std::getenv("WFST_WIDE_EST_STATES")) {  // tests: start from a tiny arena so that it has to grow
     est_s = std::max<uint64_t>(64, (uint64_t)std::atoll(e));
     est_a = 4 * est_s;
+  } else {
+    // whoever calls the wide driver has already seen the result outgrow one wave: room for a quarter of a million states
+    // to begin with (clearing that table takes ~20 us)
+    est_s = std::max<uint64_t>(est_s, 1ull << 18);
+    est_a = std::max<uint64_t>(est_a, 4 * est_s);
   }
-  for (int attempt = 0;; ++attempt) {
-    if (est_s > 0x7FFFFFF0ull || est_a > 0x7FFFFFF0ull) throw Error("compose: composition too large");
-    const LaCaps caps{(uint32_t)est_s, (uint32_t)est_a, wide_next_pow2(2 * est_s + 128)};
-    size_t bytes = 0;
-    auto take = [&](size_t n) {
-      const size_t o = bytes;
-      bytes += wide_al16(n);
-      return o;
-    };
-    const size_t o_tlo = take((size_t)caps.S * 8), o_thi = take((size_t)caps.S * 8), o_klo = take((size_t)caps.H * 8),
-                 o_khi = take((size_t)caps.H * 8), o_hord = take((size_t)caps.H * 8), o_hid = take((size_t)caps.H * 4),
-                 o_arcs = take((size_t)caps.A * 16), o_alo = take((size_t)caps.A * 8), o_ahi = take((size_t)caps.A * 8),
-                 o_sb = take((size_t)caps.S * 4), o_sc = take(((size_t)caps.S + 1) * 4), o_nf = take(((size_t)caps.S + 1) * 4),
-                 o_fb = take(((size_t)caps.S + 1) * 4), o_fin = take((size_t)caps.S * 4), o_off = take(((size_t)caps.S + 1) * 4),
-                 o_out = take((size_t)caps.A * 16);
-    DBuf<char> arena(*ctx->pool, bytes);
-    DBuf<WideCtl> d_ctl(*ctx->pool, 1);
-    char* b = arena.p;
-    const WideArena ar{(uint64_t*)(b + o_tlo), (uint64_t*)(b + o_thi), (uint64_t*)(b + o_klo),  (uint64_t*)(b + o_khi),
-                       (uint64_t*)(b + o_hord), (uint32_t*)(b + o_hid), (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo),
-                       (uint64_t*)(b + o_ahi), (uint32_t*)(b + o_sb),  (uint32_t*)(b + o_sc),  (uint32_t*)(b + o_nf),
-                       (uint32_t*)(b + o_fb),  (float*)(b + o_fin)};
-    uint32_t* d_off = (uint32_t*)(b + o_off);
-    wfst_tr* d_out = (wfst_tr*)(b + o_out);
-    size_t temp_bytes = 0;
-    HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)caps.S + 1, rocprim::plus<uint32_t>(), st));
-    DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
-    struct HostCtl {
-      uint32_t status, n_new, n_arcs;
-    };
-    HostCtl* hc = (HostCtl*)ctx->pinned.get(sizeof(HostCtl));
-    const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
-    la_wide_init<<<std::min<uint32_t>(max_blocks, (caps.H + 255) / 256), 256, 0, st>>>(ar, caps, lo0, hi0, d_ctl.p);
-    uint32_t lo = 0, hi = 1, levels = 0;
-    bool overflow = false;
-    while (lo < hi) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
-      const uint32_t n_level = hi - lo;
-      const uint32_t blocks = std::min<uint32_t>(max_blocks, (n_level + 3) / 4);
-      la_emit<P><<<blocks, 256, 0, st>>>(pol, caps, ar, lo, hi, d_ctl.p);
-      la_first<<<blocks, 256, 0, st>>>(ar, lo, hi, d_ctl.p);
-      HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.nfirst, ar.fbase, 0u, (size_t)n_level + 1, rocprim::plus<uint32_t>(), st));
-      HIP_CHECK(hipMemcpyAsync(&hc->status, &d_ctl.p->status, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(&hc->n_new, ar.fbase + n_level, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      levels++;
-      if (hc->status != LA_OK || (uint64_t)hi + hc->n_new > caps.S) {
-        overflow = true;
-        break;
-      }
-      la_assign<<<blocks, 256, 0, st>>>(ar, lo, hi, hi);
-      la_patch<<<blocks, 256, 0, st>>>(ar, lo, hi);
-      lo = hi;
-      hi += hc->n_new;
-    }
-    HIP_CHECK(hipGetLastError());
-    if (!overflow) {
-      const uint32_t n_states = hi;
-      HIP_CHECK(hipMemsetAsync(ar.seg_cnt + n_states, 0, sizeof(uint32_t), st));
-      HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, ar.seg_cnt, d_off, 0u, (size_t)n_states + 1, rocprim::plus<uint32_t>(), st));
-      la_gather<<<std::min<uint32_t>(max_blocks, (n_states + 3) / 4), 256, 0, st>>>(ar, d_off, d_out, n_states);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpyAsync(&hc->n_arcs, d_off + n_states, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      out.n_states = n_states;
-      out.n_arcs = hc->n_arcs;
-      out.n_levels = levels;
-      out.off = d_off;
-      out.arcs = d_out;
-      out.fin = ar.fin;
-      out.arena = std::move(arena);
-      return;
-    }
+  WideBuffers w;
+  wide_alloc(ctx, est_s, est_a, w);
+  DBuf<WideCtl> d_ctl(*ctx->pool, 1);
+  size_t temp_bytes = 0;
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, w.ar.nfirst, w.ar.fbase, 0u, (size_t)0x7FFFFFF0u, rocprim::plus<uint32_t>(), st));
+  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+  struct HostCtl {
+    uint32_t status, n_new, n_arcs;
+  };
+  HostCtl* hc = (HostCtl*)ctx->pinned.get(sizeof(HostCtl));
+  const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
+  la_wide_init<<<std::min<uint32_t>(max_blocks, (w.caps.H + 255) / 256), 256, 0, st>>>(w.ar, w.caps, lo0, hi0, d_ctl.p);
+  uint32_t lo = 0, hi = 1, levels = 0;
+  int grows = 0;
+  while (lo < hi) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
+    const uint32_t n_level = hi - lo;
+    const uint32_t blocks = std::min<uint32_t>(max_blocks, (n_level + 3) / 4);
+    la_emit<P><<<blocks, 256, 0, st>>>(pol, w.caps, w.ar, lo, hi, d_ctl.p);
+    la_first<<<blocks, 256, 0, st>>>(w.ar, lo, hi, d_ctl.p);
+    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, w.ar.nfirst, w.ar.fbase, 0u, (size_t)n_level + 1, rocprim::plus<uint32_t>(), st));
+    HIP_CHECK(hipMemcpyAsync(&hc->status, &d_ctl.p->status, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&hc->n_new, w.ar.fbase + n_level, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    ctx->stats.compose_retries++;
-    if (attempt > 24) throw Error("compose: arena overflow after retries");
-    est_s *= 4;
-    est_a *= 4;
+    if (hc->status != LA_OK || (uint64_t)hi + hc->n_new > w.caps.S) {
+      // the level does not fit: four times the room, everything numbered so far moves over, the level is emitted again
+      ctx->stats.compose_retries++;
+      if (++grows > 24) throw Error("compose: arena overflow after retries");
+      WideBuffers nw;
+      // (growing is cheap now, an over-sized table is not: its random accesses leave the caches — x2 once it is large)
+      const uint64_t g = w.caps.S >= (1u << 20) ? 2 : 4;
+      wide_alloc(ctx, g * w.caps.S, g * w.caps.A, nw);
+      auto copy = [&](void* d, const void* s_, size_t n) { HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st)); };
+      copy(nw.ar.t_lo, w.ar.t_lo, (size_t)hi * 8);
+      copy(nw.ar.t_hi, w.ar.t_hi, (size_t)hi * 8);
+      copy(nw.ar.seg_base, w.ar.seg_base, (size_t)lo * 4);
+      copy(nw.ar.seg_cnt, w.ar.seg_cnt, (size_t)lo * 4);
+      copy(nw.ar.fin, w.ar.fin, (size_t)lo * 4);
+      copy(nw.ar.arcs, w.ar.arcs, (size_t)w.caps.A * 16);  // (finished segments keep their positions; their tuple words
+      la_wide_clear_table<<<std::min<uint32_t>(max_blocks, (nw.caps.H + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps);  //  are dead)
+      la_wide_regrow<<<std::min<uint32_t>(max_blocks, (hi + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps, hi, w.caps.A, d_ctl.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(st));  // the old arena goes back to the pool
+      w = std::move(nw);
+      continue;  // the same level again
+    }
+    levels++;
+    la_assign<<<blocks, 256, 0, st>>>(w.ar, lo, hi, hi);
+    la_patch<<<blocks, 256, 0, st>>>(w.ar, lo, hi);
+    lo = hi;
+    hi += hc->n_new;
   }
+  HIP_CHECK(hipGetLastError());
+  const uint32_t n_states = hi;
+  HIP_CHECK(hipMemsetAsync(w.ar.seg_cnt + n_states, 0, sizeof(uint32_t), st));
+  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, w.ar.seg_cnt, w.d_off, 0u, (size_t)n_states + 1, rocprim::plus<uint32_t>(), st));
+  la_gather<<<std::min<uint32_t>(max_blocks, (n_states + 3) / 4), 256, 0, st>>>(w.ar, w.d_off, w.d_out, n_states);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(&hc->n_arcs, w.d_off + n_states, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  out.n_states = n_states;
+  out.n_arcs = hc->n_arcs;
+  out.n_levels = levels;
+  out.off = w.d_off;
+  out.arcs = w.d_out;
+  out.fin = w.ar.fin;
+  out.arena = std::move(w.arena);
 }
 
 }  // namespace

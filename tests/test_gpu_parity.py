@@ -152,16 +152,21 @@ def test_compose_acceptor_with_synthetic_transducer(gpu_ctx, oracle):
             assert exp["n_states"] > 40
 
 
-def test_compose_wide_lattice_grows_arena(gpu_ctx, oracle):
-    """Sigma=4 makes the BFS frontier grow every level: exercises arena overflow + retry."""
+def test_compose_wide_lattice_grows_arena(gpu_ctx, oracle, monkeypatch):
+    """Sigma=4 makes the BFS frontier grow every level: on the wave-per-problem kernel (pinned) that exercises arena
+    overflow + retry; by default the pair is handed to the wide driver as soon as a level is wider than one wave."""
     t = synth.make_transducer(400, 8, 4, 0.0, seed=33)
     a = synth.make_acceptors(t, 1, 30, seed0=9)[0]
     raw = to_oracle(oracle, a).compose(to_oracle(oracle, t), connect=False).to_flat()
     assert raw["n_states"] > 3000
+    monkeypatch.setenv("WFST_COMPOSE_PATH", "wave")
     before = gpu_ctx.stats()["compose_retries"]
     got = to_device(a).compose(to_device(t), ComposeConfig(connect=False)).to_flat()
-    assert_flat_identical(got, raw, "wide lattice, untrimmed")
+    assert_flat_identical(got, raw, "wide lattice, untrimmed, wave kernel")
     assert gpu_ctx.stats()["compose_retries"] > before
+    monkeypatch.delenv("WFST_COMPOSE_PATH")
+    got = to_device(a).compose(to_device(t), ComposeConfig(connect=False)).to_flat()
+    assert_flat_identical(got, raw, "wide lattice, untrimmed")
     exp = to_oracle(oracle, a).compose(to_oracle(oracle, t)).to_flat()
     got = to_device(a).compose(to_device(t)).to_flat()
     assert_flat_identical(got, exp, "wide lattice, trimmed")

@@ -40,6 +40,7 @@ for n1, n2, fan1, fan2, sigma in cases:
     out = la.compose(d2)
     torch.cuda.synchronize(); t4 = time.perf_counter()
     st = ctx.stats()
+    plain = da.compose(db, rustfst_amd.ComposeConfig(connect=False)); torch.cuda.synchronize()  # warm-up (pool growth)
     t5 = time.perf_counter(); plain = da.compose(db, rustfst_amd.ComposeConfig(connect=False)); torch.cuda.synchronize(); t6 = time.perf_counter()
     cpu_ms = float("nan")
     if n1 * n2 <= 3_000_000:
