@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 1
+#define WFST_ABI_VERSION 2 /* 2: wfst_stats gained relax_kernel */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
 

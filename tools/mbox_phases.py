@@ -6,8 +6,8 @@ raw = open(sys.argv[1], "rb").read()
 ns, nb = np.frombuffer(raw[:8], dtype=np.uint32)
 a = np.frombuffer(raw[8:], dtype=np.uint64).reshape(ns, nb, 16).astype(np.int64)
 TICK = 0.01  # wall_clock64: 100 MHz
-names = ["start", "trip1", "applied", "scanned", "rows", "staged", "stagedall", "expanded", "end"]
-order = [0, 1, 3, 4, 11, 12, 13, 5, 6]
+names = ["start", "trip1", "applied", "scanned", "staged", "expanded", "end"]
+order = [0, 1, 3, 4, 12, 5, 6]
 print("sweep  busy  idle |  msgs_in  active  sent | per phase: max over busy blocks (median) in us since sweep start | idle-exit max")
 for k in range(ns):
     st = a[k, :, 0]

@@ -30,15 +30,19 @@ def trace(path):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | "
               f"{a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
-    rel = [(e - s) for name, s, e in rows if "sssp_relax_kernel" in name]
-    if rel:
+    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mboxa_kernel"):
+        rel = [(e - s) for name, s, e in rows if kname + "(" in name]
+        if not rel:
+            continue
         n_solves = sum(1 for name, _, _ in rows if "sssp_final_kernel" in name) or 1
-        work = [d for d in rel if d >= 3000]  # launches after convergence inside a batch are ~1.5-3 us no-ops
+        work = [d for d in rel if d >= 5500]  # launches after convergence inside a batch only find an empty frontier
+        per_solve = sum(rel) / n_solves / 1e3
         print()
-        print(f"sssp_relax_kernel: {len(rel)} launches in {n_solves} solves ({len(rel) / n_solves:.1f} per solve); "
+        print(f"{kname}: {len(rel)} launches in {n_solves} solves ({len(rel) / n_solves:.1f} per solve); "
               f"avg over all launches {sum(rel) / len(rel) / 1e3:.2f} us; "
-              f"{len(work)} launches >= 3 us avg {sum(work) / max(1, len(work)) / 1e3:.2f} us; "
-              f"kernel time per solve {sum(rel) / n_solves / 1e3:.1f} us")
+              f"{len(work)} launches >= 5.5 us avg {sum(work) / max(1, len(work)) / 1e3:.2f} us; "
+              f"kernel time per solve {per_solve:.1f} us -> 212 MB (20 E + 12 N) / that = {212e6 / per_solve / 1e3:.1f} GB/s "
+              f"= {212e6 / per_solve / 1e3 / 8000:.4f} of the 8 TB/s peak")
 
 
 def pmc(fetch_db, write_db):
