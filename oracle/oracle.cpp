@@ -35,6 +35,9 @@ constexpr float INF = std::numeric_limits<float>::infinity();
 thread_local std::string t_err;
 thread_local float t_delta = KDELTA;  // ORACLE_EQ_REF_KDELTA -> KDELTA, ORACLE_EQ_EXACT -> 0
 thread_local const char* t_queue_kind = "";
+// look-ahead composition bookkeeping for tools/lookahead_tuple_gap.py: tuples created, and how many of them had an
+// already-present tuple equal in everything but a pushed weight exactly one KDELTA step away
+thread_local uint64_t t_la_tuples = 0, t_la_adjacent = 0;
 
 struct DeltaGuard {
   float saved;
@@ -2484,6 +2487,19 @@ struct LaComposeOp {
     auto it = tuple_to_id.find(t);
     if (it != tuple_to_id.end()) return it->second;
     const uint32_t n = (uint32_t)id_to_tuple.size();
+    // the reference's PartialEq would call t equal to a tuple whose weight is one quantization step away (its Hash
+    // would not); count how often such a neighbour exists so the deviation is measured, not only described
+    ++t_la_tuples;
+    if (!std::isinf(t.fs.fweight)) {
+      for (float step : {-KDELTA, KDELTA}) {
+        Tuple5 nb = t;
+        nb.fs.fweight = t.fs.fweight + step;
+        if (tuple_to_id.count(nb)) {
+          ++t_la_adjacent;
+          break;
+        }
+      }
+    }
     id_to_tuple.push_back(t);
     tuple_to_id.emplace(t, n);
     return n;
@@ -2728,6 +2744,10 @@ extern "C" {
 
 const char* oracle_last_error(void) { return t_err.c_str(); }
 const char* oracle_last_queue_kind(void) { return t_queue_kind; }
+void oracle_last_lookahead_tuples(uint64_t* tuples, uint64_t* adjacent) {
+  *tuples = t_la_tuples;
+  *adjacent = t_la_adjacent;
+}
 
 oracle_fst* oracle_fst_new(void) { return new oracle_fst(); }
 void oracle_fst_free(oracle_fst* f) { delete f; }
@@ -2831,6 +2851,7 @@ int oracle_compose_filter(const oracle_fst* f1, const oracle_fst* f2, int connec
 int oracle_compose_lookahead(const oracle_fst* f1, const oracle_fst* f2, oracle_fst** out, oracle_fst** relabeled1,
                              oracle_fst** relabeled2) {
   DeltaGuard g(ORACLE_EQ_REF_KDELTA);
+  t_la_tuples = t_la_adjacent = 0;
   std::unique_ptr<oracle_fst> o(new oracle_fst()), r1(new oracle_fst()), r2(new oracle_fst());
   la::LabelReachableData data;
   if (!la::compose_lookahead(*f1, *f2, *o, *r1, *r2, data)) return 1;

@@ -130,6 +130,9 @@ int oracle_reverse(const oracle_fst* f, oracle_fst** out);
 /* name of the queue discipline AutoQueue picked for the last oracle_shortest_path call on
  * this thread (queues/auto_queue.rs:23-99): "state_order","top_order","lifo","top_order_scc","scc" */
 const char* oracle_last_queue_kind(void);
+/* after oracle_compose_lookahead on this thread: composed-state tuples created, and how many had a twin differing only by
+ * a pushed weight one KDELTA step away (the pairs the reference's approximate PartialEq could merge) */
+void oracle_last_lookahead_tuples(uint64_t* tuples, uint64_t* adjacent);
 
 /* CANONICAL single shortest path: the deterministic tie rule the GPU engine implements
  * (DESIGN.md §Shortest path): (d,h)[t] = lexicographic min over paths of (left-fold f32 sum,

@@ -64,6 +64,8 @@ def lib():
         L.oracle_rm_epsilon.argtypes = [vp]
         L.oracle_fst_project.argtypes = [vp, C.c_int]
         L.oracle_compose_lookahead.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.oracle_last_lookahead_tuples.argtypes = [C.POINTER(u64), C.POINTER(u64)]
+        L.oracle_last_lookahead_tuples.restype = None
         L.oracle_interval_set_normalize.argtypes = [vp, C.c_size_t, C.POINTER(u64)]
         L.oracle_interval_set_normalize.restype = i64
         L.oracle_interval_set_member.argtypes = [vp, C.c_size_t, u64]
@@ -211,6 +213,13 @@ class OracleFst:
         if want_relabeled:
             return OracleFst(out.value), OracleFst(r1.value), OracleFst(r2.value)
         return OracleFst(out.value)
+
+    @staticmethod
+    def last_lookahead_tuples():
+        """(tuples created, tuples with a twin one KDELTA weight step away) of this thread's last compose_lookahead."""
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().oracle_last_lookahead_tuples(C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def label_reachable(self, reach_input=False):
         """LabelReachable::compute_data (label_reachable.rs:135-273): dict(final_label, label2index {label: index},

@@ -525,3 +525,18 @@ def test_rm_epsilon_keeps_the_weighted_relation(oracle, seed):
                 best[(il, ol)] = min(best.get((il, ol), 1 << 60), w)
             return best
         assert best_per_string(before) == best_per_string(after)
+
+
+def test_lookahead_tuples_have_no_kdelta_neighbours():
+    """The only composed-state tuples the reference's approximate PartialEq (semiring.rs:159-168) could merge while this
+    engine keeps them apart are twins whose quantized pushed weights are one KDELTA step apart.  On grid and real-valued
+    weights of ordinary scale there are none; weights of the size of the quantum do produce them (so the counter works)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lookahead_tuple_gap as G
+    shapes = [(300, 20, 3, 8, 8), (1000, 30, 3, 10, 10)]
+    rows = {r["family"]: r for r in G.measure(shapes, [("grid", 512), ("real", 10.0), ("real", 0.01)], [1, 2])}
+    assert rows["grid 512"]["tuples"] > 1000
+    assert rows["grid 512"]["adjacent"] == 0
+    assert rows["real 10.0"]["adjacent"] == 0
+    assert rows["real 0.01"]["adjacent"] > 0
