@@ -112,7 +112,7 @@ class OracleFst:
         self._h = handle if handle is not None else lib().oracle_fst_new()
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().oracle_fst_free(self._h)
             self._h = None
 

@@ -50,6 +50,8 @@ constexpr uint32_t REJECT = 0xFFFFFFFFu;
 constexpr float KDELTA_F = 1.0f / 1024.0f;  // lib.rs:269
 constexpr uint32_t WIDE_SWITCH_STATES = 2048;  // results larger than this are redone on the wide path
 constexpr uint32_t WIDE_SWITCH_WIDTH = 256;    // ... and so are results with a BFS level wider than this
+constexpr uint32_t WIDE_SWITCH_STATES_ONE = 512;  // the same two limits for a call with ONE composition
+constexpr uint32_t WIDE_SWITCH_WIDTH_ONE = 48;
 
 
 struct LaView {
@@ -355,7 +357,8 @@ __device__ uint32_t eval_item(const Reach& reach, const LaView& f2, const Expand
 // one wave = one (fst1, fst2[p]) problem; fst1 and its reachability data are shared by the batch
 __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const LaView* __restrict__ f2s, Reach reach, LaCaps caps,
                                                                char* __restrict__ arena_base, size_t arena_stride,
-                                                               LaResult* __restrict__ results, uint32_t switch_states) {
+                                                               LaResult* __restrict__ results, uint32_t switch_states,
+                                                               uint32_t switch_width) {
   const LaView f2 = f2s[blockIdx.x];
   const LaArena ar = la_carve(arena_base + (size_t)blockIdx.x * arena_stride, caps, nullptr);
   LaResult* result = results + blockIdx.x;
@@ -480,7 +483,7 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
       n_states = hi;
       // a big composition, or a frontier too wide for one wave: thousands of waves do it faster (deep and narrow results,
       // the decoding lattices, stay here: the wide path pays five launches and a read-back per level)
-      if ((n_states > switch_states || (switch_states != 0xFFFFFFFFu && n_new > WIDE_SWITCH_WIDTH)) && lo < hi) {
+      if ((n_states > switch_states || (switch_states != 0xFFFFFFFFu && n_new > switch_width)) && lo < hi) {
         res.status = LA_SWITCH_WIDE;
         ok = false;
       }
@@ -577,8 +580,9 @@ wfst_fst* compose_lookahead_wide(wfst_ctx* ctx, const wfst_lookahead* la, const 
                                  uint64_t out_props, uint64_t est_s, uint64_t est_a) {
   const LaPolicy pol{view_of(f1), view_of(fst2), Reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label}};
   WideOutput w;
+  const double d1 = (double)f1->n_arcs / std::max<uint32_t>(f1->n_states, 1), d2 = (double)fst2->n_arcs / std::max<uint32_t>(fst2->n_states, 1);
   run_wide(ctx, pol, ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)fst2->start, pack_hi(FState{0u, 0.0f, NO_LABEL}), est_s,
-           est_a, w);
+           est_a, 1.0 + std::min(d1, d2), w);
   ctx->stats.compose_states = w.n_states;
   ctx->stats.compose_arcs = w.n_arcs;
   return adopt_device(ctx, w.n_states, w.n_arcs, 0, out_props, w.off, w.arcs, w.fin);
@@ -637,8 +641,11 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
       DBuf<LaResult> d_res(*ctx->pool, m);
       HIP_CHECK(hipMemcpyAsync(d_views.p, views.data(), m * sizeof(LaView), hipMemcpyHostToDevice, st));
       const Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
+      // a lone composition hands over early (the wide driver costs ~15 us per narrow level, this kernel ~3 us per STATE);
+      // in a batch the other waves are busy meanwhile, and the wide driver would take the problems one by one
       compose_lookahead_kernel<<<(uint32_t)m, 64, 0, st>>>(view_of(f1), d_views.p, reach, caps, arena.p, stride, d_res.p,
-                                                            force == 1 ? 0xFFFFFFFFu : WIDE_SWITCH_STATES);
+                                                            force == 1 ? 0xFFFFFFFFu : (m == 1 ? WIDE_SWITCH_STATES_ONE : WIDE_SWITCH_STATES),
+                                                            m == 1 ? WIDE_SWITCH_WIDTH_ONE : WIDE_SWITCH_WIDTH);
       HIP_CHECK(hipGetLastError());
       std::vector<LaResult> res(m);
       HIP_CHECK(hipMemcpyAsync(res.data(), d_res.p, m * sizeof(LaResult), hipMemcpyDeviceToHost, st));
@@ -676,7 +683,7 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
           const LaView v = view_of(fst2);
           HIP_CHECK(hipMemcpyAsync(d_view.p, &v, sizeof(LaView), hipMemcpyHostToDevice, st));
           const Reach reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label};
-          compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), d_view.p, reach, caps, arena.p, stride, d_res.p, 0xFFFFFFFFu);
+          compose_lookahead_kernel<<<1, 64, 0, st>>>(view_of(f1), d_view.p, reach, caps, arena.p, stride, d_res.p, 0xFFFFFFFFu, 0u);
           HIP_CHECK(hipGetLastError());
           LaResult r;
           HIP_CHECK(hipMemcpyAsync(&r, d_res.p, sizeof(r), hipMemcpyDeviceToHost, st));

@@ -16,6 +16,7 @@
 // Everything here sits in an anonymous namespace: each translation unit instantiates its own copy with its policy.
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include <rocprim/device/device_scan.hpp>
@@ -82,7 +83,7 @@ __device__ __forceinline__ ArcReg load_arc(const wfst_tr* p) {
   return ArcReg{v.x, v.y, __uint_as_float(v.z), v.w};
 }
 
-// ---------------------------------------------------------------- wide path: one wave per composed state of a level
+// ---------------------------------------------------------------- wide path: G lanes per composed state of a level
 struct WideArena {
   uint64_t* t_lo;      // [S]
   uint64_t* t_hi;      // [S]
@@ -90,24 +91,53 @@ struct WideArena {
   uint64_t* khi;       // [H] KHI_UNSET until the slot's winner has written it
   uint64_t* hord;      // [H] min over this level's emissions of (state position in the level << 32 | arc position)
   uint32_t* hid;       // [H] state id, ID_UNSET while the tuple is new
-  wfst_tr* arcs;       // [A] segments in reservation order; nextstate = table slot until la_patch
+  wfst_tr* arcs;       // [A] segments in reservation order; nextstate = table slot until la_gather / la_patch_range
   uint64_t* a_lo;      // [A]
   uint64_t* a_hi;      // [A]
   uint32_t* seg_base;  // [S] first arc of the state's segment
   uint32_t* seg_cnt;   // [S+1]
-  uint32_t* nfirst;    // [S+1] per state of the level: arcs that are the first emission of a new tuple
-  uint32_t* fbase;     // [S+1] exclusive scan of nfirst
   float* fin;          // [S]
 };
 constexpr uint32_t MAX_PROBES = 512;  // open addressing at load <= 0.5: chains of tens at most
 constexpr uint32_t CUR_SHARDS = 64;  // reservation cursors: one per 128-B line (same-address atomics serialise at ~12 ns:
 constexpr uint32_t CUR_STRIDE = 32;  // 300 k states of one level on ONE cursor were 3.6 ms, the whole la_emit of that level)
+constexpr uint32_t LVL_RING = 64;    // level ranges live on the device: the host queues several levels per look
+constexpr uint32_t WIDE_MAX_BLOCKS = 4096;
 struct WideCtl {
   uint32_t status;
-  uint32_t pad[31];
+  uint32_t k_done;  // levels finished so far; lvl[k_done % LVL_RING] is the next one (lo == hi: the search is over)
+  uint32_t slack_min, arcs_used;  // after the last finished level: least room left in a shard's slice, arcs reserved in all
+  uint32_t per;                   // size of a shard's slice of the current arena part
+  uint32_t pad[27];
+  uint32_t lvl[LVL_RING][2];                  // ids [lo, hi) of level k at k % LVL_RING, written by la_assign of level k-1
   uint32_t cursor[CUR_SHARDS * CUR_STRIDE];  // shard j reserves inside [its start, limit[j]): a slice of the arc arena
   uint32_t limit[CUR_SHARDS];
+  uint32_t bsum[WIDE_MAX_BLOCKS];  // la_first: new tuples first emitted by the states of block b's share of the level
 };
+constexpr size_t WIDE_CTL_HEAD = offsetof(WideCtl, cursor);  // what the host reads back per look
+
+template <uint32_t G>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+  for (int d = (int)G / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+template <uint32_t G>
+__device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t sub, uint32_t* total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < (int)G; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, G);
+    if (sub >= (uint32_t)d) x += y;
+  }
+  *total = __shfl(x, G - 1, G);
+  return x - v;
+}
+template <uint32_t G>
+__device__ __forceinline__ uint64_t group_mask(uint64_t ballot, uint32_t grp) {
+  if constexpr (G == 64) return ballot;
+  else return (ballot >> (grp * G)) & ((1ull << G) - 1ull);
+}
 
 __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t hi0, WideCtl* ctl) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,6 +154,12 @@ __global__ void la_wide_init(WideArena ar, LaCaps caps, uint64_t lo0, uint64_t h
     ar.t_lo[0] = lo0;
     ar.t_hi[0] = hi0;
     ctl->status = LA_OK;
+    ctl->k_done = 0;
+    ctl->lvl[0][0] = 0;
+    ctl->lvl[0][1] = 1;
+    ctl->per = caps.A / CUR_SHARDS;
+    ctl->slack_min = caps.A / CUR_SHARDS;
+    ctl->arcs_used = 0;
   }
   if (i < CUR_SHARDS) {
     ctl->cursor[i * CUR_STRIDE] = i * (caps.A / CUR_SHARDS);
@@ -146,7 +182,12 @@ __global__ void la_wide_regrow(WideArena ar, LaCaps caps, uint32_t n, uint32_t a
       }
     }
   }
-  if (i == 0) ctl->status = LA_OK;
+  if (i == 0) {
+    ctl->status = LA_OK;
+    ctl->per = (caps.A - a_old) / CUR_SHARDS;
+    ctl->slack_min = (caps.A - a_old) / CUR_SHARDS;
+    ctl->arcs_used = 0;
+  }
   if (i < CUR_SHARDS) {
     const uint32_t per = (caps.A - a_old) / CUR_SHARDS;
     ctl->cursor[i * CUR_STRIDE] = a_old + i * per;
@@ -161,58 +202,74 @@ __global__ void la_wide_clear_table(WideArena ar, LaCaps caps) {
     ar.hid[k] = ID_UNSET;
   }
 }
+// table slot -> state id in the arcs of the finished states [q_lo, q_hi), before the table they point into is dropped
+__global__ void __launch_bounds__(256) la_patch_range(WideArena ar, uint32_t q_lo, uint32_t q_hi) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sub = t & 7u;
+  for (uint32_t q = q_lo + (t >> 3); q < q_hi; q += (gridDim.x * blockDim.x) >> 3) {
+    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
+    for (uint32_t k = sub; k < n; k += 8) ar.arcs[seg + k].nextstate = ar.hid[ar.arcs[seg + k].nextstate];
+  }
+}
 
-// compute_trs of every state of the level [lo, hi): arcs into a reserved segment, destinations into the table.
+// compute_trs of every state of level `level` (ids [lo, hi) from the control block): arcs into a reserved segment,
+// destinations into the table.  G lanes share a composed state (64 / G states per wave: a state of the recipes this serves
+// has a handful of arcs on its iterated side, and a lone wave per state left most lanes — and most of the memory-level
+// parallelism — idle); loops run to the longest trip count among the wave's groups so that shuffles stay wave-uniform.
 // Policy P supplies the composition itself: P::Expand, make_expand(tuple words) and eval_item(expand, item, write, position,
 // arrays, first emitted) -> number of arcs the item emits (see compose_lookahead.hip / compose_wide.hip).
-template <class P>
-__global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar, uint32_t lo, uint32_t hi, WideCtl* ctl) {
-  const uint32_t lane = lane_id();
+template <class P, uint32_t G>
+__global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar, uint32_t level, WideCtl* ctl) {
+  constexpr uint32_t SPW = 64 / G;
+  const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
+  if (lo >= hi) return;
+  const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G;
   const uint32_t hmask = caps.H - 1;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
-    if (ld_l2(&ctl->status) != LA_OK) return;  // the attempt is lost (arena or table overflow): the host retries bigger
-    const typename P::Expand x = pol.make_expand(ar.t_lo[q], ar.t_hi[q]);
-    const uint32_t n_items = x.n_it + 1;
+  for (uint32_t q0 = lo + wave * SPW; q0 < hi; q0 += n_waves * SPW) {
+    if (ld_l2(&ctl->status) != LA_OK) return;  // the attempt is lost (arena or table overflow): the host grows the arena
+    const uint32_t q = q0 + grp;
+    const bool valid = q < hi;
+    const uint32_t qc = valid ? q : hi - 1;
+    const typename P::Expand x = pol.make_expand(ar.t_lo[qc], ar.t_hi[qc]);
+    const uint32_t n_items = valid ? x.n_it + 1 : 0u;
     // size of the segment
     uint32_t cnt0 = 0, seg_total = 0;
     Emitted em0;
-    for (uint32_t base = 0; base < n_items; base += 64) {
-      const uint32_t j = base + lane;
+    for (uint32_t base = 0; __any(base < n_items); base += G) {
+      const uint32_t j = base + sub;
       Emitted em;
       const uint32_t cnt = j < n_items ? pol.eval_item(x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u;
       if (base == 0) {
         cnt0 = cnt;
         em0 = em;
       }
-      uint32_t s = cnt;
-      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-      seg_total += s;
+      seg_total += group_sum<G>(cnt);
     }
     uint32_t seg = 0;
-    const uint32_t shard = wave % CUR_SHARDS;
-    if (lane == 0) {
+    const uint32_t shard = (wave * SPW + grp) % CUR_SHARDS;
+    if (sub == 0 && valid) {
       seg = seg_total ? atomicAdd(&ctl->cursor[shard * CUR_STRIDE], seg_total) : 0u;
       ar.seg_base[q] = seg;
       ar.fin[q] = x.final_weight;
     }
-    seg = __shfl(seg, 0);
+    seg = __shfl(seg, 0, G);
     const bool fits = (uint64_t)seg + seg_total <= (uint64_t)ctl->limit[shard];
-    if (lane == 0) {
+    if (sub == 0 && valid) {
       ar.seg_cnt[q] = fits ? seg_total : 0u;
       if (!fits) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_ARCS);
     }
-    if (!fits || seg_total == 0) continue;
+    const bool live = valid && fits && seg_total != 0;
     // the arcs, in item order
     uint32_t running = seg;
-    for (uint32_t base = 0; base < n_items; base += 64) {
-      const uint32_t j = base + lane;
-      const bool have = j < n_items;
-      // (the first chunk's counts are still in registers; states with more than 63 arcs on the iterated side recount)
+    for (uint32_t base = 0; __any(live && base < n_items); base += G) {
+      const uint32_t j = base + sub;
+      const bool have = live && j < n_items;
+      // (the first chunk's counts are still in registers; states with more than G - 1 arcs on the iterated side recount)
       Emitted em = em0;
-      const uint32_t cnt = base == 0 ? cnt0 : (have ? pol.eval_item(x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u);
+      uint32_t cnt = 0;
+      if (have) cnt = base == 0 ? cnt0 : pol.eval_item(x, j, false, 0, nullptr, nullptr, nullptr, &em);
       uint32_t total;
-      const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+      const uint32_t pos = group_excl_scan<G>(cnt, sub, &total);
       if (cnt == 1) {
         *reinterpret_cast<uint4*>(ar.arcs + running + pos) = em.arc;
         ar.a_lo[running + pos] = em.lo;
@@ -226,9 +283,9 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
     // an agent-scope fence would write back this XCD's whole L2 — thousands of waves doing that was 10x the kernel)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // destinations: slot of the tuple + the order of its first emission in this level
-    for (uint32_t base = 0; base < seg_total; base += 64) {
-      const uint32_t k = base + lane;
-      const bool have = k < seg_total;
+    for (uint32_t base = 0; __any(live && base < seg_total); base += G) {
+      const uint32_t k = base + sub;
+      const bool have = live && k < seg_total;
       uint64_t klo = K_EMPTY, khi = 0;
       if (have) {
         klo = ld_l2(&ar.a_lo[seg + k]);
@@ -264,74 +321,155 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
   }
 }
 
-// per state of the level: how many of its arcs are the first emission of a tuple that has no id yet
-__global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t lo, uint32_t hi, const WideCtl* ctl) {
-  if (ld_l2(&ctl->status) != LA_OK) return;  // a lost attempt left segments unwritten: nothing here is valid
-  const uint32_t lane = lane_id();
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) ar.nfirst[hi - lo] = 0;  // the scan's extra element: fbase[hi - lo] = total
-  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
+// the share of a level that block b of a grid of nb blocks numbers: consecutive states, so that ids come out in level order
+__device__ __forceinline__ void block_share(uint32_t lo, uint32_t hi, uint32_t* b_lo, uint32_t* b_hi) {
+  const uint32_t n = hi - lo, chunk = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t a = (uint64_t)lo + (uint64_t)blockIdx.x * chunk;
+  *b_lo = (uint32_t)min(a, (uint64_t)hi);
+  *b_hi = (uint32_t)min(a + chunk, (uint64_t)hi);
+}
+// a tuple is new iff it has no id yet; its first emission is the arc whose order equals the table's minimum
+__device__ __forceinline__ bool is_first_emission(const WideArena& ar, uint32_t slot, uint32_t pos_in_level, uint32_t k) {
+  return ld_l2(&ar.hid[slot]) == ID_UNSET && ld_l2(&ar.hord[slot]) == (((uint64_t)pos_in_level << 32) | k);
+}
+
+// per block: how many arcs of its share of the level are the first emission of a tuple that has no id yet
+template <uint32_t G>
+__global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t level, WideCtl* ctl) {
+  constexpr uint32_t SPW = 64 / G;
+  __shared__ uint32_t s_part[4];
+  const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
+  if (lo >= hi || ctl->status != LA_OK) return;  // (a lost attempt left segments unwritten: nothing here is valid)
+  uint32_t b_lo, b_hi;
+  block_share(lo, hi, &b_lo, &b_hi);
+  const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  uint32_t c = 0;
+  for (uint32_t q = b_lo + wv * SPW + grp; q < b_hi; q += nwv * SPW) {
     const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
-    uint32_t c = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-      const uint32_t k = base + lane;
-      bool first = false;
-      if (k < n) {
-        const uint32_t slot = ar.arcs[seg + k].nextstate;
-        first = ld_l2(&ar.hid[slot]) == ID_UNSET && ld_l2(&ar.hord[slot]) == (((uint64_t)(q - lo) << 32) | k);
-      }
-      c += (uint32_t)__popcll(__ballot(first));
-    }
-    if (lane == 0) ar.nfirst[q - lo] = c;
+    for (uint32_t k = sub; k < n; k += G) c += is_first_emission(ar, ar.arcs[seg + k].nextstate, q - lo, k) ? 1u : 0u;
+  }
+  c = group_sum<64>(c);
+  if (lane == 0) s_part[wv] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < nwv; ++i) t += s_part[i];
+    ctl->bsum[blockIdx.x] = t;
   }
 }
 
-// numbers the new tuples in emission order: id = id_base + firsts before it (StateTable::find_id, state_table.rs:49-59)
-__global__ void __launch_bounds__(256) la_assign(WideArena ar, uint32_t lo, uint32_t hi, uint32_t id_base) {
-  const uint32_t lane = lane_id();
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
-    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
-    uint32_t next = id_base + ar.fbase[q - lo];
-    for (uint32_t base = 0; base < n; base += 64) {
-      const uint32_t k = base + lane;
+// numbers the new tuples in emission order: id = hi + firsts before it (StateTable::find_id, state_table.rs:49-59), and
+// publishes the next level's range.  Same grid as la_first.
+template <uint32_t G>
+__global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint32_t level, WideCtl* ctl) {
+  constexpr uint32_t SPW = 64 / G;
+  __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[64];
+  const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
+  if (lo >= hi) {  // the search ended before this level: the levels queued behind it must see an empty range too
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->lvl[(level + 1) % LVL_RING][0] = hi;
+      ctl->lvl[(level + 1) % LVL_RING][1] = hi;
+    }
+    return;
+  }
+  if (ctl->status != LA_OK) return;
+  const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  uint32_t pre = 0, tot = 0;
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+    const uint32_t v = ctl->bsum[i];
+    tot += v;
+    pre += i < blockIdx.x ? v : 0u;
+  }
+  pre = group_sum<64>(pre);
+  tot = group_sum<64>(tot);
+  if (lane == 0) {
+    s_pre[wv] = pre;
+    s_tot[wv] = tot;
+  }
+  __syncthreads();
+  pre = tot = 0;
+  for (uint32_t i = 0; i < nwv; ++i) {
+    pre += s_pre[i];
+    tot += s_tot[i];
+  }
+  if ((uint64_t)hi + tot > caps.S) {  // the level does not fit: nothing is numbered, the host grows the arena
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_STATES);
+    return;
+  }
+  uint32_t b_lo, b_hi;
+  block_share(lo, hi, &b_lo, &b_hi);
+  const uint32_t T = nwv * SPW, me = wv * SPW + grp;  // states per tile, my state's place in it
+  uint32_t running = hi + pre;
+  for (uint32_t t0 = b_lo; t0 < b_hi; t0 += T) {
+    const uint32_t q = t0 + me;
+    const bool valid = q < b_hi;
+    const uint32_t seg = valid ? ar.seg_base[q] : 0u, n = valid ? ar.seg_cnt[q] : 0u;
+    uint32_t c = 0;
+    for (uint32_t k = sub; k < n; k += G) c += is_first_emission(ar, ar.arcs[seg + k].nextstate, q - lo, k) ? 1u : 0u;
+    c = group_sum<G>(c);
+    if (sub == 0) s_cnt[me] = c;
+    __syncthreads();
+    const uint32_t v = lane < T ? s_cnt[lane] : 0u;
+    uint32_t tile_total;
+    const uint32_t excl = group_excl_scan<64>(v, lane, &tile_total);
+    uint32_t next = running + __shfl(excl, me);
+    __syncthreads();
+    // same predicate as the count: only the one arc whose order the table kept can pass it for a new tuple, and only its
+    // lane writes that tuple's id, so the ids written by other waves meanwhile do not disturb it
+    for (uint32_t base = 0; __any(base < n); base += G) {
+      const uint32_t k = base + sub;
       bool first = false;
       uint32_t slot = 0;
       if (k < n) {
         slot = ar.arcs[seg + k].nextstate;
-        // same predicate as la_first: only the one arc whose order the table kept can pass it for a new tuple, and only
-        // its lane writes that tuple's id, so the ids written by other waves meanwhile do not disturb it
-        first = ld_l2(&ar.hid[slot]) == ID_UNSET && ld_l2(&ar.hord[slot]) == (((uint64_t)(q - lo) << 32) | k);
+        first = is_first_emission(ar, slot, q - lo, k);
       }
-      const uint64_t m = __ballot(first);
+      const uint64_t m = group_mask<G>(__ballot(first), grp);
       if (first) {
-        const uint32_t id = next + lanes_below(m);
+        const uint32_t id = next + (uint32_t)__popcll(m & ((1ull << sub) - 1ull));
         st_l2(&ar.hid[slot], id);
         ar.t_lo[id] = ld_l2(&ar.klo[slot]);
         ar.t_hi[id] = ld_l2(&ar.khi[slot]);
       }
       next += (uint32_t)__popcll(m);
     }
+    running += tile_total;
+  }
+  if (blockIdx.x == 0 && wv == 0) {
+    // how full the arc slices are (the host grows the arena BEFORE a level that is unlikely to fit: an emission that
+    // overflows is thrown away)
+    static_assert(CUR_SHARDS == 64, "one lane per shard");
+    const uint32_t cur = ctl->cursor[lane * CUR_STRIDE], lim = ctl->limit[lane], per = ctl->per;
+    uint32_t slack = lim > cur ? lim - cur : 0u, used = min(cur, lim) - (lim - per);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      slack = min(slack, (uint32_t)__shfl_xor(slack, d));
+      used += __shfl_xor(used, d);
+    }
+    if (lane == 0) {
+      ctl->slack_min = slack;
+      ctl->arcs_used = used;
+      ctl->lvl[(level + 1) % LVL_RING][0] = hi;
+      ctl->lvl[(level + 1) % LVL_RING][1] = hi + tot;
+      ctl->k_done = level + 1;
+    }
   }
 }
 
-__global__ void __launch_bounds__(256) la_patch(WideArena ar, uint32_t lo, uint32_t hi) {
-  const uint32_t lane = lane_id();
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t q = lo + wave; q < hi; q += n_waves) {
-    const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q];
-    for (uint32_t k = lane; k < n; k += 64) ar.arcs[seg + k].nextstate = ld_l2(&ar.hid[ar.arcs[seg + k].nextstate]);
-  }
-}
-
-// segments -> CSR order
+// segments -> CSR order; states from `patch_from` on still carry table slots in their arcs
+template <uint32_t G>
 __global__ void __launch_bounds__(256) la_gather(WideArena ar, const uint32_t* __restrict__ off, wfst_tr* __restrict__ out,
-                                                 uint32_t n_states) {
-  const uint32_t lane = lane_id();
+                                                 uint32_t n_states, uint32_t patch_from) {
+  constexpr uint32_t SPW = 64 / G;
+  const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t q = wave; q < n_states; q += n_waves) {
+  for (uint32_t q = wave * SPW + grp; q < n_states; q += n_waves * SPW) {
     const uint32_t seg = ar.seg_base[q], n = ar.seg_cnt[q], o = off[q];
-    for (uint32_t k = lane; k < n; k += 64) *reinterpret_cast<uint4*>(out + o + k) = *reinterpret_cast<const uint4*>(ar.arcs + seg + k);
+    for (uint32_t k = sub; k < n; k += G) {
+      uint4 a = *reinterpret_cast<const uint4*>(ar.arcs + seg + k);
+      if (q >= patch_from) a.w = ar.hid[a.w];
+      *reinterpret_cast<uint4*>(out + o + k) = a;
+    }
   }
 }
 
@@ -375,22 +513,25 @@ inline void wide_alloc(wfst_ctx* ctx, uint64_t est_s, uint64_t est_a, WideBuffer
   const size_t o_tlo = take((size_t)caps.S * 8), o_thi = take((size_t)caps.S * 8), o_klo = take((size_t)caps.H * 8),
                o_khi = take((size_t)caps.H * 8), o_hord = take((size_t)caps.H * 8), o_hid = take((size_t)caps.H * 4),
                o_arcs = take((size_t)caps.A * 16), o_alo = take((size_t)caps.A * 8), o_ahi = take((size_t)caps.A * 8),
-               o_sb = take((size_t)caps.S * 4), o_sc = take(((size_t)caps.S + 1) * 4), o_nf = take(((size_t)caps.S + 1) * 4),
-               o_fb = take(((size_t)caps.S + 1) * 4), o_fin = take((size_t)caps.S * 4), o_off = take(((size_t)caps.S + 1) * 4),
-               o_out = take((size_t)caps.A * 16);
+               o_sb = take((size_t)caps.S * 4), o_sc = take(((size_t)caps.S + 1) * 4), o_fin = take((size_t)caps.S * 4),
+               o_off = take(((size_t)caps.S + 1) * 4), o_out = take((size_t)caps.A * 16);
   w.arena = DBuf<char>(*ctx->pool, bytes);
   char* b = w.arena.p;
   w.ar = WideArena{(uint64_t*)(b + o_tlo), (uint64_t*)(b + o_thi), (uint64_t*)(b + o_klo),  (uint64_t*)(b + o_khi),
                    (uint64_t*)(b + o_hord), (uint32_t*)(b + o_hid), (wfst_tr*)(b + o_arcs), (uint64_t*)(b + o_alo),
-                   (uint64_t*)(b + o_ahi), (uint32_t*)(b + o_sb),  (uint32_t*)(b + o_sc),  (uint32_t*)(b + o_nf),
-                   (uint32_t*)(b + o_fb),  (float*)(b + o_fin)};
+                   (uint64_t*)(b + o_ahi), (uint32_t*)(b + o_sb),  (uint32_t*)(b + o_sc),  (float*)(b + o_fin)};
   w.d_off = (uint32_t*)(b + o_off);
   w.d_out = (wfst_tr*)(b + o_out);
   w.caps = caps;
 }
 
-template <class P>
-void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, WideOutput& out) {
+// The level loop.  Level ranges, the overflow status and the count of finished levels live in the control block, so the
+// host queues `batch` levels (three launches each) per look at it; levels queued behind the last one, or behind one that
+// did not fit, return at once.  Grids are sized from the last width the host has seen (every kernel strides, so any grid
+// is correct).
+template <class P, uint32_t G>
+void run_wide_g(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, WideOutput& out) {
+  constexpr uint32_t SPB = 4 * (64 / G);  // states a block of 256 threads works on at a time
   hipStream_t st = ctx->stream;
   if (const char* e = std::getenv("WFST_WIDE_EST_STATES")) {  // tests: start from a tiny arena so that it has to grow
     est_s = std::max<uint64_t>(64, (uint64_t)std::atoll(e));
@@ -405,68 +546,136 @@ void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t 
   wide_alloc(ctx, est_s, est_a, w);
   DBuf<WideCtl> d_ctl(*ctx->pool, 1);
   size_t temp_bytes = 0;
-  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, w.ar.nfirst, w.ar.fbase, 0u, (size_t)0x7FFFFFF0u, rocprim::plus<uint32_t>(), st));
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, w.ar.seg_cnt, w.d_off, 0u, (size_t)0x7FFFFFF0u, rocprim::plus<uint32_t>(), st));
   DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
   struct HostCtl {
-    uint32_t status, n_new, n_arcs;
+    uint32_t head[WIDE_CTL_HEAD / 4];  // status, k_done, pad, lvl ring
+    uint32_t n_arcs;
   };
   HostCtl* hc = (HostCtl*)ctx->pinned.get(sizeof(HostCtl));
-  const uint32_t max_blocks = (uint32_t)ctx->n_cus * 8;
+  const uint32_t max_blocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, WIDE_MAX_BLOCKS);
   la_wide_init<<<std::min<uint32_t>(max_blocks, (w.caps.H + 255) / 256), 256, 0, st>>>(w.ar, w.caps, lo0, hi0, d_ctl.p);
-  uint32_t lo = 0, hi = 1, levels = 0;
+  uint32_t k = 0, lo = 0, hi = 1, patch_from = 0, w_prev = 0, batch_cap = 4;
+  uint32_t lo_part = 0;  // first state whose arcs went into the current part of the arc arena
+  double arcs_per_state = 4.0;
+  int fixed_batch = 0;
+  if (const char* e = std::getenv("WFST_WIDE_BATCH")) fixed_batch = std::max(1, std::min(32, std::atoi(e)));
+  const bool proactive = !std::getenv("WFST_WIDE_NO_FORESIGHT");  // tests: let levels overflow
+  const bool trace = std::getenv("WFST_WIDE_TRACE") != nullptr;
   int grows = 0;
-  while (lo < hi) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
-    const uint32_t n_level = hi - lo;
-    const uint32_t blocks = std::min<uint32_t>(max_blocks, (n_level + 3) / 4);
-    la_emit<P><<<blocks, 256, 0, st>>>(pol, w.caps, w.ar, lo, hi, d_ctl.p);
-    la_first<<<blocks, 256, 0, st>>>(w.ar, lo, hi, d_ctl.p);
-    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, w.ar.nfirst, w.ar.fbase, 0u, (size_t)n_level + 1, rocprim::plus<uint32_t>(), st));
-    HIP_CHECK(hipMemcpyAsync(&hc->status, &d_ctl.p->status, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&hc->n_new, w.ar.fbase + n_level, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (hc->status != LA_OK || (uint64_t)hi + hc->n_new > w.caps.S) {
-      // the level does not fit: four times the room, everything numbered so far moves over, the level is emitted again
-      ctx->stats.compose_retries++;
-      if (++grows > 24) throw Error("compose: arena overflow after retries");
-      WideBuffers nw;
-      // (growing is cheap now, an over-sized table is not: its random accesses leave the caches — x2 once it is large)
-      const uint64_t g = w.caps.S >= (1u << 20) ? 2 : 4;
-      wide_alloc(ctx, g * w.caps.S, g * w.caps.A, nw);
-      auto copy = [&](void* d, const void* s_, size_t n) { HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st)); };
-      copy(nw.ar.t_lo, w.ar.t_lo, (size_t)hi * 8);
-      copy(nw.ar.t_hi, w.ar.t_hi, (size_t)hi * 8);
-      copy(nw.ar.seg_base, w.ar.seg_base, (size_t)lo * 4);
-      copy(nw.ar.seg_cnt, w.ar.seg_cnt, (size_t)lo * 4);
-      copy(nw.ar.fin, w.ar.fin, (size_t)lo * 4);
-      copy(nw.ar.arcs, w.ar.arcs, (size_t)w.caps.A * 16);  // (finished segments keep their positions; their tuple words
-      la_wide_clear_table<<<std::min<uint32_t>(max_blocks, (nw.caps.H + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps);  //  are dead)
-      la_wide_regrow<<<std::min<uint32_t>(max_blocks, (hi + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps, hi, w.caps.A, d_ctl.p);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipStreamSynchronize(st));  // the old arena goes back to the pool
-      w = std::move(nw);
-      continue;  // the same level again
+  auto grow = [&]() {
+    ctx->stats.compose_retries++;
+    if (++grows > 24) throw Error("compose: arena overflow after retries");
+    // the arcs of the finished levels still name table slots, and the table is about to be rebuilt
+    if (lo > patch_from) la_patch_range<<<std::min<uint32_t>(max_blocks, (lo - patch_from + 31) / 32), 256, 0, st>>>(w.ar, patch_from, lo);
+    patch_from = lo;
+    WideBuffers nw;
+    // (growing is cheap now, an over-sized table is not: its random accesses leave the caches — x2 once it is large)
+    const uint64_t g = w.caps.S >= (1u << 20) ? 2 : 4;
+    wide_alloc(ctx, g * w.caps.S, g * w.caps.A, nw);
+    auto copy = [&](void* d, const void* s_, size_t n) { HIP_CHECK(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, st)); };
+    copy(nw.ar.t_lo, w.ar.t_lo, (size_t)hi * 8);
+    copy(nw.ar.t_hi, w.ar.t_hi, (size_t)hi * 8);
+    copy(nw.ar.seg_base, w.ar.seg_base, (size_t)lo * 4);
+    copy(nw.ar.seg_cnt, w.ar.seg_cnt, (size_t)lo * 4);
+    copy(nw.ar.fin, w.ar.fin, (size_t)lo * 4);
+    copy(nw.ar.arcs, w.ar.arcs, (size_t)w.caps.A * 16);  // (finished segments keep their positions; their tuple words
+    la_wide_clear_table<<<std::min<uint32_t>(max_blocks, (nw.caps.H + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps);  //  are dead)
+    la_wide_regrow<<<std::min<uint32_t>(max_blocks, (hi + 255) / 256), 256, 0, st>>>(nw.ar, nw.caps, hi, w.caps.A, d_ctl.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));  // the old arena goes back to the pool
+    w = std::move(nw);
+    lo_part = lo;
+  };
+  for (;;) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
+    const uint32_t width = hi - lo;
+    const double ratio = w_prev ? (double)width / w_prev : 3.0;
+    // narrow levels are launch-bound: many per look; wide ones are not, and whatever is queued behind a level that does
+    // not fit is wasted
+    const uint32_t batch = fixed_batch ? (uint32_t)fixed_batch : std::min(batch_cap, width < 8192 ? 8u : (width < 65536 ? 4u : 2u));
+    // room for the widest level of the batch if the growth of the last level goes on (every kernel strides, so a grid
+    // that turns out too small is only slower; one that is too large costs ~3 us per launch)
+    double head = 2.0;
+    for (uint32_t j = 1; j < batch && ratio > 1.0 && head < 64.0; ++j) head *= ratio;
+    const uint64_t want = (uint64_t)((double)width * std::min(head, 64.0) / SPB) + 1;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(64, want));
+    for (uint32_t j = 0; j < batch; ++j) {
+      la_emit<P, G><<<blocks, 256, 0, st>>>(pol, w.caps, w.ar, k + j, d_ctl.p);
+      la_first<G><<<blocks, 256, 0, st>>>(w.ar, k + j, d_ctl.p);
+      la_assign<G><<<blocks, 256, 0, st>>>(w.ar, w.caps, k + j, d_ctl.p);
     }
-    levels++;
-    la_assign<<<blocks, 256, 0, st>>>(w.ar, lo, hi, hi);
-    la_patch<<<blocks, 256, 0, st>>>(w.ar, lo, hi);
-    lo = hi;
-    hi += hc->n_new;
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(hc->head, d_ctl.p, WIDE_CTL_HEAD, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t status = hc->head[0];
+    const uint32_t k_new = hc->head[1];
+    if (k_new > k) w_prev = hc->head[32 + 2 * ((k_new - 1) % LVL_RING) + 1] - hc->head[32 + 2 * ((k_new - 1) % LVL_RING)];
+    k = k_new;
+    lo = hc->head[32 + 2 * (k % LVL_RING)];
+    hi = hc->head[32 + 2 * (k % LVL_RING) + 1];
+    if (trace)
+      fprintf(stderr, "wide: k=%u [%u,%u) status=%u S=%u A=%u slack_min=%u arcs_used=%u batch=%u blocks=%u\n", k, lo, hi, status,
+              w.caps.S, w.caps.A, hc->head[2], hc->head[3], batch, blocks);
+    if (status != LA_OK) {
+      // level k does not fit (arc slices, table or state count): more room, everything numbered so far moves over, the
+      // level is emitted again
+      grow();
+      continue;
+    }
+    if (lo >= hi) break;  // the last level added nothing
+    if (proactive) {
+      // how many of the next levels are going to fit?  Level k adds about width x (growth of the last level) states and
+      // width x (arcs per state so far) arcs, spread over the shards, the one after it that times the growth again ...
+      // Only that many are queued; if not even level k fits the arena grows NOW: same cost as after the overflow, minus
+      // the emission that would have been thrown away.
+      if (lo > lo_part) arcs_per_state = std::max(1.0, (double)hc->head[3] / (lo - lo_part));
+      const double r = w_prev ? std::min(8.0, std::max(1.0, (double)(hi - lo) / w_prev)) : 3.0;
+      double slack = hc->head[2];
+      auto levels_that_fit = [&](uint32_t limit) {
+        double states = hi, wl = hi - lo, room = slack;
+        uint32_t n = 0;
+        for (; n < limit; ++n) {
+          const double arcs_shard = arcs_per_state * wl / CUR_SHARDS, new_states = 1.25 * r * wl;
+          if (states + new_states > (double)w.caps.S || 1.5 * arcs_shard + 64.0 > room) break;
+          states += new_states;
+          room -= arcs_shard;
+          wl *= r;
+        }
+        return n;
+      };
+      while ((batch_cap = levels_that_fit(8)) == 0) {
+        if (trace) fprintf(stderr, "wide: growing ahead of level %u (width %u, growth %.2f, %.1f arcs per state)\n", k, hi - lo, r, arcs_per_state);
+        const uint32_t a_old = w.caps.A;
+        grow();
+        slack = (double)((w.caps.A - a_old) / CUR_SHARDS);
+      }
+    }
   }
-  HIP_CHECK(hipGetLastError());
   const uint32_t n_states = hi;
   HIP_CHECK(hipMemsetAsync(w.ar.seg_cnt + n_states, 0, sizeof(uint32_t), st));
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, w.ar.seg_cnt, w.d_off, 0u, (size_t)n_states + 1, rocprim::plus<uint32_t>(), st));
-  la_gather<<<std::min<uint32_t>(max_blocks, (n_states + 3) / 4), 256, 0, st>>>(w.ar, w.d_off, w.d_out, n_states);
+  la_gather<G><<<std::min<uint32_t>(max_blocks, (n_states + SPB - 1) / SPB), 256, 0, st>>>(w.ar, w.d_off, w.d_out, n_states, patch_from);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(&hc->n_arcs, w.d_off + n_states, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   out.n_states = n_states;
   out.n_arcs = hc->n_arcs;
-  out.n_levels = levels;
+  out.n_levels = k;
   out.off = w.d_off;
   out.arcs = w.d_out;
   out.fin = w.ar.fin;
   out.arena = std::move(w.arena);
+}
+
+// `items_hint`: arcs a composed state has on its iterated side, on average (+ the loop item) — picks the lanes per state
+template <class P>
+void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, double items_hint,
+              WideOutput& out) {
+  uint32_t g = items_hint <= 8.0 ? 8u : (items_hint <= 16.0 ? 16u : 64u);
+  if (const char* e = std::getenv("WFST_WIDE_GROUP")) g = (uint32_t)std::atoi(e);  // tests: 8, 16 or 64 lanes per state
+  if (g == 8) run_wide_g<P, 8>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  else if (g == 16) run_wide_g<P, 16>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  else run_wide_g<P, 64>(ctx, pol, lo0, hi0, est_s, est_a, out);
 }
 
 }  // namespace

@@ -283,7 +283,9 @@ wfst_fst* compose_wide(wfst_ctx* ctx, const wfst_fst* f1, const wfst_fst* f2, ui
                        uint64_t out_props, uint64_t est_s) {
   const PlainPolicy pol{PlainView{f1->dev.arcs, f1->dev.srec}, PlainView{f2->dev.arcs, f2->dev.srec}, mode, filter};
   WideOutput w;
-  run_wide(ctx, pol, ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)f2->start, 0ull, est_s, 4 * est_s, w);
+  const double d1 = (double)f1->n_arcs / std::max<uint32_t>(f1->n_states, 1), d2 = (double)f2->n_arcs / std::max<uint32_t>(f2->n_states, 1);
+  const double items = 1.0 + (mode == MODE_INPUT ? d1 : mode == MODE_OUTPUT ? d2 : std::min(d1, d2));  // iterated side
+  run_wide(ctx, pol, ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)f2->start, 0ull, est_s, 4 * est_s, items, w);
   ctx->stats.compose_states = w.n_states;
   ctx->stats.compose_arcs = w.n_arcs;
   if (!connect) return adopt_device(ctx, w.n_states, w.n_arcs, 0, out_props, w.off, w.arcs, w.fin);

@@ -1318,6 +1318,36 @@ def test_wide_driver_grows_its_arena(gpu_ctx, oracle, monkeypatch):
     assert_flat_identical(got.to_flat(), oa.compose(ob).to_flat(), "compose, grown arena")
 
 
+@pytest.mark.parametrize("group,batch,est", [("8", "1", "256"), ("8", "5", "0"), ("16", "2", "256"), ("16", "8", "0"), ("64", "3", "256"),
+                                             ("8", "4", "-64"), ("16", "auto", "-256")])
+def test_wide_driver_lane_groups_and_level_batches(gpu_ctx, oracle, monkeypatch, group, batch, est):
+    """The wide driver with 8, 16 or 64 lanes per composed state and 1..8 levels queued per look at the control block
+    (level ranges, overflow status and finished-level count live on the device), from a small arena that has to grow in
+    the middle of a batch (before the level that is not going to fit, or — foresight off — after it has overflowed) and
+    from the default one: plain and look-ahead composition equal the oracle — also with states
+    that have more arcs than a lane group (several chunks per state) and with levels queued behind the last one."""
+    monkeypatch.setenv("WFST_WIDE_GROUP", group)
+    if batch != "auto":
+        monkeypatch.setenv("WFST_WIDE_BATCH", batch)
+    if est.startswith("-"):  # the arena is only grown AFTER a level has overflowed (in the middle of a batch)
+        monkeypatch.setenv("WFST_WIDE_NO_FORESIGHT", "1")
+        est = est[1:]
+    if est != "0":
+        monkeypatch.setenv("WFST_WIDE_EST_STATES", est)
+    monkeypatch.setenv("WFST_COMPOSE_PATH", "wide")
+    monkeypatch.setenv("WFST_LOOKAHEAD_PATH", "wide")
+    for (n1, f1, n2, f2, sigma) in [(300, 3, 20, 8, 8), (40, 40, 12, 30, 6)]:
+        a = _swap_labels(synth.make_transducer(n1, f1, sigma, 0.2, seed=1, p_final=0.05))
+        b = synth.make_transducer(n2, f2, sigma, 0.05, seed=101, p_final=0.05)
+        oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+        la = rustfst_amd.LookAhead(to_device(a))
+        out = la.compose(la.relabel(to_device(b)))
+        assert_flat_identical(out.to_flat(), oa.compose_lookahead(ob).to_flat(), f"look-ahead, group {group} batch {batch}")
+        for connect in (False, True):
+            got = to_device(a).compose(to_device(b), ComposeConfig(connect=connect))
+            assert_flat_identical(got.to_flat(), oa.compose(ob, connect=connect).to_flat(), f"compose, group {group} batch {batch}")
+
+
 def test_reference_known_answers_reverse_tr_sort_connect(gpu_ctx):
     """The reference's own vectors for the operations around the path (rustfst-python/tests/algorithms/test_reverse.py:4-57,
     test_tr_sort.py:4-97, test_connect.py:4-55) through the GPU path: reverse and tr_sort directly; connect as the trim of a

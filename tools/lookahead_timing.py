@@ -37,11 +37,17 @@ for n1, n2, fan1, fan2, sigma in cases:
     d2 = la.relabel(db); t2 = time.perf_counter()
     out = la.compose(d2)  # warm-up (arena growth retries included)
     torch.cuda.synchronize(); t3 = time.perf_counter()
-    out = la.compose(d2)
-    torch.cuda.synchronize(); t4 = time.perf_counter()
+    la_ms = plain_ms = float("inf")
+    for _ in range(3):  # best of three (a pool that has to go back to hipMalloc shows up as a 2x outlier)
+        t3 = time.perf_counter()
+        out = la.compose(d2)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        la_ms = min(la_ms, (t4 - t3) * 1e3)
     st = ctx.stats()
     plain = da.compose(db, rustfst_amd.ComposeConfig(connect=False)); torch.cuda.synchronize()  # warm-up (pool growth)
-    t5 = time.perf_counter(); plain = da.compose(db, rustfst_amd.ComposeConfig(connect=False)); torch.cuda.synchronize(); t6 = time.perf_counter()
+    for _ in range(3):
+        t5 = time.perf_counter(); plain = da.compose(db, rustfst_amd.ComposeConfig(connect=False)); torch.cuda.synchronize(); t6 = time.perf_counter()
+        plain_ms = min(plain_ms, (t6 - t5) * 1e3)
     cpu_ms = float("nan")
     if n1 * n2 <= 3_000_000:
         oa, ob = to_oracle(oracle_py, a), to_oracle(oracle_py, b)
@@ -49,4 +55,4 @@ for n1, n2, fan1, fan2, sigma in cases:
         cpu_ms = (t8 - t7) * 1e3
         f1, f2 = out.to_flat(), ref.to_flat()
         assert f1["n_states"] == f2["n_states"] and np.array_equal(f1["arcs"], f2["arcs"]) and np.array_equal(f1["finals"].view(np.uint32), f2["finals"].view(np.uint32))
-    print(f"{n1:6d} {n2:6d} {out.num_states:7d} {out.num_arcs:7d} {'':7s} {(t1-t0)*1e3:8.1f} {(t2-t1)*1e3:10.1f} {(t4-t3)*1e3:7.2f} {cpu_ms:8.1f}  {(t6-t5)*1e3:7.2f} ({plain.num_states})", flush=True)
+    print(f"{n1:6d} {n2:6d} {out.num_states:7d} {out.num_arcs:7d} {'':7s} {(t1-t0)*1e3:8.1f} {(t2-t1)*1e3:10.1f} {la_ms:7.2f} {cpu_ms:8.1f}  {plain_ms:7.2f} ({plain.num_states})", flush=True)
