@@ -157,6 +157,43 @@ def main():
             cold.append(round(1e3 * (time.perf_counter() - c0), 4))
         del dcold
 
+    # ------------------------------------------------------------------ the reference harness's split (untimed setup, reported)
+    # rustfst-cli --bench (rustfst-cli/src/binary_fst_algorithm.rs:88-214) times, per iteration, parsing the input file,
+    # the algorithm, and serialising the result, and reports mean +- sigma of each; the same three legs for
+    # shortest_path on T through this engine: OpenFST vector file -> host parse + upload to HBM, the (cold: fresh handle)
+    # solve, result path -> OpenFST bytes -> file
+    harness = None
+    if rank == 0 and not args.no_extras:
+        import tempfile
+        f_in = os.path.join(tempfile.gettempdir(), f"wfst_bench_T_{os.getpid()}.fst")
+        f_out = f_in + ".out"
+        with open(f_in, "wb") as fh:
+            fh.write(dt.to_bytes())
+        legs = {"parsing": [], "algorithm": [], "serialization": [], "cli": []}
+        H_WARM, H_ITERS = 1, 3
+        for i in range(H_WARM + H_ITERS):
+            h0 = time.perf_counter()
+            with open(f_in, "rb") as fh:
+                dparsed = rustfst_amd.DeviceFst.from_bytes(fh.read(), ctx)
+            torch.cuda.synchronize(device)
+            h1 = time.perf_counter()
+            hres = dparsed.shortest_path()
+            h2 = time.perf_counter()
+            with open(f_out, "wb") as fh:
+                fh.write(hres.to_bytes())
+            h3 = time.perf_counter()
+            if i >= H_WARM:
+                for name, v in (("parsing", h1 - h0), ("algorithm", h2 - h1), ("serialization", h3 - h2), ("cli", h3 - h0)):
+                    legs[name].append(1e3 * v)
+            del dparsed, hres
+        harness = {"algorithm": "shortest_path", "input_file_bytes": os.path.getsize(f_in), "warmups": H_WARM, "iterations": H_ITERS,
+                   "note": "rustfst-cli --bench legs (binary_fst_algorithm.rs:88-214): parse = read + host parse + upload to HBM; "
+                           "algorithm = cold solve on the fresh handle; serialization = path FST -> OpenFST bytes -> file"}
+        for name, v in legs.items():
+            harness[name + "_ms"] = {"mean": round(float(np.mean(v)), 3), "std": round(float(np.std(v)), 3)}
+        os.remove(f_in)
+        os.remove(f_out)
+
     last = {}
 
     def exchange():
@@ -441,6 +478,7 @@ def main():
                                                         "note": "shortest_path(T) on a fresh HBM-resident handle: 1st builds the "
                                                                 "mailbox region plan + parent pass, 2nd builds the transpose"},
             "config2_single_string": config2,
+            "reference_harness_split": harness,
             "roofline": roofline, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -31,14 +31,41 @@ while time.time() < t_end:
         n["skipped"] += 1
         seed += 1
         continue
+    # the wide driver's knobs, drawn per case: lanes per composed state, levels queued per look, a first arena that has to
+    # grow (ahead of the level that would not fit, or after it has overflowed)
+    knobs = {}
+    if rng.integers(0, 3):
+        knobs["WFST_WIDE_GROUP"] = str(int(rng.choice([8, 16, 64])))
+    if rng.integers(0, 3):
+        knobs["WFST_WIDE_BATCH"] = str(int(rng.integers(1, 9)))
+    if rng.integers(0, 2):
+        knobs["WFST_WIDE_EST_STATES"] = str(int(rng.choice([64, 256, 1024])))
+    if rng.integers(0, 2):
+        knobs["WFST_WIDE_NO_FORESIGHT"] = "1"
+    for k in ("WFST_WIDE_GROUP", "WFST_WIDE_BATCH", "WFST_WIDE_EST_STATES", "WFST_WIDE_NO_FORESIGHT"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
     for path in ("wave", "wide"):
         if path == "wave" and ref["n_states"] > 20000:
             continue
         os.environ["WFST_LOOKAHEAD_PATH"] = path
         la = rustfst_amd.LookAhead(to_device(a))
         out = la.compose(la.relabel(to_device(b))).to_flat()
-        assert_flat_identical(out, ref, f"seed {seed} path {path}")
+        assert_flat_identical(out, ref, f"seed {seed} path {path} knobs {knobs}")
         n[path] += 1
+    # the same pair through compose() pinned to the wide driver, a random filter, with and without connect
+    flt = int(rng.integers(0, 7))
+    connect = bool(rng.integers(0, 2))
+    try:
+        refc = to_oracle(O, a).compose(to_oracle(O, b), connect=connect, compose_filter=flt).to_flat()
+    except O.OracleError:
+        refc = None
+    if refc is not None:
+        os.environ["WFST_COMPOSE_PATH"] = "wide"
+        got = to_device(a).compose(to_device(b), rustfst_amd.ComposeConfig(rustfst_amd.ComposeFilter(flt), connect=connect)).to_flat()
+        os.environ.pop("WFST_COMPOSE_PATH")
+        assert_flat_identical(got, refc, f"seed {seed} plain wide filter {flt} connect {connect} knobs {knobs}")
+        n["plain_wide"] = n.get("plain_wide", 0) + 1
     if ref["n_states"] > 2048:
         n["big"] += 1
     seed += 1
