@@ -74,6 +74,15 @@ struct Ctl {
   uint32_t f_parent, hops;
   float final_weight, total;
   uint32_t has_path, pad;
+  // fused tail (sssp_tail_kernel): per-workgroup best final state, and the ticket that tells the last workgroup it is last
+  unsigned long long tail_best[128];
+  uint32_t tail_ticket, tail_pad;
+};
+constexpr uint32_t TAIL_BLOCKS = 128;
+// what the host needs from the tail of a solve, written straight into pinned memory by sssp_tail_kernel
+struct TailOut {
+  uint32_t has_path, hops, pad, f_parent;
+  float final_weight, total;
 };
 
 // threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
@@ -565,6 +574,122 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
     cur = s;
   }
   if (lane == 0) ctl->hops = k;  // the real length of the walk
+}
+
+// The tail of a repeated query in ONE launch: arg-min over the final states (sssp_final_kernel), the header
+// (sssp_header_kernel) and the walk over the transpose (sssp_backtrace_rev_kernel), with the result header written into
+// pinned host memory next to the path arcs.  Every workgroup leaves the best final state of its share; the workgroup
+// that draws the last ticket reduces them and walks back.  (Three launches, a 1-thread kernel and a copy of the whole
+// control block cost ~30 us at the end of every solve; 1024 workgroups each polling and lowering ONE word were most of
+// the final-state search: same-address atomics serialise at ~12 ns.)
+__global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key,
+                                                         uint32_t n, Ctl* __restrict__ ctl,
+                                                         const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
+                                                         const uint2* __restrict__ wn, const uint32_t* __restrict__ rev_off,
+                                                         const uint2* __restrict__ rev_arc, wfst_tr* __restrict__ out,
+                                                         uint32_t out_cap, TailOut* __restrict__ hout) {
+  __shared__ unsigned long long s_best[16];
+  __shared__ uint32_t s_last;
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long best = KEY_INF;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const float f = finals[s];
+    if (!(f < INF)) continue;  // most states are not final: their key is never fetched
+    const uint64_t k = key[s];
+    if (k == KEY_INF) continue;
+    const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;  // d[s] (x) rho(s), shortest_path.rs:214-220
+    if (!(tot < INF)) continue;
+    const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | s;
+    best = c < best ? c : best;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  if (lane == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) best = s_best[w] < best ? s_best[w] : best;
+    __hip_atomic_store(&ctl->tail_best[blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(&ctl->tail_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  // the last workgroup's first wave: every other workgroup's result is in memory
+  best = KEY_INF;
+  for (uint32_t b = lane; b < gridDim.x; b += 64) {
+    const unsigned long long o = __hip_atomic_load(&ctl->tail_best[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    best = o < best ? o : best;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  uint32_t pad = ctl->pad;
+  if (lane == 0) {
+    ctl->tail_ticket = 0;  // the tail may run again on the same control block (a solve that outran its prediction)
+    ctl->best = best;
+  }
+  if (best == KEY_INF) {
+    if (lane == 0) {
+      ctl->has_path = 0;
+      ctl->hops = 0;
+      *hout = TailOut{0u, 0u, pad, 0u, INF, INF};
+    }
+    return;
+  }
+  const uint32_t fp = (uint32_t)best;
+  const float final_weight = finals[fp], total = dec_f32((uint32_t)(best >> 32));
+  uint32_t cur = fp, k = 0;
+  if ((uint32_t)key[fp] > out_cap) pad |= 8u;  // the host falls back to the parent pass
+  while (!(pad & 12u)) {
+    const uint64_t kt = key[cur];
+    if ((uint32_t)kt == 0u) break;  // the start state
+    if (k >= out_cap) {
+      pad |= 8u;
+      break;
+    }
+    unsigned long long bp = ~0ull;
+    for (uint32_t j = rev_off[cur] + lane; j < rev_off[cur + 1]; j += 64) {
+      const uint2 ra = rev_arc[j];
+      const uint64_t ks = key[ra.x];
+      if (ks == KEY_INF) continue;
+      const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(wn[offsets[ra.x] + ra.y].x)) + 0.0f;
+      if (!(c < INF)) continue;
+      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
+      const unsigned long long cls = parent_class(ck, ks, kt);
+      if (cls != PARENT_NONE) {
+        const unsigned long long cand = cls | ((unsigned long long)ra.x << 32) | ra.y;
+        bp = cand < bp ? cand : bp;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long o = __shfl_xor(bp, d);
+      bp = o < bp ? o : bp;
+    }
+    if (bp == PARENT_NONE) {  // no admissible predecessor: reported, not followed
+      pad |= 4u;
+      break;
+    }
+    const uint32_t s = (uint32_t)(bp >> 32) & 0x7FFFFFFFu, pos = (uint32_t)bp;
+    if (lane == 0) {
+      wfst_tr tr = arcs[offsets[s] + pos];
+      tr.nextstate = k;
+      out[k] = tr;
+    }
+    cur = s;
+    ++k;
+  }
+  if (lane == 0) {
+    ctl->has_path = 1;
+    ctl->f_parent = fp;
+    ctl->hops = (pad & 12u) ? (uint32_t)key[fp] : k;
+    ctl->final_weight = final_weight;
+    ctl->total = total;
+    // (the walk's own flags go to the host only: a tail that ran ahead of the last sweeps is run again on this block)
+    *hout = TailOut{1u, (pad & 12u) ? (uint32_t)key[fp] : k, pad, fp, final_weight, total};
+  }
 }
 
 __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __restrict__ dist, uint32_t* __restrict__ hops,
@@ -1105,11 +1230,13 @@ struct wfst_sp_job {
   const wfst_fst* f = nullptr;
   bool trivial = false;      // no start state: the result is the empty FST (shortest_path.rs:185-187)
   bool tail_queued = false;  // final / header / backtrace / read-back already queued behind the first batch
+  bool fused_tail = false;   // ... as the one-launch sssp_tail_kernel (result header in h_tail instead of hc)
   wfst::Solve sv;
   wfst::SweepDriver drv;
   const wfst::RevCsr* rev = nullptr;
   wfst::Ctl* hc = nullptr;
   wfst_tr* h_path = nullptr;
+  wfst::TailOut* h_tail = nullptr;  // header of the result, written by sssp_tail_kernel (transpose cached)
 };
 
 namespace wfst {
@@ -1122,6 +1249,14 @@ void queue_tail(wfst_sp_job* j) {
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   Solve& sv = j->sv;
+  if (j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL")) {  // one launch, header straight into pinned memory
+    sssp_tail_kernel<<<std::min<uint32_t>(TAIL_BLOCKS, (n + 1023) / 1024), 1024, 0, st>>>(
+        f->dev.finals, sv.key.p, n, sv.ctl.p, f->dev.offsets, f->dev.arcs, f->dev.wn, j->rev->off.p, j->rev->arc.p, j->h_path,
+        PATH_PINNED, j->h_tail);
+    j->fused_tail = true;
+    return;
+  }
+  j->fused_tail = false;
   sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p,
                                                                                                           n, sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
@@ -1142,9 +1277,10 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
     return j.release();
   }
   ensure_device(const_cast<wfst_fst*>(f));
-  char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 64 + PATH_PINNED * sizeof(wfst_tr));
+  char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 128 + PATH_PINNED * sizeof(wfst_tr));
   j->hc = (Ctl*)pin;
-  j->h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
+  j->h_tail = (TailOut*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
+  j->h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63) + 64);
   j->rev = reverse_csr(ctx, f);  // may build the transpose (second query of a large FST): before anything is queued
   if (ctx->profiling) {
     run_relaxation(ctx, f, j->sv);  // per-sweep events: synchronous
@@ -1183,12 +1319,13 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   if (!j->tail_queued) queue_tail(j.get());
   HIP_CHECK(hipStreamSynchronize(st));
   const Ctl* hc = j->hc;
-  if (hc->pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
-  if (hc->pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
-  if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
-  const uint32_t hops = hc->hops;
-  const float final_weight = hc->final_weight;
-  if (j->rev && !(hc->pad & 8u)) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
+  const uint32_t r_pad = j->fused_tail ? j->h_tail->pad : hc->pad, r_has_path = j->fused_tail ? j->h_tail->has_path : hc->has_path;
+  if (r_pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
+  if (r_pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
+  if (!r_has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
+  const uint32_t hops = j->fused_tail ? j->h_tail->hops : hc->hops;
+  const float final_weight = j->fused_tail ? j->h_tail->final_weight : hc->final_weight;
+  if (j->rev && !(r_pad & 8u)) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
   // the parent pass (first query of an FST, or a path longer than the pinned buffer): a path has at most n - 1 arcs
   std::vector<wfst_tr> path;
   uint32_t len = 0;

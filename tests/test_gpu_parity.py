@@ -733,6 +733,36 @@ def test_shortest_path_repeated_queries_use_transpose(gpu_ctx, oracle, seed):
         assert_flat_identical(d.shortest_path().to_flat(), ref2, f"after tr_sort, query {q}")
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_shortest_path_tail_in_one_launch(gpu_ctx, oracle, monkeypatch, split):
+    """Repeated queries end in ONE launch (sssp_tail_kernel: final-state search by 128 workgroups, the last one walks back
+    over the transpose and writes the result header into pinned memory) or, with WFST_SSSP_SPLIT_TAIL, in the three
+    kernels + copy of round 1: same FSTs — with a path, without any reachable final state, and with a path longer than
+    the pinned buffer (a 270 k-state chain: the walk gives up and the parent pass takes over)."""
+    if split:
+        monkeypatch.setenv("WFST_SSSP_SPLIT_TAIL", "1")
+    t = synth.make_transducer(50000, 8, 64, 0.05, seed=611)
+    cases = [("path", t)]
+    nofinal = dict(t)
+    nofinal["finals"] = np.full_like(t["finals"], np.inf)
+    cases.append(("no final state", nofinal))
+    n = 270_000  # one arc per state: >= 2^18 arcs, so the second query builds the transpose; 270 k hops
+    arcs = np.zeros(n - 1, dtype=t["arcs"].dtype)
+    arcs["ilabel"] = arcs["olabel"] = 1 + (np.arange(n - 1) % 5)
+    arcs["weight"] = ((np.arange(n - 1) % 7) / 4.0).astype(np.float32)
+    arcs["nextstate"] = np.arange(1, n, dtype=np.uint32)
+    fin = np.full(n, np.inf, dtype=np.float32)
+    fin[-1] = 0.5
+    chain = dict(n_states=n, start=0, offsets=np.concatenate([np.arange(n, dtype=np.uint32), [n - 1]]).astype(np.uint32), arcs=arcs,
+                 finals=fin, props=0)
+    cases.append(("long chain", chain))
+    for name, f in cases:
+        d = to_device(f)
+        ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
+        for q in range(3):
+            assert_flat_identical(d.shortest_path().to_flat(), ref, f"{name}, query {q}, split={split}", check_props=(name != "long chain"))
+
+
 def test_async_shortest_path_matches_sync(gpu_ctx, oracle, monkeypatch):
     """wfst_shortest_path_begin/_end: same FST as the synchronous call and the oracle — on the first queries (no
     prediction, no transpose), on predicted ones (final search + backtrace queued speculatively behind the sweeps),
