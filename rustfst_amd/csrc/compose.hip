@@ -1250,7 +1250,11 @@ struct BatchRun {
   uint32_t eager = 0;
   const wfst_tr* host_paths = nullptr;
   bool string_kernel = false;  // this run went through string_compose_sp_kernel
+  // descriptors read from, results and path arcs written to pinned host memory by the kernel itself: no copy commands
+  // (each is a ~3 us API call on the host and a ~5 us command on the GPU) — when the whole path buffer fits there
+  bool zero_copy = false;
 };
+constexpr uint32_t ZERO_COPY_ARCS = 1u << 18;  // 4 MB of pinned memory per run
 
 inline size_t run_pinned_bytes(size_t n, uint32_t eager) {
   return ((n * (sizeof(ProblemDesc) + sizeof(Result)) + 64 + (size_t)eager * sizeof(wfst_tr)) + 255) & ~(size_t)255;
@@ -1276,25 +1280,30 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   run.d_cursor = DBuf<uint32_t>(pool, 1);
   const uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
   run.path_cap = path_cap;
-  run.paths = DBuf<wfst_tr>(pool, path_cap);
   run.eager = want_paths ? std::min(eager_paths, path_cap) : 0u;
+  run.zero_copy = want_paths && pinned && run.eager == path_cap && !ctx->profiling;
+  run.paths = DBuf<wfst_tr>(pool, run.zero_copy ? 1 : path_cap);
   ProblemDesc* h_desc = (ProblemDesc*)(pinned ? pinned : (char*)ctx->pinned_big.get(run_pinned_bytes(n, run.eager)));
   std::memcpy(h_desc, descs.data(), n * sizeof(ProblemDesc));
-  HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
+  run.h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
+  run.h_cursor = (uint32_t*)((char*)run.h_res + n * sizeof(Result));
+  run.h_eager = (wfst_tr*)((char*)run.h_cursor + 64);
+  const ProblemDesc* k_desc = run.zero_copy ? h_desc : run.d_desc.p;
+  Result* k_res = run.zero_copy ? run.h_res : run.d_res.p;
+  wfst_tr* k_paths = run.zero_copy ? run.h_eager : run.paths.p;
+  if (!run.zero_copy) HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(run.d_cursor.p, 0, sizeof(uint32_t), st));
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev0, st));
   if (string_kernel)
-    string_compose_sp_kernel<<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, run.d_res.p, run.paths.p, path_cap, run.d_cursor.p);
+    string_compose_sp_kernel<<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p);
   else
-    compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(run.d_desc.p, f2, caps, run.arena.p, run.stride, run.d_res.p,
-                                                            run.paths.p, path_cap, run.d_cursor.p);
+    compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, caps, run.arena.p, run.stride, k_res, k_paths, path_cap,
+                                                            run.d_cursor.p);
   HIP_CHECK(hipGetLastError());
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev1, st));
-  run.h_res = (Result*)((char*)h_desc + n * sizeof(ProblemDesc));
-  run.h_cursor = (uint32_t*)((char*)run.h_res + n * sizeof(Result));
+  if (run.zero_copy) return;
   HIP_CHECK(hipMemcpyAsync(run.h_res, run.d_res.p, n * sizeof(Result), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(run.h_cursor, run.d_cursor.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  run.h_eager = (wfst_tr*)((char*)run.h_cursor + 64);
   if (run.eager)
     HIP_CHECK(hipMemcpyAsync(run.h_eager, run.paths.p, (size_t)run.eager * sizeof(wfst_tr), hipMemcpyDeviceToHost, st));
 }
@@ -1323,7 +1332,9 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
                  tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot[4] / n, tot[5] / n, tot[6] / n, n, h_res[0].n_levels);
   }
 #endif
-  if (want_paths) {
+  if (want_paths && run.zero_copy) {
+    run.host_paths = run.h_eager;  // written by the kernel
+  } else if (want_paths) {
     const uint32_t used = std::min<uint32_t>(*h_cursor, path_cap);
     if (used <= run.eager) {
       run.host_paths = run.h_eager;
@@ -1519,7 +1530,14 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
     }
   }
   job->todo.swap(todo_gen);
-  const uint32_t e_s = (uint32_t)std::min<uint64_t>(eager_s, 1u << 22), e_g = (uint32_t)std::min<uint64_t>(eager_g, 1u << 22);
+  uint32_t e_s = (uint32_t)std::min<uint64_t>(eager_s, 1u << 22), e_g = (uint32_t)std::min<uint64_t>(eager_g, 1u << 22);
+  {  // a run whose whole path buffer fits in pinned memory writes there itself (launch_begin: zero_copy)
+    const Caps c0 = make_caps(job->est_s, job->est_a);
+    const uint64_t cap_s = (uint64_t)c0.S * d_str.size(), cap_g = (uint64_t)c0.S * d_gen.size();
+    const bool allow = !std::getenv("WFST_BATCH_COPY");  // tests: the copy-command path
+    if (allow && cap_s && cap_s <= ZERO_COPY_ARCS) e_s = (uint32_t)cap_s;
+    if (allow && cap_g && cap_g <= ZERO_COPY_ARCS) e_g = (uint32_t)cap_g;
+  }
   const size_t pin_s = d_str.empty() ? 0 : run_pinned_bytes(d_str.size(), e_s);
   const size_t pin_g = d_gen.empty() ? 0 : run_pinned_bytes(d_gen.size(), e_g);
   char* pin = (char*)ctx->pinned_big.get(pin_s + pin_g + 256);

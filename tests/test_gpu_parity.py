@@ -1050,6 +1050,20 @@ def test_reverse_and_nbest_with_hub_states(gpu_ctx, oracle, lazy, monkeypatch):
 @pytest.mark.parametrize("kernel", ["1", "0"], ids=["string_kernel", "general_kernel"])
 @pytest.mark.parametrize("seed", range(10))
 def test_string_batch_both_kernels_match_oracle(gpu_ctx, oracle, seed, kernel, monkeypatch):
+    _string_batch_case(gpu_ctx, oracle, seed, kernel, monkeypatch)
+
+
+@pytest.mark.parametrize("kernel", ["1", "0"], ids=["string_kernel", "general_kernel"])
+@pytest.mark.parametrize("seed", [0, 3])
+def test_string_batch_through_copy_commands(gpu_ctx, oracle, seed, kernel, monkeypatch):
+    """The same cases with WFST_BATCH_COPY: descriptors, results and path arcs travel by copy commands (what large
+    batches do) instead of being read from / written to pinned host memory by the kernel itself (the default when the
+    whole path buffer fits there)."""
+    monkeypatch.setenv("WFST_BATCH_COPY", "1")
+    _string_batch_case(gpu_ctx, oracle, seed, kernel, monkeypatch)
+
+
+def _string_batch_case(gpu_ctx, oracle, seed, kernel, monkeypatch):
     """Linear epsilon-free acceptors against an input-epsilon-free T: the specialised string o T kernel and the general
     kernel must both return the oracle's canonical path (ids of the untrimmed composition decide ties: small alphabets
     and integer weights make ties and wide levels frequent), the same composed-arc count, and identical property words."""

@@ -11,20 +11,22 @@ t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
 accs = synth.make_acceptors(t, 64, 200, seed0=1000)
 dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
 daccs = rustfst_amd.DeviceFst.upload_many(accs, ctx2)
-acc = np.zeros(4)
-N = 30
-for it in range(N + 5):
-    torch.cuda.synchronize()
+daccs = rustfst_amd.HandleArray(daccs)
+acc = np.zeros(5)
+N = 200
+for it in range(N + 10):  # bench.py's schedule: batch begin, shortest_path begin, batch finish, shortest_path finish
     a = time.perf_counter()
     job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
     b = time.perf_counter()
-    sp = dt.shortest_path()
+    sp_job = dt.shortest_path_begin()
     c = time.perf_counter()
     outs, na = job.finish()
     d = time.perf_counter()
-    if it >= 5:
-        acc += [b - a, c - b, d - c, d - a]
-print("begin %.1f us | shortest_path(T) %.1f us | finish %.1f us | step %.1f us" % tuple(acc / N * 1e6))
+    sp = sp_job.finish()
+    e = time.perf_counter()
+    if it >= 10:
+        acc += [b - a, c - b, d - c, e - d, e - a]
+print("batch begin %.1f us | shortest_path begin %.1f us | batch finish %.1f us | shortest_path finish %.1f us | step %.1f us" % tuple(acc / N * 1e6))
 # each alone
 for name, fn in (("shortest_path(T) alone", lambda: dt.shortest_path()),
                  ("batch alone", lambda: rustfst_amd.compose_shortest_path_batch(daccs, dt, ctx=ctx2))):
