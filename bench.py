@@ -195,6 +195,7 @@ def main():
         os.remove(f_out)
 
     last = {}
+    phases = [0.0, 0.0, 0.0, 0.0, 0]  # host seconds in: first begin, second begin, batch finish, shortest_path finish; steps
 
     def exchange():
         # RCCL all-gather of this step's result paths: queued asynchronously on the torch stream at the end of the
@@ -217,15 +218,22 @@ def main():
             # S2 first: its one long, narrow kernel (one wave per acceptor) must be in flight BEFORE the chain of
             # GPU-wide relaxation sweeps is queued, or the hardware runs the chain to its end first
             # (tools/ubench_concurrency.hip: 623 us overlapped vs 904 us serialised).
+            p0 = time.perf_counter()
             if args.order == "s2-first":
                 job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
+                p1 = time.perf_counter()
                 # S1 asynchronously too: the host builds the batch's 64 result FSTs while the sweeps are still running
                 sp_job = dt.shortest_path_begin()
             else:
                 sp_job = dt.shortest_path_begin()
+                p1 = time.perf_counter()
                 job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
+            p2 = time.perf_counter()
             outs, n_arcs = job.finish()
+            p3 = time.perf_counter()
             sp = sp_job.finish()
+            p4 = time.perf_counter()
+            phases[:] = [phases[0] + p1 - p0, phases[1] + p2 - p1, phases[2] + p3 - p2, phases[3] + p4 - p3, phases[4] + 1]
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
         if world > 1 or force_dist:
             last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
@@ -271,6 +279,11 @@ def main():
         drain()
         barrier()
         elapsed = time.perf_counter() - t_start
+        step_phases_us = None
+        if args.overlap and phases[4]:
+            # (the counters include the warm-up steps: same code path)
+            step_phases_us = {k: round(1e6 * phases[i] / phases[4], 1) for i, k in
+                              enumerate(("first_begin", "second_begin", "batch_finish", "shortest_path_finish"))}
 
         if world > 1 or force_dist:
             import torch.distributed as dist
@@ -459,6 +472,7 @@ def main():
             "ms_per_step_stats": {"mean": round(float(ms.mean()), 4), "std": round(float(ms.std()), 4), "min": round(float(ms.min()), 4),
                                   "p50": round(float(np.percentile(ms, 50)), 4), "p99": round(float(np.percentile(ms, 99)), 4),
                                   "timed_seconds": round(elapsed, 3), "clock": "host perf_counter per step on rank 0"},
+            "step_host_phases_us": step_phases_us,
             "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist),
             "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),

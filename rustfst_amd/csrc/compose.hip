@@ -1019,14 +1019,22 @@ constexpr uint32_t WIDE_COMPOSE_WIDTH = 64;      // ... and so do results with a
 constexpr uint32_t STR_MAXS = 2048;
 constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
 
-__global__ void __launch_bounds__(64) string_compose_sp_kernel(const ProblemDesc* __restrict__ descs, FstView f2,
-                                                               Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
-                                                               uint32_t path_cap, uint32_t* __restrict__ path_cursor) {
-  __shared__ uint32_t s_par[STR_MAXS];  // predecessor state on the best path into this state (STR_NONE: unreached)
-  __shared__ uint32_t s_ol[STR_MAXS];   // olabel of the arc taken from it
-  __shared__ float s_w[STR_MAXS];       // weight of that arc (w1 (x) w2)
-  __shared__ uint32_t s_pth[STR_MAXS];  // states of the best path, from the final one backwards
-  const uint32_t p = blockIdx.x;
+// One wave = one problem; a workgroup holds blockDim.x / 64 of them, each with its own `maxs`-state slice of the dynamic
+// LDS (the waves never meet: no workgroup barrier anywhere).  Why several waves per workgroup: a resident wave of this
+// kernel blocks its whole CU for the 1024-thread, 128-VGPR workgroups of the mailbox relaxation sweeps (they need every
+// register of all four SIMDs), so 64 lone waves on 64 CUs sent a quarter of every concurrent sweep into a second round;
+// 8 workgroups of 8 waves land on one CU per XCD and leave 31 CUs per XCD to the sweeps' 30-31 workgroups per XCD.
+__global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDesc* __restrict__ descs, FstView f2,
+                                                                Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
+                                                                uint32_t path_cap, uint32_t* __restrict__ path_cursor,
+                                                                uint32_t n_problems, uint32_t maxs) {
+  extern __shared__ uint32_t s_dyn[];
+  const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= n_problems) return;
+  uint32_t* const s_par = s_dyn + (size_t)(threadIdx.x >> 6) * 4u * maxs;  // predecessor state on the best path into this state (STR_NONE: unreached)
+  uint32_t* const s_ol = s_par + maxs;                                      // olabel of the arc taken from it
+  float* const s_w = reinterpret_cast<float*>(s_ol + maxs);                 // weight of that arc (w1 (x) w2)
+  uint32_t* const s_pth = s_ol + 2u * maxs;                                 // states of the best path, from the final one backwards
   const uint32_t lane = lane_id();
   const FstView f1 = descs[p].f1;
   Result res;
@@ -1088,7 +1096,7 @@ __global__ void __launch_bounds__(64) string_compose_sp_kernel(const ProblemDesc
           uint32_t idx;
           if (ex == 0) {
             idx = n_new;
-            if (idx >= 64u || hi + idx >= STR_MAXS) {
+            if (idx >= 64u || hi + idx >= maxs) {
               ok = false;
               break;
             }
@@ -1265,7 +1273,8 @@ inline size_t run_pinned_bytes(size_t n, uint32_t eager) {
 // `string_kernel`: launch string_compose_sp_kernel (no arena) instead of compose_wave_kernel.
 template <uint32_t FLAGS>
 void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
-                  bool want_paths, uint32_t eager_paths = 0, char* pinned = nullptr, bool string_kernel = false) {
+                  bool want_paths, uint32_t eager_paths = 0, char* pinned = nullptr, bool string_kernel = false,
+                  uint32_t max_f1_states = 0) {
   const size_t n = descs.size();
   DevicePool& pool = *ctx->pool;
   hipStream_t st = ctx->stream;
@@ -1294,9 +1303,19 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   if (!run.zero_copy) HIP_CHECK(hipMemcpyAsync(run.d_desc.p, h_desc, n * sizeof(ProblemDesc), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(run.d_cursor.p, 0, sizeof(uint32_t), st));
   if (ctx->profiling) HIP_CHECK(hipEventRecord(ctx->ev0, st));
-  if (string_kernel)
-    string_compose_sp_kernel<<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p);
-  else
+  if (string_kernel) {
+    // waves per workgroup x states per problem: 64 KB of LDS per workgroup at most
+    uint32_t wpb = 1, maxs = STR_MAXS;
+    if (!std::getenv("WFST_STRING_UNPACKED") && n >= 16) {
+      // a string of L arcs against an input-deterministic-ish T composes to a little more than L states; a problem that
+      // outgrows its slice reports ST_NOT_A_STRING_CASE and is redone by the general kernel like any other misfit
+      const uint64_t need = max_f1_states ? 2ull * max_f1_states + 64 : STR_MAXS;
+      maxs = need <= 512 ? 512u : (need <= 1024 ? 1024u : STR_MAXS);
+      wpb = (64u << 10) / (16u * maxs);
+    }
+    string_compose_sp_kernel<<<(uint32_t)((n + wpb - 1) / wpb), 64 * wpb, (size_t)wpb * 16u * maxs, st>>>(
+        k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p, (uint32_t)n, maxs);
+  } else
     compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, caps, run.arena.p, run.stride, k_res, k_paths, path_cap,
                                                             run.d_cursor.p);
   HIP_CHECK(hipGetLastError());
@@ -1513,6 +1532,7 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   std::vector<ProblemDesc> d_str, d_gen;
   std::vector<size_t> todo_gen;
   uint64_t eager_s = 0, eager_g = 0;  // a path through A_i o T has at most |A_i| - 1 arcs unless T loops on input epsilons
+  uint32_t max_str_states = 0;
   if (string_ok) {
     job->v2_s = job->v2;
     job->v2_s.anext = ensure_anext(ctx, t);
@@ -1523,6 +1543,7 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
       job->todo_s.push_back(i);
       d_str.push_back(job->descs[i]);
       eager_s += accs[i]->n_states;
+      max_str_states = std::max(max_str_states, accs[i]->n_states);
     } else {
       todo_gen.push_back(i);
       d_gen.push_back(job->descs[i]);
@@ -1542,7 +1563,7 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   const size_t pin_g = d_gen.empty() ? 0 : run_pinned_bytes(d_gen.size(), e_g);
   char* pin = (char*)ctx->pinned_big.get(pin_s + pin_g + 256);
   if (!d_str.empty())
-    launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true);
+    launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true, max_str_states);
   if (!d_gen.empty())
     launch_begin<FLAG_SP>(ctx, d_gen, job->v2, make_caps(job->est_s, job->est_a), job->run, true, e_g, pin + pin_s, false);
   return job.release();

@@ -1095,6 +1095,27 @@ def _string_batch_case(gpu_ctx, oracle, seed, kernel, monkeypatch):
     assert n_arcs == want_arcs
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_string_batch_packed_workgroups(gpu_ctx, oracle, seed):
+    """Batches of 16 or more strings run several waves per workgroup, every wave with its own slice of LDS sized from the
+    longest acceptor; with a small alphabet some compositions outgrow their slice and are redone by the general kernel.
+    Every result is the oracle's canonical path."""
+    rng = np.random.default_rng(15_000 + seed)
+    sigma = 2 + seed
+    t = random_fst_flat(rng, 40, 5, sigma, p_final=0.3, sort="ilabel", min_fanout=1, weight_grid=512)
+    accs = [synth.linear_acceptor_flat(rng.integers(1, sigma + 1, int(rng.integers(1, 90))).astype(np.uint32), final_weight=0.25 * (k % 3))
+            for k in range(27)]
+    ctx = rustfst_amd.default_context()
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs, ctx), to_device(t))
+    ot = to_oracle(oracle, t)
+    want_arcs = 0
+    for k, (a, out) in enumerate(zip(accs, outs)):
+        oc = to_oracle(oracle, a).compose(ot, connect=False)
+        want_arcs += oc.num_arcs
+        assert_flat_identical(out.to_flat(), oc.shortest_path_canonical().to_flat(), f"seed {seed} string {k}")
+    assert n_arcs == want_arcs
+
+
 def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
     """Levels wider than one wave, input epsilons in T, epsilons or branching in fst1, explicit non-sequence filters: the
     batch silently takes the general kernel (per problem) and still matches the oracle."""
