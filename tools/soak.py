@@ -74,8 +74,13 @@ while time.time() < t_end:
             # ... and linear acceptors (the string o T kernel when t has no input epsilons), small alphabet => ties
             from rustfst_amd import synth as _synth
             accs += [_synth.linear_acceptor_flat(rng.integers(1, 3 if seed % 3 else 5, int(rng.integers(0, 30))).astype(np.uint32),
-                                                 final_weight=float(rng.integers(0, 3))) for _ in range(int(rng.integers(0, 5)))]
+                                                 final_weight=float(rng.integers(0, 3)))
+                     for _ in range(int(rng.integers(16, 40)) if seed % 4 == 0 else int(rng.integers(0, 5)))]  # 16+: packed workgroups
             os.environ["WFST_STRING_KERNEL"] = str(int(rng.integers(0, 2)))
+            if rng.integers(0, 2):
+                os.environ["WFST_BATCH_COPY"] = "1"  # results by copy commands instead of kernel writes to pinned memory
+            else:
+                os.environ.pop("WFST_BATCH_COPY", None)
             flt = FILTERS[int(rng.integers(0, len(FILTERS)))]
             outs, _ = rustfst_amd.compose_shortest_path_batch([to_device(x) for x in accs], to_device(t), ComposeConfig(flt))
             ot = to_oracle(O, t)
