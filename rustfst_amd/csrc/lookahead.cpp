@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <thread>
 #include <unordered_map>
 
 #include "common.h"
@@ -109,33 +111,51 @@ void normalize(Intervals& iv) {
   iv.resize(w);
 }
 
-// IntervalReachVisitor (interval_reach_visitor.rs:28-96)
+// IntervalReachVisitor (interval_reach_visitor.rs:28-96).  The reference keeps one IntervalSet per state and pours a
+// child's set into its parent when the child is finished (tree arcs) or met again (cross arcs).  On an acyclic graph every
+// successor of s is finished when s is, so the same set — the normalised union over s's arcs of the successors' sets,
+// plus s's own interval if it is final — is assembled here in ONE go at finish(s), from a flat arena that holds every
+// finished state's intervals back to back: no vector per state (five million small allocations were most of the visit),
+// and the per-state CSR the caller wants is a copy out of the arena.
 struct ReachVisitor {
   const Graph& g;
-  std::vector<Intervals> sets;
-  std::vector<uint32_t> state2index;
+  Intervals arena;                     // intervals of the finished states, in finishing order
+  std::vector<uint64_t> set_off;       // [n] first interval of the state in the arena
+  std::vector<uint32_t> set_len;       // [n]
+  std::vector<uint32_t> state2index, own_begin;
+  Intervals scratch;
   uint32_t index = 1;
+  bool cyclic = false;
   // the super-initial state (the visit's root) would collect the sets of every state nothing points at — millions of
   // intervals to sort for a set that find_intervals drops (label_reachable.rs:258): it is left empty
   uint32_t root;
-  explicit ReachVisitor(const Graph& gr) : g(gr), sets(gr.n()), state2index(gr.n(), UNASSIGNED), root(gr.start) {}
+  explicit ReachVisitor(const Graph& gr)
+      : g(gr), set_off(gr.n(), 0), set_len(gr.n(), 0), state2index(gr.n(), UNASSIGNED), own_begin(gr.n(), 0), root(gr.start) {
+    arena.reserve(gr.dst.size() / 2 + gr.n());
+  }
   void discover(uint32_t s) {
     if (g.is_final[s]) {
-      sets[s].push_back({index, index + 1});
+      own_begin[s] = index;
       state2index[s] = index;
       index++;
-    } else {
-      sets[s].reserve(g.off[s + 1] - g.off[s] + 1);  // one interval per arc before normalize: one allocation, not five
     }
   }
-  void back(uint32_t, uint32_t) { throw Error("IntervalReachVisitor: cyclic input"); }
-  void cross(uint32_t s, uint32_t t) {
-    if (s != root) sets[s].insert(sets[s].end(), sets[t].begin(), sets[t].end());
-  }
-  void finish(uint32_t s, bool has_parent, uint32_t parent) {
-    if (g.is_final[s]) sets[s][0].second = index;  // every final state discovered below s has an index in [mine, index)
-    normalize(sets[s]);
-    if (has_parent && parent != root) sets[parent].insert(sets[parent].end(), sets[s].begin(), sets[s].end());
+  void back(uint32_t, uint32_t) { cyclic = true; }  // (the caller falls back to the condensation)
+  void cross(uint32_t, uint32_t) {}
+  void finish(uint32_t s, bool, uint32_t) {
+    if (cyclic) return;
+    scratch.clear();
+    if (g.is_final[s]) scratch.push_back({own_begin[s], index});  // every final state discovered below s has an index in [mine, index)
+    if (s != root)
+      for (uint32_t k = g.off[s]; k < g.off[s + 1]; ++k) {
+        const uint32_t t = g.dst[k];
+        const auto* b = arena.data() + set_off[t];
+        scratch.insert(scratch.end(), b, b + set_len[t]);
+      }
+    normalize(scratch);
+    set_off[s] = arena.size();
+    set_len[s] = (uint32_t)scratch.size();
+    arena.insert(arena.end(), scratch.begin(), scratch.end());
   }
 };
 
@@ -179,27 +199,37 @@ struct SccVisitor {
 };
 
 // StateReachable::new (state_reachable.rs:26-76): interval sets + discovery index of the final states; cyclic inputs go
-// through their condensation (no final state may lie on a cycle)
-void state_reachable(const Graph& g, std::vector<Intervals>& sets, std::vector<uint32_t>& state2index) {
+// through their condensation (no final state may lie on a cycle).  The sets come back as slices of one arena.
+struct ReachSets {
+  Intervals arena;
+  std::vector<uint64_t> off;  // per state of g
+  std::vector<uint32_t> len;
+  std::vector<uint32_t> state2index;
+};
+void state_reachable(const Graph& g, ReachSets& out) {
   const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
   };
   const auto t0 = now();
-  // one visit answers "acyclic?" (no back arc: compute_and_update_properties(ACYCLIC), label_reachable.rs:146) and, if
-  // not, already holds the components of the condensation
-  SccVisitor sv(g.n());
-  depth_first(g, sv);
-  const auto t1 = now();
-  if (timing) std::fprintf(stderr, "[wfst]   scc visit %.1f ms (cyclic %d)\n", ms(t0, t1), (int)sv.cyclic);
-  if (!sv.cyclic) {
+  {
+    // the visit that builds the sets also answers "acyclic?" (no back arc: compute_and_update_properties(ACYCLIC),
+    // label_reachable.rs:146); decoding graphs are acyclic in their epsilon structure, so this is usually all there is
     ReachVisitor rv(g);
     depth_first(g, rv);
-    sets = std::move(rv.sets);
-    state2index = std::move(rv.state2index);
-    return;
+    if (timing) std::fprintf(stderr, "[wfst]   reach visit %.1f ms (cyclic %d)\n", ms(t0, now()), (int)rv.cyclic);
+    if (!rv.cyclic) {
+      out.arena = std::move(rv.arena);
+      out.off = std::move(rv.set_off);
+      out.len = std::move(rv.set_len);
+      out.state2index = std::move(rv.state2index);
+      return;
+    }
   }
+  const auto t1 = now();
+  SccVisitor sv(g.n());
+  depth_first(g, sv);
   sv.done();
   const uint32_t nc = (uint32_t)sv.nscc;
   Graph c;  // condense (condense.rs:15-55): arcs between different components, in source-state then arc order
@@ -227,17 +257,21 @@ void state_reachable(const Graph& g, std::vector<Intervals>& sets, std::vector<u
   const auto t2 = now();
   ReachVisitor rv(c);
   depth_first(c, rv);
+  if (rv.cyclic) throw Error("IntervalReachVisitor: cyclic input");  // (a condensation is acyclic)
   const auto t3 = now();
-  sets.assign(g.n(), Intervals());
-  state2index.assign(g.n(), UNASSIGNED);
+  out.arena = std::move(rv.arena);
+  out.off.assign(g.n(), 0);
+  out.len.assign(g.n(), 0);
+  out.state2index.assign(g.n(), UNASSIGNED);
   for (uint32_t s = 0; s < g.n(); ++s) {
     const uint32_t cs = (uint32_t)sv.scc[s];
     if (c.is_final[cs] && members[cs] > 1) throw Error("StateReachable: Final state contained in a cycle");
-    sets[s] = rv.sets[cs];
-    state2index[s] = rv.state2index[cs];
+    out.off[s] = rv.set_off[cs];
+    out.len[s] = rv.set_len[cs];
+    out.state2index[s] = rv.state2index[cs];
   }
   if (timing)
-    std::fprintf(stderr, "[wfst]   condense %.1f ms, reach visit %.1f ms, copy back %.1f ms\n", ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    std::fprintf(stderr, "[wfst]   scc + condense %.1f ms, reach visit %.1f ms, copy back %.1f ms\n", ms(t1, t2), ms(t2, t3), ms(t3, now()));
 }
 
 }  // namespace
@@ -291,20 +325,22 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
   g.start = start;
 
   const auto t_graph = now();
-  std::vector<Intervals> sets;
-  std::vector<uint32_t> state2index;
-  state_reachable(g, sets, state2index);
+  ReachSets sets;
+  state_reachable(g, sets);
+  const std::vector<uint32_t>& state2index = sets.state2index;
   const auto t_reach = now();
 
   iv_off.assign((size_t)ins + 1, 0);
-  iv.clear();
+  uint64_t total = 0;
   for (uint32_t s = 0; s < ins; ++s) {
-    for (const auto& p : sets[s]) {
-      iv.push_back(p.first);
-      iv.push_back(p.second);
-    }
-    iv_off[s + 1] = (uint32_t)(iv.size() / 2);
+    total += sets.len[s];
+    if (total > 0xFFFFFFFFull) throw Error("LabelReachable: more than 2^32 intervals");
+    iv_off[s + 1] = (uint32_t)total;
   }
+  static_assert(sizeof(std::pair<uint32_t, uint32_t>) == 8, "an interval is two packed words");
+  iv.resize(2 * (size_t)total);
+  for (uint32_t s = 0; s < ins; ++s)
+    if (sets.len[s]) std::memcpy(iv.data() + 2 * (size_t)iv_off[s], sets.arena.data() + sets.off[s], (size_t)sets.len[s] * 8);
   for (uint32_t k = 0; k < sink_label.size(); ++k) {
     const uint32_t idx = state2index[ins + k];
     label2index[sink_label[k]] = idx;
@@ -331,13 +367,25 @@ uint64_t LabelReachData::relabel_fst(uint32_t n_states, const uint32_t* offsets,
   uint64_t p = props_in;
   const uint64_t keep = props::ACCEPTOR | props::NOT_ACCEPTOR | props::EPSILONS | props::NO_EPSILONS | props::I_EPSILONS |
                         props::NO_I_EPSILONS | props::O_EPSILONS | props::NO_O_EPSILONS | props::WEIGHTED | props::UNWEIGHTED;
+  // labels of decoding graphs are small integers: a table in front of the map (fifty million hash lookups were a third
+  // of wfst_lookahead_create on the 5M-state graph); unseen labels still get their index in order of first appearance
+  constexpr uint32_t LUT_MAX = 1u << 22;
+  std::vector<uint32_t> lut;
+  auto relabel_fast = [&](uint32_t label) -> uint32_t {
+    if (label == 0) return 0;
+    if (label >= LUT_MAX) return relabel(label);
+    if (label >= lut.size()) lut.resize(std::min<size_t>(LUT_MAX, std::max<size_t>(2 * (size_t)label + 2, 1024)), UNASSIGNED);
+    uint32_t& v = lut[label];
+    if (v == UNASSIGNED) v = relabel(label);
+    return v;
+  };
   for (uint64_t k = 0; k < offsets[n_states]; ++k) {
     wfst_tr& tr = arcs[k];
     const uint32_t oi = tr.ilabel, oo = tr.olabel;
     if (relabel_input)
-      tr.ilabel = relabel(tr.ilabel);
+      tr.ilabel = relabel_fast(tr.ilabel);
     else
-      tr.olabel = relabel(tr.olabel);
+      tr.olabel = relabel_fast(tr.olabel);
     const uint32_t ni = tr.ilabel, no = tr.olabel;
     if (oi != oo) p &= ~props::NOT_ACCEPTOR;
     if (oi == 0) {
@@ -363,13 +411,45 @@ uint64_t LabelReachData::relabel_fst(uint32_t n_states, const uint32_t* offsets,
     }
     p &= keep;
   }
-  for (uint32_t s = 0; s < n_states; ++s) {
-    wfst_tr* b = arcs + offsets[s];
-    wfst_tr* e = arcs + offsets[s + 1];
-    if (relabel_input)
-      std::stable_sort(b, e, [](const wfst_tr& x, const wfst_tr& y) { return x.ilabel < y.ilabel; });
-    else
-      std::stable_sort(b, e, [](const wfst_tr& x, const wfst_tr& y) { return x.olabel < y.olabel; });
+  // tr_sort (stable) of every state's arcs on the relabelled column: states are independent, so the range is cut over a
+  // few host threads; short rows (the rule) by insertion sort — std::stable_sort allocates a buffer per call
+  auto sort_range = [&](uint32_t s_lo, uint32_t s_hi) {
+    auto keyof = [relabel_input](const wfst_tr& x) { return relabel_input ? x.ilabel : x.olabel; };
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
+      wfst_tr* b = arcs + offsets[s];
+      wfst_tr* e = arcs + offsets[s + 1];
+      if (e - b <= 48) {
+        for (wfst_tr* i = b + 1; i < e; ++i) {
+          const wfst_tr v = *i;
+          wfst_tr* j = i;
+          for (; j > b && keyof(*(j - 1)) > keyof(v); --j) *j = *(j - 1);
+          *j = v;
+        }
+      } else {
+        std::stable_sort(b, e, [&](const wfst_tr& x, const wfst_tr& y) { return keyof(x) < keyof(y); });
+      }
+    }
+  };
+  const uint64_t n_arcs = offsets[n_states];
+  unsigned n_thr = n_arcs >= (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (n_thr <= 1) {
+    sort_range(0, n_states);
+  } else {
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errs(n_thr);
+    for (unsigned t = 0; t < n_thr; ++t) {
+      const uint32_t lo = (uint32_t)((uint64_t)n_states * t / n_thr), hi = (uint32_t)((uint64_t)n_states * (t + 1) / n_thr);
+      pool.emplace_back([&, lo, hi, t] {
+        try {
+          sort_range(lo, hi);
+        } catch (...) {
+          errs[t] = std::current_exception();
+        }
+      });
+    }
+    for (auto& th : pool) th.join();
+    for (auto& e : errs)
+      if (e) std::rethrow_exception(e);
   }
   return tr_sort_props(p, relabel_input);
 }

@@ -1209,6 +1209,35 @@ def test_lookahead_compose_matches_oracle(gpu_ctx, oracle, seed):
     assert tot(w1) == tot(w2)
 
 
+def test_lookahead_relabelling_of_large_operands(gpu_ctx, oracle):
+    """Operands of more than 2^20 arcs: the host side of wfst_lookahead_create / _relabel goes through its table-driven
+    relabelling and sorts the states' arcs on several host threads; relabelled fst1, relabelled fst2 (with labels fst1
+    never emits) and the composition with a tiny second operand are the oracle's, bit for bit."""
+    a = _swap_labels(synth.make_transducer(120_000, 9, 300, 0.1, seed=41, p_final=0.02))
+    b_big = synth.make_transducer(110_000, 10, 340, 0.05, seed=42, p_final=0.02)  # labels 301..340 are new to fst1
+    b_small = synth.make_transducer(3, 4, 300, 0.0, seed=43, p_final=0.5)
+    assert a["offsets"][-1] >= 1 << 20 and b_big["offsets"][-1] >= 1 << 20
+    oa = to_oracle(oracle, a)
+    ref, r1, r2 = oa.compose_lookahead(to_oracle(oracle, b_small), want_relabeled=True)
+    la = rustfst_amd.LookAhead(to_device(a))
+    assert_flat_identical(la.fst1.to_flat(), r1.to_flat(), "relabelled fst1 (1.08 M arcs)")
+    d2 = la.relabel(to_device(b_small))
+    assert_flat_identical(d2.to_flat(), r2.to_flat(), "relabelled small fst2")
+    assert_flat_identical(la.compose(d2).to_flat(), ref.to_flat(), "look-ahead composition")
+    # the big second operand starts in an extra state without arcs, so the composition is one state while the relabelling
+    # still rewrites and re-sorts 1.1 M arcs
+    nb = b_big["n_states"]
+    iso = dict(b_big)
+    iso["n_states"] = nb + 1
+    iso["start"] = nb
+    iso["offsets"] = np.concatenate([b_big["offsets"], b_big["offsets"][-1:]]).astype(np.uint32)
+    iso["finals"] = np.concatenate([b_big["finals"], np.array([np.inf], np.float32)]).astype(np.float32)
+    ref_b, _, r2_big = oa.compose_lookahead(to_oracle(oracle, iso), want_relabeled=True)
+    d2_big = la.relabel(to_device(iso))
+    assert_flat_identical(d2_big.to_flat(), r2_big.to_flat(), "relabelled fst2 (1.1 M arcs, labels fst1 never emits)")
+    assert_flat_identical(la.compose(d2_big).to_flat(), ref_b.to_flat(), "look-ahead composition from an isolated start state")
+
+
 def _swap_labels(t):
     """output-epsilon version of a synthetic transducer (its epsilons sit on the input side): swap the label columns and
     re-sort by olabel"""
