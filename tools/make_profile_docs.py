@@ -59,24 +59,27 @@ if atomic_pmc:
            subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), atomic_pmc]).decode(), "```\n"]
 md += ["## `string_compose_sp_kernel` (fused batch: 64 linear acceptors of 200 labels against the 1M-state T; `tools/pmc_batch.sh`)\n```\n",
        read("pmc_string.txt"), "```\n",
-       "Reading (per wave and BFS level; SQ rows are per shader-engine instance = 2 waves, so divide the `per launch` column by 2 × 201): "
-       "≈ 62 VALU + 80 SALU + 2 VMEM + 4 LDS instructions; SQ_WAVE_CYCLES 209.8 k quad-cycles per instance = 2 087 cycles per wave-level, of "
-       "which SQ_WAIT_ANY 63 % (≈ 1 310 cycles: ONE dependent miss — TCC_MISS 3.7 vs TCC_HIT 0.65 per wave-level, i.e. the arc block and "
-       "its `anext` words come from beyond the L2 in one trip) and SQ_ACTIVE_INST_ANY 36 % (≈ 760 cycles for ≈ 150 instructions of a lone "
-       "wave, ≈ 5 cycles each).  Kernel time / 201 levels = 0.75 µs alone (0.97 µs beside the relaxation in `bench.py`).\n"]
+       "Reading (per wave and BFS level): the kernel is one dependent chain per problem — per level ≈ 62 VALU + 80 SALU + 2 VMEM + 4 LDS "
+       "instructions of a lone wave (≈ 5 cycles each) and ONE dependent miss (TCC_MISS ≫ TCC_HIT: the arc block and its `anext` words come "
+       "from beyond the L2 in one trip); SQ_WAIT_ANY against SQ_ACTIVE_INST_ANY gives the split (≈ 63 % / 36 % when it was measured with one "
+       "wave per workgroup, `profiles/r02k`).  Since then a workgroup holds 8 problems (DESIGN.md §3.1): the SQ rows are per shader-engine "
+       f"instance and now cover several waves each.  Kernel time per BFS level in the bench line of this set: {d.get('batch_kernel', {}).get('us_per_bfs_level')} µs.\n"]
 open(os.path.join(dst, f"{tag}_counters.md"), "w").write("\n".join(md))
 
 # wide compose
 md = [f"# {tag} — the wide composition driver (commit {head})\n",
-      "`rocprofv3 --kernel-trace -- python tools/lookahead_timing.py 10000,100,3,16,16`: one look-ahead composition (1.22 M states / "
-      "4.27 M arcs) and one plain composition (1.11 M states / 3.9 M arcs) of the same pair, each run twice (warm-up + timed).  Since "
-      "round 1: the arena grows in place and the search continues from the level that did not fit (no restart), the first arena holds "
-      "256 k states, the wave-per-problem kernel hands over as soon as a level is wider than 64 states.\n",
+      "`rocprofv3 --kernel-trace -- python tools/lookahead_timing.py 10000,100,3,16,16`: the look-ahead composition (1.22 M states / "
+      "4.27 M arcs), the plain composition without connect (1.11 M states / 3.9 M arcs) and the default `compose()` (with connect) of the "
+      "same pair, each once as warm-up and three times timed.  The driver as of this set (DESIGN.md §3.7): 8 lanes per composed state, "
+      "three launches per level (`la_emit`, `la_first`, `la_assign`) that read the level's id range from the control block, up to 8 "
+      "levels queued per host look, the arena grown in place and ahead of the level that would not fit.\n",
       cap(rocpd_summary.trace, os.path.join(src, "wide_results.db")),
       "\n## end-to-end times of the tool (warm), oracle-identical where the oracle was run\n```\n", read("wide_timing.txt"), "```\n",
-      "(gpu_ms = look-ahead composition on the GPU, cpu_ms = the oracle's, plain_gpu_ms = `compose(connect=False)` of the same pair, states in "
-      "parentheses.)  Round 1: 4.2 / 5.4 / 8.5 / 27.8 ms for the four plain compositions, 1.7 / 4.4 / 11.4 / 39.7 ms with look-ahead.\n"]
+      "(gpu_ms = look-ahead composition on the GPU, cpu_ms = the oracle's, plain_gpu_ms = `compose(connect=False)` of the same pair, the last "
+      "column the default `compose()` with connect; states in parentheses; best of three.)  Round 1: 4.2 / 5.4 / 8.5 / 27.8 ms for the four "
+      "plain compositions, 1.7 / 4.4 / 11.4 / 39.7 ms with look-ahead.\n"]
 open(os.path.join(dst, f"{tag}_wide_compose.md"), "w").write("\n".join(md))
-open(os.path.join(dst, f"{tag}_kdelta_gap.txt"), "w").write(read("kdelta_gap.txt"))
-open(os.path.join(dst, f"{tag}_rm_epsilon_timing.txt"), "w").write(read("rm_epsilon_timing.txt"))
+for name in ("kdelta_gap.txt", "rm_epsilon_timing.txt", "step_breakdown.txt"):  # (optional parts of the set)
+    if os.path.exists(os.path.join(src, name)):
+        open(os.path.join(dst, f"{tag}_{name}"), "w").write(read(name))
 print("written")
