@@ -5,7 +5,7 @@ rows = {}
 for db in sorted(glob.glob(os.path.join(out, "*_results.db"))):
     c = sqlite3.connect(db)
     try:
-        n_solves = c.execute("select count(*) from pmc_events where name like '%sssp_final_kernel%' group by counter_name").fetchone()
+        n_solves = c.execute("select count(*) from pmc_events where name like '%setup_kernel%' group by counter_name").fetchone()
     except sqlite3.Error as e:
         print(f"{db}: {e}")
         continue

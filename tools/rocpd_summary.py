@@ -34,7 +34,7 @@ def trace(path):
         rel = [(e - s) for name, s, e in rows if kname + "(" in name]
         if not rel:
             continue
-        n_solves = sum(1 for name, _, _ in rows if "sssp_final_kernel" in name) or 1
+        n_solves = sum(1 for name, _, _ in rows if "setup_kernel" in name) or 1
         work = [d for d in rel if d >= 5500]  # launches after convergence inside a batch only find an empty frontier
         per_solve = sum(rel) / n_solves / 1e3
         print()
@@ -52,7 +52,7 @@ def pmc(fetch_db, write_db):
         for name, cname, n, tot in c.execute(
                 "select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
             out[name] = (cname, n, tot)
-        nsolves = c.execute("select count(*) from pmc_events where name like '%sssp_final_kernel%'").fetchone()[0]
+        nsolves = c.execute("select count(*) from pmc_events where name like '%setup_kernel%'").fetchone()[0]
         return out, max(1, nsolves)
     f, nf = load(fetch_db)
     w, nw = load(write_db)
@@ -78,7 +78,8 @@ def timeline(path, which=-1):
     if not setups:
         return
     i0 = setups[which]
-    i1 = next((i for i in range(i0, len(rows)) if "sssp_header_kernel" in rows[i][0]), len(rows) - 1)
+    # the solve ends with its tail: sssp_tail_kernel (repeated queries) or the header kernel of the three-launch tail
+    i1 = next((i for i in range(i0, len(rows)) if "sssp_header_kernel" in rows[i][0] or "sssp_tail_kernel" in rows[i][0]), len(rows) - 1)
     print("| # | kernel | us | gap before (us) |")
     print("|---:|---|---:|---:|")
     tot = gaps = 0
