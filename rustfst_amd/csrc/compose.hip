@@ -1672,7 +1672,7 @@ wfst_ctx* batch_job_ctx(const wfst_batch_job* job) { return job->ctx; }
 
 void compose_shortest_path_batch_abandon(wfst_batch_job* job) {
   if (!job) return;
-  if (job->n) hipStreamSynchronize(job->ctx->stream);  // the kernel may still be writing into the job's buffers
+  if (job->n) (void)hipStreamSynchronize(job->ctx->stream);  // the kernel may still be writing into the job's buffers
   delete job;
 }
 
