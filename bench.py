@@ -76,6 +76,15 @@ def parse_args():
     return args
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -495,11 +504,18 @@ def main():
             "reference_harness_split": harness,
             "roofline": roofline, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        out_line = json.dumps(out)
+    # RCCL prints a version banner through C stdio when its communicator comes up; piped, that buffer only drains at exit
+    # and the banner would land BEHIND the result line.  Everybody drains it now, rank 0 prints the line last.
+    _flush_c_stdio()
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
+    if rank == 0:
+        print(out_line, flush=True)
+    if world > 1 or force_dist:
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 if __name__ == "__main__":
