@@ -206,17 +206,20 @@ def main():
     last = {}
     phases = [0.0, 0.0, 0.0, 0.0, 0]  # host seconds in: first begin, second begin, batch finish, shortest_path finish; steps
 
+    xstream = torch.cuda.Stream(device=device) if (world > 1 or force_dist) else None
+
     def exchange():
-        # RCCL all-gather of this step's result paths: queued asynchronously on the torch stream at the end of the
-        # step and collected one step later, so the communication overlaps with the next step's compute; the last
-        # one is drained before the closing barrier, inside the timed region.  (Issuing it earlier in the step,
-        # between the batch kernel and shortest_path(T), stalls the step by ~0.4 ms: its kernels then queue between
-        # the two compute streams.)
+        # RCCL all-gather of this step's batch results: packed and queued as soon as the batch is collected, WHILE the
+        # relaxation sweeps of the same step are still running (the host would only wait for them), on a stream of its
+        # own (the copies and the collective depend on host memory only: queued on the solve's stream they would sit
+        # behind its sweeps and in front of the next solve's), and collected one step later; the last one is drained
+        # before the closing barrier, inside the timed region.
         if last.get("pending") is not None:
             last["gathered"] = last["pending"].result()
             last["pending"] = None
         if last.get("to_send") is not None:
-            last["pending"] = wdist.gather_paths_async(last["to_send"], world, device)
+            with torch.cuda.stream(xstream):
+                last["pending"] = wdist.gather_paths_async(last["to_send"], world, device)
             last["to_send"] = None
 
     def step():
@@ -240,11 +243,14 @@ def main():
             p2 = time.perf_counter()
             outs, n_arcs = job.finish()
             p3 = time.perf_counter()
+            if world > 1 or force_dist:
+                last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
+                exchange()
             sp = sp_job.finish()
             p4 = time.perf_counter()
             phases[:] = [phases[0] + p1 - p0, phases[1] + p2 - p1, phases[2] + p3 - p2, phases[3] + p4 - p3, phases[4] + 1]
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
-        if world > 1 or force_dist:
+        if (world > 1 or force_dist) and not args.overlap:
             last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
             exchange()
         return e_t + 2 * n_arcs
