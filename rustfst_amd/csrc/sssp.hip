@@ -587,10 +587,23 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
                                                          const uint2* __restrict__ wn, const uint32_t* __restrict__ rev_off,
                                                          const uint2* __restrict__ rev_arc, wfst_tr* __restrict__ out,
-                                                         uint32_t out_cap, TailOut* __restrict__ hout) {
+                                                         uint32_t out_cap, TailOut* __restrict__ hout,
+                                                         uint32_t* __restrict__ improved_ring, uint32_t adv_count,
+                                                         uint32_t* __restrict__ host_ring) {
   __shared__ unsigned long long s_best[16];
   __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
+  if (adv_count && blockIdx.x == 0 && threadIdx.x < 64) {
+    // closes the sweep batch queued in front of this launch (what sssp_advance_kernel does: the flags of its sweeps go to
+    // pinned host memory, the slots half a ring ahead are recycled, the base moves on) — one launch and one flush of
+    // host-memory writes less at the end of a predicted solve
+    const uint32_t base = ctl->base;
+    for (uint32_t i = threadIdx.x; i < adv_count; i += 64) {
+      host_ring[(base + i) % IMP_RING] = improved_ring[(base + i) % IMP_RING];
+      improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
+    }
+    if (threadIdx.x == 0) ctl->base = base + adv_count;  // (every lane of the wave has read the old value above)
+  }
   unsigned long long best = KEY_INF;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const float f = finals[s];
@@ -803,7 +816,8 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
     sssp_mboxa_kernel<<<sv.mav.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mav, n, sv.improved.p, sv.ctl.p,
                                                         abs_sweep, sv.delta, sv.ma_rounds, profile);
   else if (sv.mbox)
-    sssp_mbox_kernel<<<sv.mv.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, j & 1u, n, sv.improved.p,
+    // (message parity from the ABSOLUTE sweep index: mailbox batches may hold an odd number of sweeps)
+    sssp_mbox_kernel<<<sv.mv.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n, sv.improved.p,
                                                       sv.ctl.p, abs_sweep, sv.delta, sv.near_low, profile);
   else
     sssp_relax_kernel<<<sv.blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u], sv.fl[(j & 1u) ^ 1u], n,
@@ -943,9 +957,12 @@ struct SweepDriver {
     // A batch boundary costs ~14 us of idle GPU (profiles/r01d), so the FIRST batch of a solve is sized to what the
     // previous solve of this FST needed (+1 sweep to see the quiet one, rounded up to an even count; batch sizes stay
     // even because the flag parity of a sweep inside a batch is static).
+    // The mailbox sweeps are deterministic (owner-computes: the same sweeps change the same keys every time), so a
+    // repeated query gets EXACTLY the sweeps the last one needed, quiet one included: an idle launch is ~5 us.
     const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, (last_sweeps + 1 + 1) & ~1u);
-    predicted = last_sweeps != 0 && last_sweeps < first_count;
+    const bool exact = sv->mbox && !sv->mboxa;
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, exact ? last_sweeps : ((last_sweeps + 1 + 1) & ~1u));
+    predicted = last_sweeps != 0 && (exact ? last_sweeps <= first_count : last_sweeps < first_count);
     evs[0] = ctx->ev0;
     evs[1] = ctx->ev1;
   }
@@ -1014,7 +1031,9 @@ struct SweepDriver {
     return g.exec;
   }
 
-  SweepBatch enqueue_batch(hipEvent_t ev) {
+  // `defer_advance`: the caller queues a kernel behind the batch that closes it (sssp_tail_kernel mirrors the flags and
+  // advances the base itself) and records the event
+  SweepBatch enqueue_batch(hipEvent_t ev, bool defer_advance = false) {
     hipStream_t st = ctx->stream;
     // after the first batch: constant small batches while the solve is shallow, larger ones for deep lattices
     SweepBatch b{next_sweep, 8u, 1};
@@ -1026,13 +1045,14 @@ struct SweepDriver {
       // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
       // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
       for (uint32_t j = 0; j < b.count; ++j) launch_sweep(f, *sv, n, st, j, j, b.first + j, 0u);
-      sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
+      if (!defer_advance) sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
       HIP_CHECK(hipGetLastError());
     }
-    HIP_CHECK(hipEventRecord(ev, st));
+    if (!defer_advance) HIP_CHECK(hipEventRecord(ev, st));
     next_sweep += b.count;
     return b;
   }
+  uint32_t* host_flags(const SweepBatch& b) const { return h_imp + b.which * IMP_RING; }
 
   bool scan_flags(const SweepBatch& b) {  // true when a sweep of the batch changed nothing
     const uint32_t* hf = h_imp + b.which * IMP_RING;
@@ -1043,7 +1063,7 @@ struct SweepDriver {
     return false;
   }
 
-  void start() { cur = enqueue_batch(evs[0]); }
+  void start(bool defer_advance = false) { cur = enqueue_batch(evs[0], defer_advance); }
 
   void finish() {
     int which = 0;
@@ -1243,7 +1263,8 @@ namespace wfst {
 namespace {
 constexpr uint32_t PATH_PINNED = 4096;  // arcs of the path written straight into pinned memory by the backtrace
 
-void queue_tail(wfst_sp_job* j) {
+// `adv`: the sweep batch this tail closes (enqueued with defer_advance), or null
+void queue_tail(wfst_sp_job* j, const SweepBatch* adv = nullptr) {
   wfst_ctx* ctx = j->ctx;
   const wfst_fst* f = j->f;
   const uint32_t n = f->n_states;
@@ -1252,10 +1273,11 @@ void queue_tail(wfst_sp_job* j) {
   if (j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL")) {  // one launch, header straight into pinned memory
     sssp_tail_kernel<<<std::min<uint32_t>(TAIL_BLOCKS, (n + 1023) / 1024), 1024, 0, st>>>(
         f->dev.finals, sv.key.p, n, sv.ctl.p, f->dev.offsets, f->dev.arcs, f->dev.wn, j->rev->off.p, j->rev->arc.p, j->h_path,
-        PATH_PINNED, j->h_tail);
+        PATH_PINNED, j->h_tail, sv.improved.p, adv ? adv->count : 0u, adv ? j->drv.host_flags(*adv) : nullptr);
     j->fused_tail = true;
     return;
   }
+  if (adv) throw Error("shortest_path: internal error (deferred advance without the one-launch tail)");
   j->fused_tail = false;
   sssp_final_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p,
                                                                                                           n, sv.ctl.p);
@@ -1289,8 +1311,14 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   relax_setup(ctx, f, j->sv);
   ctx->stats.sweeps = 0;
   j->drv.init(ctx, f, &j->sv);
-  j->drv.start();
-  if (j->drv.predicted && j->rev) {
+  const bool fuse = j->drv.predicted && j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL") &&
+                    !(j->drv.use_graphs && !j->sv.mbox);  // (a sweep graph carries its own advance node)
+  j->drv.start(/*defer_advance=*/fuse);
+  if (fuse) {  // the tail closes the batch: flags to the host, base advanced, then the event finish() waits for
+    queue_tail(j.get(), &j->drv.cur);
+    HIP_CHECK(hipEventRecord(j->drv.evs[0], ctx->stream));
+    j->tail_queued = true;
+  } else if (j->drv.predicted && j->rev) {
     queue_tail(j.get());
     j->tail_queued = true;
   }
