@@ -27,9 +27,9 @@
 //    winner writes the second; a lane that finds the first word equal but the second still "unset" retries the slot on the
 //    next iteration of the wave-uniform loop).  One launch takes a whole batch (one wave per problem:
 //    wfst_compose_lookahead_batch).  It gives up (LA_SWITCH_WIDE) once a BFS level adds more than WIDE_SWITCH_WIDTH states
-//    or the result passes WIDE_SWITCH_STATES.
-//  * the wide driver of compose_wide.h (one wave per composed state of a BFS level, one launch set per level), with the
-//    look-ahead filter stack as its policy (LaPolicy below).
+//    or the result passes WIDE_SWITCH_STATES (a call with ONE composition hands over earlier: *_ONE).
+//  * the wide driver of compose_wide.h (a few lanes per composed state of a BFS level, three launches per level, level
+//    control on the device), with the look-ahead filter stack as its policy (LaPolicy below).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>

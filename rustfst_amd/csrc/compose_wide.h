@@ -1,17 +1,20 @@
 // compose_wide.h — the "wide" composition driver shared by compose_lookahead.hip (look-ahead filter stack) and
-// compose_wide.hip (the ComposeFilterEnum filters): one wave per composed state of a BFS level, one launch set per level.
+// compose_wide.hip (the ComposeFilterEnum filters): G lanes per composed state of a BFS level (G = 8 / 16 / 64), three
+// launches per level, level ranges and overflow status in a control block on the device.
 //
 // The reference numbers composed states in first-touch order of a FIFO BFS (StateTable::find_id, lazy/state_table.rs:49-59;
-// LazyFst::compute, lazy/lazy_fst.rs:226-269).  Per level [lo, hi):
+// LazyFst::compute, lazy/lazy_fst.rs:226-269).  Per level k (ids [lo, hi) = WideCtl::lvl[k]):
 //   la_emit   every state's arcs go to a segment reserved with one atomicAdd; every destination tuple (two 64-bit words)
 //             is inserted into an open-addressing table together with atomicMin(position of the state in the level << 32 |
 //             position of the arc in its segment) = the order of its first emission in this level;
 //   la_first  a tuple is new iff it has no id yet; its first emission is the arc whose order equals the table's minimum;
-//             firsts are counted per state;
-//   (rocPRIM exclusive scan over the level, one 8-byte read-back: new states, overflow status)
-//   la_assign firsts are numbered hi + rank: exactly the reference's ids;   la_patch  table slot -> id in the arcs.
-// At the end the segments are gathered into CSR order.  No lane ever spins on another lane: a slot whose second key word is
-// not written yet is retried on the next iteration of a wave-uniform loop.
+//             every block counts the firsts of a contiguous share of the level;
+//   la_assign sums the block counts (overflow check, next level's range), numbers the firsts of its share hi + rank:
+//             exactly the reference's ids.  Arcs keep table slots as destinations until la_gather (or la_patch_range
+//             before a growth drops the table).
+// The host queues several levels per look at the control block (run_wide_g) and grows the arena in place, ahead of the
+// level that would not fit.  At the end the segments are gathered into CSR order.  No lane ever spins on another lane: a
+// slot whose second key word is not written yet is retried on the next iteration of a wave-uniform loop.
 //
 // Everything here sits in an anonymous namespace: each translation unit instantiates its own copy with its policy.
 #pragma once

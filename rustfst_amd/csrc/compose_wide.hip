@@ -1,5 +1,6 @@
 // compose_wide.hip — composition of ONE large pair of FSTs with the ComposeFilterEnum filters on the wide driver of
-// compose_wide.h (one wave per composed state of a BFS level), plus connect() on the device.
+// compose_wide.h (8 / 16 / 64 lanes per composed state of a BFS level, level control on the device), plus connect() on
+// the device.
 //
 // compose.hip runs one wavefront per (fst1, fst2) problem: right for batches of small lattices, hopeless for a single
 // composition of a million states (5 s on MI355X, slower than the CPU).  compose() hands such a result over to this file
