@@ -638,7 +638,8 @@ void run_wide_g(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_
         double states = hi, wl = hi - lo, room = slack;
         uint32_t n = 0;
         for (; n < limit; ++n) {
-          const double arcs_shard = arcs_per_state * wl / CUR_SHARDS, new_states = 1.25 * r * wl;
+          // (a level cannot discover more states than it emits arcs)
+          const double arcs_shard = arcs_per_state * wl / CUR_SHARDS, new_states = std::min(1.25 * r, arcs_per_state) * wl;
           if (states + new_states > (double)w.caps.S || 1.5 * arcs_shard + 64.0 > room) break;
           states += new_states;
           room -= arcs_shard;
