@@ -354,6 +354,23 @@ def main():
             dt.shortest_path()
             ctx.set_profiling(False)
             st = ctx.stats()
+            profiled_ms, profiled_launches = st["relax_ms"], st["relax_launches"]
+            # The per-launch events above synchronise after every sweep, and a sweep launched onto an idle GPU runs ~30 %
+            # longer than inside its chain.  The time that counts is the chain's: two events on the solve's stream around
+            # the pre-queued sweeps of an ordinary (un-profiled) repeated query, no synchronisation in between
+            # (wfst_ctx_set_profiling(ctx, 2)); median of 31 solves.  It is what rocprofv3's kernel trace sums to.
+            ctx.set_profiling(2)
+            chain = []
+            for _ in range(31):
+                dt.shortest_path()
+                cs = ctx.stats()
+                if cs["relax_launches"]:
+                    chain.append((cs["relax_ms"], int(cs["relax_launches"])))
+            ctx.set_profiling(0)
+            if chain:
+                chain.sort()
+                st = dict(st)
+                st["relax_ms"], st["relax_launches"] = chain[len(chain) // 2]
             if st["relax_ms"] > 0:
                 algo_bytes = 20.0 * st["relax_arcs"] + 12.0 * st["relax_states"]
                 achieved = algo_bytes / (st["relax_ms"] * 1e-3) / 1e9
@@ -372,6 +389,12 @@ def main():
                     "solve_achieved": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9, 2),
                     "solve_frac": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "re_relaxation_factor": round(st["relax_arcs"] / max(1, e_t), 3),
+                    "timing": ("HIP events around the pre-queued sweep chain of un-profiled repeated queries (median of "
+                               f"{len(chain)}); arcs / states counted by one separate profiled solve") if chain else
+                              "HIP events around every launch of one profiled solve (synchronised after each)",
+                    "profiled_solve": {"launches": int(profiled_launches), "relax_kernel_ms": round(profiled_ms, 4),
+                                       "avg_launch_us": round(1e3 * profiled_ms / max(1, profiled_launches), 2),
+                                       "note": "per-launch events + a synchronisation after every sweep: each sweep starts on an idle GPU"},
                 }
                 # HBM-side traffic cannot be counted live: it comes from the committed rocprofv3 PMC passes of this
                 # same command (profiles/pmc_relax_traffic.json, regenerated by tools/profile_round.sh), per launch

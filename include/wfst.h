@@ -299,7 +299,10 @@ typedef struct {
   uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
                                (owner-computes mailbox sweeps), 2 sssp_mboxa_kernel (several rounds per launch) */
 } wfst_stats;
-/* profiling on: relaxation launches are bracketed by HIP events (adds sync; never on in timed runs) */
+/* on = 1: every relaxation launch is bracketed by HIP events and followed by a synchronisation (per-launch trace below;
+ * never on in timed runs).  on = 2: no per-launch events; the sweeps of a repeated shortest_path query (one pre-queued
+ * batch) are timed as ONE chain between two events on the stream: relax_ms = that time, relax_launches = its sweeps
+ * (0 when the query was not a single predicted batch).  on = 0: off. */
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on);
 wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out);
 wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx);

@@ -172,6 +172,8 @@ wfst_status wfst_ctx_destroy(wfst_ctx* ctx) {
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->ev_chain)
+      if (e) (void)hipEventDestroy(e);
     ctx->pool.reset();
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -558,7 +560,12 @@ wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on) {
   return wrap([&] {
     if (!ctx) throw Error("null ctx");
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 1;
+    ctx->chain_timing = on == 2;
+    if (ctx->chain_timing && !ctx->ev_chain[0]) {
+      HIP_CHECK(hipEventCreate(&ctx->ev_chain[0]));
+      HIP_CHECK(hipEventCreate(&ctx->ev_chain[1]));
+    }
   });
 }
 wfst_status wfst_ctx_get_stats(wfst_ctx* ctx, wfst_stats* out) {

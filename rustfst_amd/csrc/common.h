@@ -111,6 +111,10 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned;      // small D2H/H2D staging
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
+  // wfst_ctx_set_profiling(ctx, 2): no per-launch events; the sweeps of a repeated (predicted) shortest_path query are timed
+  // as ONE chain between two events on the stream, without any synchronisation between launches
+  bool chain_timing = false;
+  hipEvent_t ev_chain[2] = {nullptr, nullptr};
   bool batch_in_flight = false;  // wfst_compose_shortest_path_batch_begin .. _end
   bool sp_in_flight = false;     // wfst_shortest_path_begin .. _end
   wfst_stats stats{};

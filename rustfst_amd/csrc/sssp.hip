@@ -1044,7 +1044,10 @@ struct SweepDriver {
     } else {
       // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
       // N nodes only starts after ~2.7 us x N of host-side work: 89 us for the 32-sweep replay, profiles/r01g)
+      const bool time_chain = ctx->chain_timing && b.first == 0;
+      if (time_chain) HIP_CHECK(hipEventRecord(ctx->ev_chain[0], st));
       for (uint32_t j = 0; j < b.count; ++j) launch_sweep(f, *sv, n, st, j, j, b.first + j, 0u);
+      if (time_chain) HIP_CHECK(hipEventRecord(ctx->ev_chain[1], st));
       if (!defer_advance) sssp_advance_kernel<<<1, 64, 0, st>>>(sv->ctl.p, sv->improved.p, b.count, h_imp + b.which * IMP_RING);
       HIP_CHECK(hipGetLastError());
     }
@@ -1346,6 +1349,16 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   }
   if (!j->tail_queued) queue_tail(j.get());
   HIP_CHECK(hipStreamSynchronize(st));
+  if (ctx->chain_timing && !ctx->profiling) {  // the sweeps of this query as one chain (wfst_ctx_set_profiling(ctx, 2))
+    ctx->stats.relax_ms = 0.0;
+    ctx->stats.relax_launches = 0;
+    if (j->drv.predicted && !j->drv.extended && !(j->drv.use_graphs && !sv.mbox)) {
+      float ms = 0.0f;
+      HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_chain[0], ctx->ev_chain[1]));
+      ctx->stats.relax_ms = ms;
+      ctx->stats.relax_launches = j->drv.first_count;
+    }
+  }
   const Ctl* hc = j->hc;
   const uint32_t r_pad = j->fused_tail ? j->h_tail->pad : hc->pad, r_has_path = j->fused_tail ? j->h_tail->has_path : hc->has_path;
   if (r_pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");

@@ -77,8 +77,10 @@ class Context:
         check(_lib.lib().wfst_ctx_stream(self._h, C.byref(s)))
         return s.value or 0
 
-    def set_profiling(self, on: bool):
-        check(_lib.lib().wfst_ctx_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False / 0: off; True / 1: events around every relaxation launch (synchronises after each); 2: the sweeps of a
+        repeated shortest_path query timed as one chain between two events (stats: relax_ms, relax_launches)."""
+        check(_lib.lib().wfst_ctx_set_profiling(self._h, int(on)))
 
     def reset_stats(self):
         check(_lib.lib().wfst_ctx_reset_stats(self._h))

@@ -763,6 +763,26 @@ def test_shortest_path_tail_in_one_launch(gpu_ctx, oracle, monkeypatch, split):
             assert_flat_identical(d.shortest_path().to_flat(), ref, f"{name}, query {q}, split={split}", check_props=(name != "long chain"))
 
 
+def test_chain_timing_of_repeated_queries(oracle):
+    """wfst_ctx_set_profiling(ctx, 2): the pre-queued sweeps of a repeated query are timed between two events on the
+    solve's stream (what bench.py's roofline object uses); results are unchanged, the first query of a handle (no
+    prediction yet) reports no chain, later ones report their sweep count and a plausible time."""
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(80_000, 8, 64, 0.0, seed=91)
+    d = to_device(t, ctx)
+    ref = to_oracle(oracle, t).shortest_path_canonical().to_flat()
+    ctx.set_profiling(2)
+    seen = []
+    for q in range(4):
+        assert_flat_identical(d.shortest_path().to_flat(), ref, f"chain-timed query {q}")
+        st = ctx.stats()
+        seen.append((st["relax_launches"], st["relax_ms"]))
+    ctx.set_profiling(0)
+    assert seen[0][0] == 0  # nothing to predict from
+    assert seen[-1][0] == ctx.stats()["sweeps"] and 0.0 < seen[-1][1] < 50.0, seen
+    assert_flat_identical(d.shortest_path().to_flat(), ref, "after chain timing")
+
+
 def test_async_shortest_path_matches_sync(gpu_ctx, oracle, monkeypatch):
     """wfst_shortest_path_begin/_end: same FST as the synchronous call and the oracle — on the first queries (no
     prediction, no transpose), on predicted ones (final search + backtrace queued speculatively behind the sweeps),
