@@ -65,7 +65,10 @@ while time.time() < t_end:
                     ok, _ = orc.contains_path(O.OracleFst.from_flat(**{k: got[k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props")}))
                     assert ok, "not a path of the input"
     except rustfst_amd.WfstError as e:
-        if "did not converge" in str(e) and d == "0.3":  # a forced band far narrower than the arcs: more sweeps than the cap
+        # a FORCED band far narrower than the arcs (delta 0.3, or 2.5 against weights up to 5000 on a few hundred states)
+        # needs more sweeps than the 4 n + 64 the driver allows before it suspects a negative cycle; the automatic band is
+        # 1.5 x the mean weight and only used from 65 536 states on
+        if "did not converge" in str(e) and d in ("0.3", "2.5"):
             counts["skipped"] = counts.get("skipped", 0) + 1
             seed += 1
             continue
