@@ -131,7 +131,7 @@ struct ReachVisitor {
   uint32_t root;
   explicit ReachVisitor(const Graph& gr)
       : g(gr), set_off(gr.n(), 0), set_len(gr.n(), 0), state2index(gr.n(), UNASSIGNED), own_begin(gr.n(), 0), root(gr.start) {
-    arena.reserve(gr.dst.size() / 2 + gr.n());
+    arena.reserve(2 * gr.dst.size() + gr.n());  // (a decoding graph's sets hold ~1.5 intervals per arc; regrowing 100+ MB is a copy)
   }
   void discover(uint32_t s) {
     if (g.is_final[s]) {
