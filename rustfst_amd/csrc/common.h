@@ -179,13 +179,6 @@ struct MboxPlan {
   DBuf<uint32_t> roff;     // [nb*nb + 1] destination-major
   DBuf<uint32_t> roff_t;   // [nb*nb]     source-major copy
 };
-// Ring plan of the multi-round mailbox kernel (sssp_mailbox_async.h): one ring of cap >= 2 x arcs + 2 slots per pair
-struct MboxPlanA {
-  uint32_t nb = 0;
-  uint64_t slots = 0;      // sum of the ring capacities
-  DBuf<uint2> rinfo;       // [nb*nb] receiver-major {offset, cap - 1}
-  DBuf<uint4> sinfo;       // [nb*nb] sender-major   {offset, cap - 1, arcs, 0}
-};
 }  // namespace wfst
 
 namespace wfst {
@@ -221,7 +214,6 @@ struct wfst_fst {
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
   // region plan of the mailbox relaxation sweeps; depends on (source, target) pairs only, built on first use
   mutable std::shared_ptr<wfst::MboxPlan> mbox;
-  mutable std::shared_ptr<wfst::MboxPlanA> mboxa;
   // a linear, epsilon-free, single-final acceptor ("string": utils::acceptor, labels_to_fst.rs:111-132), detected at
   // upload from the host arrays; such an fst1 takes the specialised string o T kernel of the fused batch
   bool is_string = false;
@@ -231,6 +223,9 @@ struct wfst_fst {
   mutable int ieps_state = 0;  // 0 unknown, 1 no input epsilons, 2 has input epsilons
   mutable std::atomic<uint32_t> sp_queries{0};
   mutable std::atomic<uint32_t> last_sweeps{0};  // sweeps the last relaxation of this FST needed (sizes the first graph replay)
+  // mailbox sweeps: bit k set = launch k of the last solve was NOT a busy wide sweep (idle, hand-over or narrow launch):
+  // the next solve gates that launch's bulk loads behind its mode / sleep decision
+  mutable std::atomic<uint64_t> last_hint_mask{~0ull};
   // the lazily built caches above may be requested from several contexts (threads) at once: built under this lock,
   // with buffers taken from the OWNER context's pool (this->ctx), which outlives the handle
   mutable std::mutex cache_mu;

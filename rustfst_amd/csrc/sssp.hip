@@ -66,6 +66,10 @@ struct Ctl {
   // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
   uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
   uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
+  // mailbox sweeps: the mode launch k ran in (MODE_*), and the number of states waiting beyond the threshold (sharded like
+  // `near`; a block adds the change of its own count, unsigned wrap-around)
+  uint32_t mode[RING];
+  uint32_t far[NEAR_SHARDS * NEAR_STRIDE];
   // arcs / states relaxed so far (profiling only): sharded like `near`, shard j at [j * PROF_STRIDE]
   unsigned long long arcs[PROF_SHARDS * PROF_STRIDE];
   unsigned long long states[PROF_SHARDS * PROF_STRIDE];
@@ -113,7 +117,6 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
 }
 
 #include "sssp_mailbox.h"
-#include "sssp_mailbox_async.h"
 
 // Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
 // +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
@@ -732,15 +735,13 @@ struct Solve {
   bool mbox = false;
   std::shared_ptr<MboxPlan> plan;
   DBuf<uint2> mb_msgs;      // two message buffers of n_arcs entries
-  DBuf<uint32_t> mb_words;  // counts (2 x nb^2), wrote (2 x nb), pend masks, blk_pend, blk_mind
+  DBuf<uint32_t> mb_words;  // counts (2 x nb^2), wrote (2 x nb), pend masks, blk_pend, blk_mind, blk_far, wl_cnt
+  DBuf<uint4> mb_wl;        // work-list segments of the NARROW launches (nb x NW_SEG entries)
   DBuf<unsigned long long> mb_dbg;  // WFST_SSSP_MBOX_TRACE=<file>: per-block phase stamps of the first 64 sweeps
   MboxView mv{};
-  // multi-round mailbox launches (sssp_mailbox_async.h), WFST_SSSP_MAILBOX=2
-  bool mboxa = false;
-  std::shared_ptr<MboxPlanA> plana;
-  DBuf<MboxGlobal> ma_g;
-  MboxAView mav{};
-  uint32_t ma_rounds = MA_MAX_ROUNDS_DEFAULT;
+  uint32_t narrow_t = 0;     // mailbox: near + far-waiting states below which the sweeps hand over to NARROW launches (0 = never)
+  uint64_t hint_mask = ~0ull;  // mailbox: bit k = launch k of this FST's last solve was not a busy WIDE sweep (gated launch)
+  size_t mb_dyn = 0;         // dynamic LDS bytes of a mailbox launch
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -750,7 +751,7 @@ constexpr uint32_t MAX_BATCH = 64;
 // idles on a host round trip.  A sweep that changes nothing leaves an empty frontier: everything enqueued behind it is
 // a ~3 us no-op.
 bool mbox_eligible(const wfst_fst* f) {
-  return f->n_states <= (MB_NBMAX << MB_LOG) && f->n_arcs > 0 && f->n_arcs < 0x7FFFFFFFull && !f->has_negative;
+  return f->n_states <= (MB_NBMAX_BIG << MB_LOG) && f->n_arcs > 0 && f->n_arcs < 0x7FFFFFFFull && !f->has_negative;
 }
 
 // Region plan of the mailbox sweeps: arcs between every pair of blocks, scanned into region offsets.  Depends only on
@@ -780,45 +781,24 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   return p;
 }
 
-std::shared_ptr<MboxPlanA> mboxa_plan(wfst_ctx* ctx, const wfst_fst* f) {
-  std::lock_guard<std::mutex> lk(f->cache_mu);
-  if (f->mboxa) return f->mboxa;
-  const uint32_t n = f->n_states, nb = (n + MB_B - 1) >> MB_LOG;
-  hipStream_t st = ctx->stream;
-  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
-  auto p = std::make_shared<MboxPlanA>();
-  p->nb = nb;
-  const size_t cells = (size_t)nb * nb;
-  p->rinfo = DBuf<uint2>(owner_pool, cells);
-  p->sinfo = DBuf<uint4>(owner_pool, cells);
-  DBuf<uint32_t> hist(*ctx->pool, cells + 1), caps(*ctx->pool, cells + 1), roff(*ctx->pool, cells + 1);
-  mbox_hist_kernel<<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
-  mboxa_caps_kernel<<<(uint32_t)((cells + 256) / 256), 256, 0, st>>>(hist.p, (uint32_t)cells, caps.p);
-  size_t temp_bytes = 0;
-  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, caps.p, roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
-  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
-  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, caps.p, roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
-  mboxa_info_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(hist.p, caps.p, roff.p, nb, p->rinfo.p, p->sinfo.p);
-  uint32_t total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, roff.p + cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(st));
-  p->slots = total;
-  f->mboxa = p;
-  return p;
-}
-
 // one relaxation sweep on the stream: `j` = position inside the batch (static flag / message parity), `off` = sweep
 // index relative to the device-side base, `abs_sweep` = the absolute index (what the host has queued so far)
 void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint32_t j, uint32_t off, uint32_t abs_sweep,
                   uint32_t profile) {
-  if (sv.mboxa)
-    sssp_mboxa_kernel<<<sv.mav.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mav, n, sv.improved.p, sv.ctl.p,
-                                                        abs_sweep, sv.delta, sv.ma_rounds, profile);
-  else if (sv.mbox)
+  if (sv.mbox) {
     // (message parity from the ABSOLUTE sweep index: mailbox batches may hold an odd number of sweeps)
-    sssp_mbox_kernel<<<sv.mv.nb, MB_THREADS, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n, sv.improved.p,
-                                                      sv.ctl.p, abs_sweep, sv.delta, sv.near_low, profile);
+    // hint = the launch is probably NOT a busy WIDE sweep (what the last solve of this FST did in that slot, or unknown):
+    // it then finds out its mode and whether it sleeps BEFORE it asks for its 48 KB of keys and offsets
+    const uint32_t hint = profile || abs_sweep >= 64 ? 1u : (uint32_t)((sv.hint_mask >> abs_sweep) & 1ull);
+    if (sv.mv.nb > MB_NBMAX)
+      sssp_mbox_kernel<true><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
+                                                                      sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
+                                                                      profile, hint, sv.narrow_t);
+    else
+      sssp_mbox_kernel<false><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
+                                                                       sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
+                                                                       profile, hint, sv.narrow_t);
+  }
   else
     sssp_relax_kernel<<<sv.blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u], sv.fl[(j & 1u) ^ 1u], n,
                                                  sv.improved.p, sv.ctl.p, off, sv.delta, sv.near_low, sv.shadow.p, sv.chase_cap,
@@ -855,41 +835,28 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   bool want_mbox = delta < INF && mbox_eligible(f);
   int mbox_mode = want_mbox ? 1 : 0;
   if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) mbox_mode = mbox_eligible(f) ? std::atoi(e) : 0;
-  if (mbox_mode == 2 && f->n_arcs < 0x3FFFFFFFull) {
-    sv.plana = mboxa_plan(ctx, f);
-    const uint32_t nb = sv.plana->nb;
-    sv.mboxa = true;
-    sv.mbox = true;  // (plain launches, no sweep graphs, absolute sweep index: same driver path)
-    if (const char* e = std::getenv("WFST_SSSP_MBOX_ROUNDS")) sv.ma_rounds = std::max(1, std::atoi(e));
-    sv.mb_msgs = DBuf<uint2>(pool, sv.plana->slots);
-    const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
-    sv.mb_words = DBuf<uint32_t>(pool, 4 * w_cnt + w_pend + 2 * nb);
-    sv.ma_g = DBuf<MboxGlobal>(pool, 1);
-    MboxAView& mv = sv.mav;
-    mv.rinfo = sv.plana->rinfo.p;
-    mv.sinfo = sv.plana->sinfo.p;
-    mv.msgs = sv.mb_msgs.p;
-    uint32_t* w = sv.mb_words.p;
-    mv.head_r = w;
-    mv.tail_s = w + w_cnt;
-    mv.cur_s = w + 2 * w_cnt;
-    mv.tail_r = w + 3 * w_cnt;
-    w += 4 * w_cnt;
-    mv.pend = w;
-    w += w_pend;
-    mv.blk_pend = w;
-    mv.blk_mind = w + nb;
-    mv.g = sv.ma_g.p;
-    mv.nb = nb;
-    sssp_mboxa_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
-                                                       delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
-  } else if (mbox_mode >= 1) {
-    sv.plan = mbox_plan(ctx, f);
+  if (mbox_mode >= 1) {
+    // Two message buffers of one slot per arc, the nb^2 region tables and counts come from the pool: on a tight pool (or a
+    // dense graph) the atomic sweeps, which need none of it, run instead.
+    try {
+      sv.plan = mbox_plan(ctx, f);
+      const uint32_t nb = sv.plan->nb;
+      sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
+      const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
+      sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 4 * nb);
+      sv.mb_wl = DBuf<uint4>(pool, (size_t)nb * NW_SEG);
+      sv.mbox = true;
+    } catch (const Error&) {
+      sv.plan.reset();
+      sv.mb_msgs.reset();
+      sv.mb_words.reset();
+      sv.mb_wl.reset();
+      sv.mbox = false;
+    }
+  }
+  if (sv.mbox) {
     const uint32_t nb = sv.plan->nb;
-    sv.mbox = true;
-    sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
     const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
-    sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 2 * nb);
     MboxView& mv = sv.mv;
     mv.roff = sv.plan->roff.p;
     mv.roff_t = sv.plan->roff_t.p;
@@ -906,22 +873,38 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     w += w_pend;
     mv.blk_pend = w;
     mv.blk_mind = w + nb;
+    mv.blk_far = w + 2 * nb;
+    mv.wl_cnt = w + 3 * nb;
+    mv.wl = sv.mb_wl.p;
     mv.nb = nb;
+    // staging depth: what the dynamic LDS budget leaves after the three per-destination tables
+    mv.stg = std::max<uint32_t>(1u, std::min<uint32_t>(MB_STG_MAX, (MB_DYN_BUDGET - 12u * nb) / (8u * nb)));
+    sv.mb_dyn = (size_t)nb * mv.stg * sizeof(uint2) + 3u * (size_t)nb * sizeof(uint32_t);
+    static std::once_flag lds_once[64];  // (a function attribute is per device)
+    std::call_once(lds_once[(unsigned)ctx->device & 63u], [] {
+      HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_DYN_BUDGET));
+      HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_DYN_BUDGET));
+    });
+    // hand-over to NARROW launches when the near set plus everything waiting beyond the threshold is this small
+    sv.narrow_t = 8192;
+    if (const char* e = std::getenv("WFST_SSSP_NARROW")) sv.narrow_t = (uint32_t)std::atol(e);
+    sv.hint_mask = f->last_hint_mask.load(std::memory_order_relaxed);
+    if (const char* e = std::getenv("WFST_SSSP_HINT")) sv.hint_mask = std::atoi(e) ? ~0ull : 0ull;  // experiments: all / no launches gated
     mv.dbg = nullptr;
     if (std::getenv("WFST_SSSP_MBOX_TRACE")) {
       sv.mb_dbg = DBuf<unsigned long long>(pool, (size_t)MB_DBG_SWEEPS * nb * 16);
       HIP_CHECK(hipMemsetAsync(sv.mb_dbg.p, 0, (size_t)MB_DBG_SWEEPS * nb * 16 * 8, st));
       mv.dbg = sv.mb_dbg.p;
     }
-    sssp_mbox_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
-                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
+    sssp_mbox_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, f->dev.offsets, n, (uint32_t)f->start,
+                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t);
   } else {
     sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
                                                  sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
                                                  delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
   }
   HIP_CHECK(hipGetLastError());
-  ctx->stats.relax_kernel = sv.mboxa ? 2u : sv.mbox ? 1u : 0u;
+  ctx->stats.relax_kernel = sv.mbox ? 1u : 0u;
   sv.sweep_cap = 4ull * n + 64;
   if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
   if (const char* e = std::getenv("WFST_SSSP_CHASE_ROUNDS")) sv.chase_rounds = (uint32_t)std::atol(e);
@@ -957,12 +940,13 @@ struct SweepDriver {
     // A batch boundary costs ~14 us of idle GPU (profiles/r01d), so the FIRST batch of a solve is sized to what the
     // previous solve of this FST needed (+1 sweep to see the quiet one, rounded up to an even count; batch sizes stay
     // even because the flag parity of a sweep inside a batch is static).
-    // The mailbox sweeps are deterministic (owner-computes: the same sweeps change the same keys every time), so a
-    // repeated query gets EXACTLY the sweeps the last one needed, quiet one included: an idle launch is ~5 us.
+    // The mailbox sweeps repeat themselves closely but not exactly (a state expanded while other waves of the same launch
+    // improve it sends its old or its new key; NARROW launches follow discoveries in whatever order the atomics land), so a
+    // repeated query gets the launches the last one needed, the quiet one included, plus ONE: a gated idle launch is ~3 us,
+    // a second batch is a host round trip and a re-run of the fused tail.
     const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    const bool exact = sv->mbox && !sv->mboxa;
-    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, exact ? last_sweeps : ((last_sweeps + 1 + 1) & ~1u));
-    predicted = last_sweeps != 0 && (exact ? last_sweeps <= first_count : last_sweeps < first_count);
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, sv->mbox ? last_sweeps + 1u : ((last_sweeps + 1 + 1) & ~1u));
+    predicted = last_sweeps != 0 && last_sweeps < first_count;
     evs[0] = ctx->ev0;
     evs[1] = ctx->ev1;
   }
@@ -1057,14 +1041,19 @@ struct SweepDriver {
   }
   uint32_t* host_flags(const SweepBatch& b) const { return h_imp + b.which * IMP_RING; }
 
+  uint64_t seen_busy = 0;  // bit k: launch k was a busy WIDE sweep (flag value 1 + MODE_WIDE)
   bool scan_flags(const SweepBatch& b) {  // true when a sweep of the batch changed nothing
     const uint32_t* hf = h_imp + b.which * IMP_RING;
     for (uint32_t k = 0; k < b.count; ++k) {
       sweeps_done = b.first + k + 1;
-      if (!hf[(b.first + k) % IMP_RING]) return true;
+      const uint32_t v = hf[(b.first + k) % IMP_RING];
+      if (!v) return true;
+      if (v == 1u && b.first + k < 64) seen_busy |= 1ull << (b.first + k);
     }
     return false;
   }
+  // which launches of the next solve of this FST may skip the gate (they were busy WIDE sweeps this time)
+  uint64_t hint_mask() const { return ~seen_busy; }
 
   void start(bool defer_advance = false) { cur = enqueue_batch(evs[0], defer_advance); }
 
@@ -1095,7 +1084,7 @@ struct SweepDriver {
 // tuning aid: the phase stamps of a mailbox solve go to the file named by WFST_SSSP_MBOX_TRACE (u64 [64][nb][16])
 void mbox_dump_trace(wfst_ctx* ctx, Solve& sv) {
   const char* path = std::getenv("WFST_SSSP_MBOX_TRACE");
-  if (!sv.mbox || sv.mboxa || !sv.mb_dbg.p || !path) return;
+  if (!sv.mbox || !sv.mb_dbg.p || !path) return;
   std::vector<unsigned long long> h((size_t)MB_DBG_SWEEPS * sv.mv.nb * 16);
   HIP_CHECK(hipMemcpyAsync(h.data(), sv.mb_dbg.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1158,6 +1147,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     drv.start();
     drv.finish();
     sweeps_done = drv.sweeps_done;
+    f->last_hint_mask.store(drv.hint_mask(), std::memory_order_relaxed);
   }
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
@@ -1341,6 +1331,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     sv.sweeps = j->drv.sweeps_done;
     ctx->stats.sweeps = sv.sweeps;
     f->last_sweeps.store(sv.sweeps, std::memory_order_relaxed);
+    f->last_hint_mask.store(j->drv.hint_mask(), std::memory_order_relaxed);
     mbox_dump_trace(ctx, sv);
   }
   if (j->tail_queued && j->drv.extended) {  // the speculative tail ran on unfinished distances: once more

@@ -1,13 +1,13 @@
 // sssp_mailbox.h — owner-computes relaxation sweeps ("mailbox sweeps") for sssp.hip.
 //
-// Included by sssp.hip inside namespace wfst { namespace { ... } } after Ctl / sweep_tau / enc_f32.
+// Included by sssp.hip inside namespace wfst { namespace { ... } } after Ctl / enc_f32.
 //
 // Same recurrence as sssp_relax_kernel (single_shortest_path, rustfst/src/algorithms/shortest_path.rs:173-239:
 // relax arc (s,w,t) with nd = d[s] (x) w, keep the minimum), same (d, hops) key, same near-far schedule — the
 // least fixed point is unique, so the keys it leaves are bit-identical.  What changes is WHERE the minimum is taken:
 //
-//   * the states are cut into blocks of MB_B = 4096; workgroup j OWNS block j and is the only one that ever writes
-//     key[] of its states.  It keeps the block's 4096 keys in LDS for the duration of a sweep (32 KB);
+//   * the states are cut into blocks of MB_B = 4096; workgroup j OWNS block j and is the only one that writes key[] of
+//     its states during a WIDE sweep.  It keeps the block's 4096 keys in LDS for the duration of the sweep (32 KB);
 //   * a relaxation is a MESSAGE {enc(d[s] + w), hops[s] + 1, t mod 4096} (8 bytes) written by the workgroup that
 //     owns s into the region reserved for the pair (block of s -> block of t).  Regions are static: region (i -> j)
 //     has room for every arc from block i to block j (one message per arc per sweep at most), so a slot is one LDS
@@ -15,27 +15,41 @@
 //   * next sweep the owner reads its regions (contiguous per destination: coalesced), applies the candidates with
 //     LDS atomicMin, and expands the states that changed (or were waiting beyond the near-far threshold).
 //
-// Why: on MI355X the atomic sweep is bound by the 26.5 G/s global-atomic rate while a band is discovered and by 64-byte
-// sectors moved for every 4..8-byte gather / atomic / flag store (1.5 GB per solve of the 1M-state graph against 0.2 GB
-// algorithmic, profiles/r01h); a compute unit also retires only about one DIVERGENT lane access every three cycles.
-// Here every access to memory is a coalesced stream except the read of an active state's arc row: messages are staged
-// per destination in LDS and flushed as contiguous runs, the owner reads its regions as contiguous runs, arcs that stay
-// inside the block never leave LDS, and nothing is looked up per arc on the sending side (a per-target filter was
-// tried: its 2-byte gathers cost more than the messages it saved once those were coalesced).
+// A launch ("slot") runs in one of three MODES, decided on the device by every workgroup from the same few words of the
+// control block (mbox_schedule), so the host still queues a solve's launches back to back without looking:
+//   WIDE     the owner-computes sweep above: one level of the search per launch (~8.6 us even for one state);
+//   NARROW   the frontier is a handful of states per block (the head of the search, the tail of the last band): every
+//            workgroup follows ITS OWN discoveries level after level inside the launch, with global atomicMin on key[]
+//            and a work list in LDS whose entries carry key and arc range (two dependent trips per level: arc rows, then
+//            atomic + the target's offsets together); nothing is handed to another workgroup, so there is no barrier
+//            between workgroups.  States beyond the threshold (or more than the list holds) are left in the waiting
+//            masks for the next WIDE sweep;
+//   COLLECT  the hand-over WIDE -> NARROW: the owners apply their inboxes as usual but, instead of expanding, write
+//            the states they would have expanded into their segment of the global work list.
+// Relaxation order does not change the fixed point, so the modes only change how fast it is reached.
 //
-// Limits: n <= 2^20 states (20 hop bits + 12 state bits share a word of the message), no negative weights (the hop
-// count of a tentative label is then < n), n_arcs < 2^32.  Anything else takes sssp_relax_kernel.
+// Limits: hop counts < 2^20 (20 hop bits + 12 state bits share a word of the message; checked at run time), no negative
+// weights, n_arcs < 2^31, at most MB_NBMAX_BIG blocks (8M states).  Anything else takes sssp_relax_kernel.
 
 constexpr uint32_t MB_LOG = 12;
 constexpr uint32_t MB_B = 1u << MB_LOG;  // states per block
-constexpr uint32_t MB_NBMAX = 256;       // blocks (n <= 2^20)
+constexpr uint32_t MB_NBMAX = 256;       // blocks handled with one inbox region per 4 lanes in one pass (n <= 2^20)
+constexpr uint32_t MB_NBMAX_BIG = 2048;  // blocks at most (n <= 2^23): inbox regions in passes of 256, shallower staging
 constexpr uint32_t MB_THREADS = 1024;
 constexpr uint32_t MB_HOP_BITS = 32 - MB_LOG;
 constexpr uint32_t MB_UNROLL = 8;  // active states a 16-lane group relaxes at once (independent load chains per lane)
-#ifndef MB_WT
-#define MB_WT 0  // staged messages leave with write-through (sc1) stores: nothing is left dirty in the L2 for the end of the kernel
-#endif
-constexpr uint32_t MB_STG = 24;    // messages per destination staged in LDS between two flushes (the rest is stored directly)
+constexpr uint32_t MB_STG_MAX = 24;  // messages per destination staged in LDS between two flushes (the rest is stored directly)
+constexpr uint32_t MB_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-destination cursors) next to 57 KB static
+
+// modes of a launch (also what the activity flag of a sweep holds, + 1)
+constexpr uint32_t MODE_WIDE = 0, MODE_COLLECT = 1, MODE_NARROW = 2;
+// NARROW launches
+constexpr uint32_t NW_SEG = 256;        // work-list entries a block may hand over (COLLECT) per launch
+constexpr uint32_t NW_CAP = 1024;       // entries per level a workgroup keeps in LDS (two lists of 16 KB)
+constexpr uint32_t NW_GROW = 384;       // a level wider than this goes back to the WIDE sweeps
+constexpr uint32_t NW_UNROLL = 4;       // entries a 16-lane group relaxes at once
+constexpr uint32_t NW_MAX_LEVELS = 4096;
+constexpr uint32_t NW_DEG_SAT = 0xFFFu;  // arc count field of an entry; saturated = read offsets[s + 1]
 
 struct MboxView {
   const uint32_t* roff;    // [nb*nb + 1] region offsets, destination-major: region (i -> j) starts at roff[j*nb + i]
@@ -45,8 +59,12 @@ struct MboxView {
   uint32_t* wrote[2];      // [nb] each: sender i left non-zero counts in this parity's column
   uint32_t* pend;          // [nb * MB_B/32] states improved but not yet expanded (waiting beyond the threshold)
   uint32_t* blk_pend;      // [nb] number of such states per block
-  uint32_t* blk_mind;      // [nb] min enc(d) among them
+  uint32_t* blk_mind;      // [nb] min enc(d) among them (a lower bound after a NARROW launch)
+  uint32_t* blk_far;       // [nb] how many of them are beyond the threshold
+  uint4* wl;               // [nb * NW_SEG] work list of the NARROW launches: {state, arc begin, enc(d), hops << 12 | arcs}
+  uint32_t* wl_cnt;        // [nb] entries in segment j
   uint32_t nb;
+  uint32_t stg;            // staging slots per destination (MB_STG_MAX, fewer for many blocks)
   unsigned long long* dbg;  // tuning only (WFST_SSSP_MBOX_TRACE): wall-clock stamps [sweep][block][16], or null
 };
 constexpr uint32_t MB_DBG_SWEEPS = 64;
@@ -55,7 +73,7 @@ constexpr uint32_t MB_DBG_SWEEPS = 64;
 // ---- plan (cached on the FST handle): region offsets from the number of arcs between every pair of blocks
 __global__ void __launch_bounds__(1024) mbox_hist_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                          uint32_t n, uint32_t nb, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t l_h[MB_NBMAX];
+  __shared__ uint32_t l_h[MB_NBMAX_BIG];
   const uint32_t j = blockIdx.x;
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) l_h[d] = 0;
   __syncthreads();
@@ -63,18 +81,20 @@ __global__ void __launch_bounds__(1024) mbox_hist_kernel(const uint32_t* __restr
   const uint32_t b = offsets[s0], e = offsets[s1];
   for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&l_h[wn[i].y >> MB_LOG], 1u);
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) hist[d * nb + j] = l_h[d];  // destination-major
+  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) hist[(size_t)d * nb + j] = l_h[d];  // destination-major
 }
 __global__ void mbox_transpose_kernel(const uint32_t* __restrict__ roff, uint32_t nb, uint32_t* __restrict__ roff_t) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nb * nb) return;
   const uint32_t i = k / nb, j = k % nb;
-  roff_t[k] = roff[j * nb + i];
+  roff_t[k] = roff[(size_t)j * nb + i];
 }
 
-// Initial state of a mailbox solve in one launch.
+// Initial state of a mailbox solve in one launch.  With NARROW launches the start state is the one entry of its block's
+// work-list segment (sweep 0 is NARROW); without, it waits in the pending mask (sweep 0 is WIDE).
 __global__ void __launch_bounds__(256) sssp_mbox_setup_kernel(uint64_t* __restrict__ key, MboxView mb, uint32_t* __restrict__ improved,
-                                                              Ctl* __restrict__ ctl, uint32_t n, uint32_t start, float tau0) {
+                                                              Ctl* __restrict__ ctl, const uint32_t* __restrict__ offsets, uint32_t n,
+                                                              uint32_t start, float tau0, uint32_t narrow_on) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   const uint32_t nb = mb.nb;
   for (uint32_t i = tid; i < n; i += nt) {
@@ -85,13 +105,21 @@ __global__ void __launch_bounds__(256) sssp_mbox_setup_kernel(uint64_t* __restri
     mb.cnt[0][i] = 0;
     mb.cnt[1][i] = 0;
   }
+  const bool waits = narrow_on == 0;
   for (uint32_t i = tid; i < nb * (MB_B / 32); i += nt)
-    mb.pend[i] = i == (start >> 5) ? 1u << (start & 31u) : 0u;
+    mb.pend[i] = waits && i == (start >> 5) ? 1u << (start & 31u) : 0u;
   for (uint32_t i = tid; i < nb; i += nt) {
+    const bool mine = i == (start >> MB_LOG);
     mb.wrote[0][i] = 0;
     mb.wrote[1][i] = 0;
-    mb.blk_pend[i] = i == (start >> MB_LOG) ? 1u : 0u;
-    mb.blk_mind[i] = i == (start >> MB_LOG) ? enc_f32(0.0f) : 0xFFFFFFFFu;
+    mb.blk_pend[i] = waits && mine ? 1u : 0u;
+    mb.blk_mind[i] = waits && mine ? enc_f32(0.0f) : 0xFFFFFFFFu;
+    mb.blk_far[i] = 0;
+    mb.wl_cnt[i] = !waits && mine ? 1u : 0u;
+    if (!waits && mine) {
+      const uint32_t b = offsets[start], c = offsets[start + 1] - b;
+      mb.wl[(size_t)i * NW_SEG] = make_uint4(start, b, enc_f32(0.0f), min(c, NW_DEG_SAT));
+    }
   }
   for (uint32_t i = tid; i < IMP_RING; i += nt) improved[i] = 0;
   uint32_t* cw = (uint32_t*)ctl;
@@ -111,8 +139,226 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// One mailbox sweep.  Workgroup j:
-//   trip 1  counts of its inbox regions, pending words, threshold, AND (speculatively) the block's keys and offsets
+// ---- the schedule of a launch: threshold (same rules as sweep_tau) and mode, from what the previous launches left in the
+// control block.  Two halves so that the loads can be issued together with everything else a launch asks for first.
+struct SchedRaw {
+  uint32_t mine, prev_tau, prev_streak, prev_mode;
+};
+struct Sched {
+  float tau;
+  uint32_t streak, prev_near, far_total, mode;
+};
+// lanes 0..15: near counter of sweep-1, 16..31: of sweep-2, 32..47: states waiting beyond the threshold (all sharded)
+__device__ __forceinline__ SchedRaw mbox_sched_load(const Ctl* ctl, uint32_t sweep) {
+  SchedRaw r{0u, 0u, 0u, MODE_WIDE};
+  if (sweep == 0) return r;
+  const uint32_t lane = threadIdx.x & 63u, p = (sweep - 1) % RING;
+  if (lane < NEAR_SHARDS) r.mine = ctl->near[(sweep - 1) % NEAR_RING][lane * NEAR_STRIDE];
+  else if (lane < 2 * NEAR_SHARDS) r.mine = sweep >= 2 ? ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE] : 0u;
+  else if (lane < 3 * NEAR_SHARDS) r.mine = ctl->far[(lane - 2 * NEAR_SHARDS) * NEAR_STRIDE];
+  r.prev_tau = ctl->tau[p];
+  r.prev_streak = ctl->streak[p];
+  r.prev_mode = ctl->mode[p];
+  return r;
+}
+__device__ __forceinline__ Sched mbox_sched_eval(const Ctl* ctl, const SchedRaw& r, uint32_t sweep, float delta, uint32_t near_low,
+                                                 uint32_t narrow_t) {
+  Sched s{0.0f, 0u, 0u, 0u, MODE_WIDE};
+  if (sweep == 0) {
+    s.tau = ctl->tau0;
+    s.mode = narrow_t ? MODE_NARROW : MODE_WIDE;
+    return s;
+  }
+  uint32_t mine = r.mine;
+  for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
+  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
+  s.far_total = __shfl(mine, 32);
+  s.prev_near = cnt;
+  const float prev = __uint_as_float(r.prev_tau);
+  if (r.prev_mode == MODE_COLLECT) {  // the states listed under the previous threshold are followed under the same one
+    s.tau = prev;
+    s.mode = MODE_NARROW;
+    return s;
+  }
+  if (narrow_t && r.prev_mode == MODE_WIDE && cnt != 0u && cnt + s.far_total <= narrow_t) s.mode = MODE_COLLECT;
+  if (cnt >= near_low) {
+    s.tau = prev;
+  } else if (cnt) {
+    // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
+    // widen the band by delta and keep relaxing
+    s.tau = cnt < before ? prev + delta : prev;
+  } else {
+    const uint32_t st = min(r.prev_streak + 1u, 30u);
+    s.streak = st;
+    s.tau = prev + delta * (float)(1u << (st - 1u));
+  }
+  return s;
+}
+
+// a state improved by a NARROW launch that it does not follow itself: it waits in the masks for the next WIDE sweep
+__device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, uint32_t enc_d, bool is_far, uint32_t& far_new) {
+  const uint32_t bit = 1u << (t & 31u), b = t >> MB_LOG;
+  const uint32_t old = atomicOr(&mb.pend[t >> 5], bit);
+  if (!(old & bit)) {
+    atomicAdd(&mb.blk_pend[b], 1u);
+    if (is_far) {
+      atomicAdd(&mb.blk_far[b], 1u);
+      far_new += 1u;
+    }
+  }
+  atomicMin(&mb.blk_mind[b], enc_d);
+}
+
+// One NARROW launch of workgroup j: follows the entries of its segment, and what they improve, until nothing near is
+// left, the frontier has grown beyond what one workgroup should carry, or (while states wait beyond the threshold) it
+// has started to shrink — the rule by which sweep_tau widens the band.  `wl` = 2 x NW_CAP entries of LDS.
+__device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
+                                            uint64_t* __restrict__ key, const MboxView& mb, Ctl* __restrict__ ctl,
+                                            uint32_t* __restrict__ improved, uint32_t sweep, float tau, uint32_t far_total,
+                                            uint32_t near_low, uint32_t profile, uint32_t wl_n, uint32_t bp, uint4* wl,
+                                            uint32_t* s_n /*[4]: list sizes [0..1], far_new [2], stop flag [3]*/) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x;
+  const uint32_t sub = tid & 15u, grp = tid >> 4;
+  if (tid < wl_n) wl[tid] = mb.wl[(size_t)j * NW_SEG + tid];
+  if (tid == 0) {
+    s_n[0] = wl_n;
+    s_n[1] = 0;
+    s_n[2] = 0;
+    s_n[3] = 0;
+    if (wl_n) mb.wl_cnt[j] = 0;
+    if ((wl_n || bp) && *improved == 0u) *improved = 1u + MODE_NARROW;
+  }
+  if (wl_n == 0) return;  // (uniform: nothing to follow; whoever waits in this block's masks waits for a WIDE sweep)
+  __syncthreads();
+  uint32_t cur = 0, prev_n = 0, prev2_n = 0, far_new = 0;
+  unsigned long long p_arcs = 0, p_states = 0;
+  bool grew = false;
+  for (uint32_t level = 0;; ++level) {
+    const uint32_t n_lv = min(s_n[cur], NW_CAP);
+    const uint32_t far_seen = s_n[2];
+    if (n_lv == 0) break;
+    if (n_lv > NW_GROW) {
+      grew = true;
+      break;
+    }
+    if (level >= 2 && prev_n < prev2_n && (far_total | far_seen) != 0u) break;  // the band's tail: widen instead
+    if (level >= NW_MAX_LEVELS) {
+      grew = true;  // (keeps the threshold where it is: the rest is followed after the next WIDE sweep)
+      break;
+    }
+    const uint4* __restrict__ in = wl + cur * NW_CAP;
+    uint4* __restrict__ out = wl + (cur ^ 1u) * NW_CAP;
+    uint32_t* n_out = &s_n[cur ^ 1u];
+    for (uint32_t r0 = 0; r0 < n_lv; r0 += (MB_THREADS / 16) * NW_UNROLL) {
+      uint32_t i_[NW_UNROLL], end_[NW_UNROLL], h1_[NW_UNROLL];
+      float d_[NW_UNROLL];
+      bool more = false;
+      for (uint32_t u = 0; u < NW_UNROLL; ++u) {
+        const uint32_t e = r0 + grp + (MB_THREADS / 16) * u;
+        i_[u] = end_[u] = h1_[u] = 0;
+        d_[u] = 0.0f;
+        if (e < n_lv) {
+          const uint4 en = in[e];
+          uint32_t c = en.w & NW_DEG_SAT;
+          if (c == NW_DEG_SAT) c = offsets[en.x + 1] - en.y;
+          i_[u] = en.y + sub;
+          end_[u] = en.y + c;
+          d_[u] = dec_f32(en.z);
+          h1_[u] = (en.w >> MB_LOG) + 1u;
+          if (profile && sub == 0) {
+            p_arcs += c;
+            p_states += 1;
+          }
+        }
+        more |= i_[u] < end_[u];
+      }
+      more = __any(more);
+      while (more) {
+        uint2 a[NW_UNROLL];
+        bool v[NW_UNROLL];
+        for (uint32_t u = 0; u < NW_UNROLL; ++u) {
+          v[u] = i_[u] < end_[u];
+          a[u] = make_uint2(0x7F800000u, 0u);
+          if (v[u]) a[u] = wn[i_[u]];
+        }
+        uint32_t enc[NW_UNROLL], tb[NW_UNROLL], te[NW_UNROLL];
+        unsigned long long ck[NW_UNROLL], old[NW_UNROLL];
+        for (uint32_t u = 0; u < NW_UNROLL; ++u) {
+          const float c = (d_[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+          v[u] = v[u] && c < INF;                                    // +inf never improves (shortest_path.rs:226)
+          enc[u] = enc_f32(c);
+          ck[u] = ((unsigned long long)enc[u] << 32) | h1_[u];
+          old[u] = 0;
+          tb[u] = te[u] = 0;
+          if (v[u]) {  // the atomic and the target's arc range travel together: the entry it may become needs no further trip
+            old[u] = atomicMin((unsigned long long*)&key[a[u].y], ck[u]);
+            tb[u] = offsets[a[u].y];
+            te[u] = offsets[a[u].y + 1];
+          }
+        }
+        more = false;
+        for (uint32_t u = 0; u < NW_UNROLL; ++u) {
+          const bool won = v[u] && ck[u] < old[u];
+          if (won) {
+            if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;  // hop count beyond the message format: the host refuses the result
+            bool listed = false;
+            if (dec_f32(enc[u]) <= tau) {
+              const uint32_t slot = atomicAdd(n_out, 1u);
+              if (slot < NW_CAP) {
+                out[slot] = make_uint4(a[u].y, tb[u], enc[u], (h1_[u] << MB_LOG) | min(te[u] - tb[u], NW_DEG_SAT));
+                listed = true;
+              }
+              if (!listed) mbox_make_wait(mb, a[u].y, enc[u], false, far_new);
+            } else {
+              mbox_make_wait(mb, a[u].y, enc[u], true, far_new);
+            }
+          }
+          i_[u] += 16;
+          more |= i_[u] < end_[u];
+        }
+        more = __any(more);
+      }
+    }
+    // what this level found beyond the threshold, for the shrink rule of the next levels
+    {
+      uint32_t f = far_new;
+      for (int d = 32; d >= 1; d >>= 1) f += __shfl_xor(f, d);
+      if (lane == 0 && f) atomicAdd(&s_n[2], f);
+      if (lane == 0 && f) atomicAdd(&ctl->far[(j % NEAR_SHARDS) * NEAR_STRIDE], f);
+      far_new = 0;
+    }
+    __syncthreads();  // the next list is complete; the current one is free
+    if (tid == 0) s_n[cur] = 0;
+    prev2_n = prev_n;
+    prev_n = n_lv;
+    cur ^= 1u;
+    __syncthreads();
+  }
+  // whatever is still listed waits for the next WIDE sweep (near states: it expands them at once)
+  {
+    const uint32_t left = min(s_n[cur], NW_CAP);
+    const uint4* __restrict__ in = wl + cur * NW_CAP;
+    uint32_t dummy = 0;
+    for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false, dummy);
+    // a frontier that outgrew the workgroup keeps the threshold where it is (>= near_low activations: sweep_tau's rule);
+    // otherwise the next sweep sees no near activations and widens the band
+    if (tid == 0 && grew) atomicAdd(&ctl->near[sweep % NEAR_RING][(j % NEAR_SHARDS) * NEAR_STRIDE], near_low);
+  }
+  if (profile) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      p_arcs += __shfl_xor(p_arcs, d);
+      p_states += __shfl_xor(p_states, d);
+    }
+    if (lane == 0 && p_states) {
+      atomicAdd(&ctl->arcs[(j % PROF_SHARDS) * PROF_STRIDE], p_arcs);
+      atomicAdd(&ctl->states[(j % PROF_SHARDS) * PROF_STRIDE], p_states);
+    }
+  }
+}
+
+// One mailbox launch.  Workgroup j, WIDE mode:
+//   trip 1  counts of its inbox regions, pending words, the schedule words, AND (speculatively, unless the host hints
+//           that this slot is probably not WIDE or idle: `hint`) the block's keys and offsets
 //           -> nothing arrives and nobody waiting is near: leave
 //   trip 2  the messages; candidates applied with LDS atomicMin
 //   scan    states whose key changed or that were waiting: written back; near ones (d <= tau) listed, far ones wait
@@ -120,17 +366,20 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 //   flush   staged messages leave as contiguous runs; counts of the regions written; the new waiting set
 // The kernel is bound by its chain of dependent round trips (global AND LDS), so every phase asks for all it needs
 // at once: no prefix sums, no searches, no shuffle reductions (ballots and one LDS atomic per wave instead).
+// BIG: more than 256 blocks — inbox counts staged through LDS, regions visited in passes of 256.
+template <bool BIG>
 __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                                uint64_t* __restrict__ key, MboxView mb, uint32_t par_in, uint32_t n,
                                                                uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
-                                                               uint32_t sweep, float delta, uint32_t near_low, uint32_t profile) {
+                                                               uint32_t sweep, float delta, uint32_t near_low, uint32_t profile,
+                                                               uint32_t hint, uint32_t narrow_t) {
+  extern __shared__ __align__(16) unsigned char mb_dyn[];
   __shared__ unsigned long long lkey[MB_B];
   __shared__ uint32_t l_off[MB_B + 1];
   __shared__ uint16_t a_state[MB_B];  // states expanded in this sweep
-  __shared__ uint2 l_stage[MB_NBMAX * MB_STG];
-  __shared__ uint32_t l_roff_out[MB_NBMAX], l_cur[MB_NBMAX], l_base[MB_NBMAX];
   __shared__ uint32_t s_wany[MB_THREADS / 64];
-  __shared__ uint32_t s_an, s_sent, s_npend, s_mind;
+  __shared__ uint32_t s_an, s_sent, s_npend, s_mind, s_nfar;
+  __shared__ uint32_t s_nw[4];
   __shared__ unsigned long long s_prof_arcs;
   constexpr uint32_t R = MB_B / MB_THREADS;  // states per thread
   constexpr uint32_t PW = MB_B / 32;         // pending words per block
@@ -138,63 +387,96 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
 
   // `sweep` is the absolute sweep index: the host knows it (plain launches), which saves the trip to ctl->base
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t j = blockIdx.x, nb = mb.nb;
+  const uint32_t j = blockIdx.x, nb = mb.nb, stg = mb.stg;
+  uint2* const l_stage = (uint2*)mb_dyn;                         // [nb * stg]
+  uint32_t* const l_roff_out = (uint32_t*)(l_stage + nb * stg);  // [nb]
+  uint32_t* const l_cur = l_roff_out + nb;                       // [nb]
+  uint32_t* const l_base = l_cur + nb;                           // [nb]
+  uint32_t* const l_cin = (uint32_t*)l_stage;                    // BIG: inbox counts / region offsets until the expansion
+  uint32_t* const l_rin = l_cin + nb;
   const uint32_t par_out = par_in ^ 1u;
   const uint32_t s0 = j << MB_LOG;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
   MB_STAMP(0);
 
-  // ---- trip 1.  Inbox region i is read by threads 4i .. 4i+3.
+  // ---- trip 1.  Inbox region i is read by threads 4i .. 4i+3 (BIG: in passes of 256 regions).
   const uint32_t reg = tid >> 2, q = tid & 3u;
   uint32_t c_in = 0, rb_in = 0;
-  if (reg < nb) {
-    c_in = mb.cnt[par_in][j * nb + reg];
-    rb_in = mb.roff[j * nb + reg];
+  bool my_any = false;
+  if (!BIG) {
+    if (reg < nb) {
+      c_in = mb.cnt[par_in][j * nb + reg];
+      rb_in = mb.roff[j * nb + reg];
+    }
+  } else {
+    for (uint32_t i = tid; i < nb; i += MB_THREADS) {
+      const uint32_t c = mb.cnt[par_in][(size_t)j * nb + i];
+      l_cin[i] = c;
+      l_rin[i] = mb.roff[(size_t)j * nb + i];
+      my_any |= c != 0;
+    }
   }
   uint32_t pw[R];  // pending words of this thread's states (state tl = tid + 1024 r sits in word (tid >> 5) + 32 r)
   for (uint32_t r = 0; r < R; ++r) pw[r] = mb.pend[j * PW + (tid >> 5) + WPR * r];
-  const uint32_t bp = mb.blk_pend[j], bmind = mb.blk_mind[j], wrote_out = mb.wrote[par_out][j];
+  const uint32_t bp = mb.blk_pend[j], bmind = mb.blk_mind[j], bfar = mb.blk_far[j], wrote_out = mb.wrote[par_out][j];
+  const uint32_t wl_n = min(mb.wl_cnt[j], NW_SEG);
   unsigned long long kreg[R];
-  for (uint32_t r = 0; r < R; ++r) {
-    const uint32_t s = s0 + tid + MB_THREADS * r;
-    kreg[r] = KEY_INF;
-    uint32_t o = 0;
-    if (s < n) {
-      kreg[r] = key[s];
-      o = offsets[s];
-    } else if (s == n) {
-      o = offsets[n];
+  uint32_t oreg[R], o_last = 0;
+  auto bulk_load = [&]() {
+    for (uint32_t r = 0; r < R; ++r) {
+      const uint32_t s = s0 + tid + MB_THREADS * r;
+      kreg[r] = KEY_INF;
+      oreg[r] = 0;
+      if (s < n) {
+        kreg[r] = key[s];
+        oreg[r] = offsets[s];
+      } else if (s == n) {
+        oreg[r] = offsets[n];
+      }
     }
-    l_off[tid + MB_THREADS * r] = o;
-    lkey[tid + MB_THREADS * r] = kreg[r];
+    if (tid == 0) o_last = s0 + MB_B <= n ? offsets[s0 + MB_B] : 0u;
+  };
+  auto bulk_store = [&]() {
+    for (uint32_t r = 0; r < R; ++r) {
+      l_off[tid + MB_THREADS * r] = oreg[r];
+      lkey[tid + MB_THREADS * r] = kreg[r];
+    }
+    if (tid == 0) l_off[MB_B] = o_last;
+  };
+  if (!hint) bulk_load();
+  // (the sender-side tables of the expansion: 1 KB, asked for with everything else)
+  for (uint32_t d = tid; d < nb; d += MB_THREADS) {
+    l_roff_out[d] = mb.roff_t[(size_t)j * nb + d];
+    l_cur[d] = 0;
+    l_base[d] = 0;
   }
-  if (tid == 0) l_off[MB_B] = s0 + MB_B <= n ? offsets[s0 + MB_B] : 0u;
-  if (tid < nb) {
-    l_roff_out[tid] = mb.roff_t[j * nb + tid];
-    l_cur[tid] = 0;
-    l_base[tid] = 0;
-  }
-  // every wave works the threshold out for itself (the same few words: one trip, no LDS hand-over)
-  uint32_t streak, prev_near;
-  const float tau = sweep_tau(ctl, sweep, delta, near_low, &streak, &prev_near);
+  // every wave works the schedule out for itself (the same few words: one trip, no LDS hand-over)
+  const SchedRaw raw = mbox_sched_load(ctl, sweep);
+  const Sched sc = mbox_sched_eval(ctl, raw, sweep, delta, near_low, narrow_t);
+  const float tau = sc.tau;
+  const uint32_t mode = sc.mode;
+  if (!hint) bulk_store();
   if (tid < 64) {
     if (tid == 0) {
       s_an = 0;
       s_sent = 0;
       s_npend = 0;
+      s_nfar = 0;
       s_mind = 0xFFFFFFFFu;
       s_prof_arcs = 0;
     }
     if (j == 0) {
       if (tid == 0) {
         ctl->tau[sweep % RING] = __float_as_uint(tau);
-        ctl->streak[sweep % RING] = streak;
+        ctl->streak[sweep % RING] = sc.streak;
+        ctl->mode[sweep % RING] = mode;
       }
       if (tid < NEAR_SHARDS) ctl->near[(sweep + 1) % NEAR_RING][tid * NEAR_STRIDE] = 0;  // recycle
     }
   }
   {
-    const bool wany = __ballot(c_in != 0) != 0;
+    if (!BIG) my_any = c_in != 0;
+    const bool wany = __ballot(my_any) != 0;
     if (lane == 0) s_wany[tid >> 6] = wany ? 1u : 0u;
   }
   __syncthreads();
@@ -204,22 +486,38 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     any_in |= (f.x | f.y | f.z | f.w) != 0;
   }
   MB_STAMP(1);
-  const bool waiting = bp != 0;
-  if (!any_in && (!waiting || dec_f32(bmind) > tau)) {
-    // nothing arrives and nobody who waits is near: the block sleeps through this sweep
+  if (mode == MODE_NARROW) {
+    // (no messages are in flight: the launch before this one was a COLLECT, or this is sweep 0)
     if (wrote_out) {  // counts this workgroup published two sweeps ago are still in the column it writes now
-      for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][d * nb + j] = 0;
+      for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = 0;
       if (tid == 0) mb.wrote[par_out][j] = 0;
     }
-    if (waiting && tid == 0 && *improved == 0u) *improved = 1u;  // the solve is not over
+    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bp, (uint4*)lkey, s_nw);
     MB_STAMP(15);
     return;
   }
+  const bool waiting = bp != 0;
+  if (!any_in && (!waiting || dec_f32(bmind) > tau)) {
+    // nothing arrives and nobody who waits is near: the block sleeps through this sweep
+    if (wrote_out) {
+      for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = 0;
+      if (tid == 0) mb.wrote[par_out][j] = 0;
+    }
+    if (waiting && tid == 0 && *improved == 0u) *improved = 1u + mode;  // the solve is not over
+    MB_STAMP(15);
+    return;
+  }
+  if (hint) {  // gated launch: the block is awake, now it asks for its keys and offsets
+    bulk_load();
+    bulk_store();
+    __syncthreads();
+  }
+  const bool collect = mode == MODE_COLLECT;
 
   // ---- trip 2: the messages
   const uint2* __restrict__ msgs_in = mb.msgs[par_in];
-  {
-    constexpr uint32_t MU = 8;  // messages a thread requests at once (a region of up to 32 messages is one trip)
+  constexpr uint32_t MU = 8;  // messages a thread requests at once (a region of up to 32 messages is one trip)
+  if (!BIG) {
     for (uint32_t k0 = q; k0 < c_in; k0 += 4u * MU) {
       uint2 m[MU];
       for (uint32_t u = 0; u < MU; ++u) {
@@ -229,6 +527,20 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       for (uint32_t u = 0; u < MU; ++u)
         if (k0 + 4u * u < c_in)
           atomicMin(&lkey[m[u].x & (MB_B - 1u)], ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
+    }
+  } else {
+    for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / 4) {
+      const uint32_t c = l_cin[rg], rb = l_rin[rg];
+      for (uint32_t k0 = q; k0 < c; k0 += 4u * MU) {
+        uint2 m[MU];
+        for (uint32_t u = 0; u < MU; ++u) {
+          m[u] = make_uint2(0u, 0u);
+          if (k0 + 4u * u < c) m[u] = msgs_in[rb + k0 + 4u * u];
+        }
+        for (uint32_t u = 0; u < MU; ++u)
+          if (k0 + 4u * u < c)
+            atomicMin(&lkey[m[u].x & (MB_B - 1u)], ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
+      }
     }
   }
   __syncthreads();
@@ -240,20 +552,15 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   unsigned long long kn[R];  // keys after the inbox (what a later change from inside the block is measured against)
   {
     for (uint32_t r = 0; r < R; ++r) kn[r] = lkey[tid + MB_THREADS * r];
-    bool near_[R];
+    bool near_[R], act_[R];
     uint32_t n_near = 0;
     for (uint32_t r = 0; r < R; ++r) {
       const uint32_t tl = tid + MB_THREADS * r, s = s0 + tl;
       const bool chg = kn[r] != kreg[r];
-      const bool act = chg || ((pw[r] >> (tl & 31u)) & 1u) != 0;
+      act_[r] = chg || ((pw[r] >> (tl & 31u)) & 1u) != 0;
       if (chg) key[s] = kn[r];
-      const uint32_t ed = (uint32_t)(kn[r] >> 32);
-      near_[r] = act && dec_f32(ed) <= tau;
-      const bool far = act && !near_[r];
-      if (far) my_mind = min(my_mind, ed);
-      const unsigned long long fm = __ballot(far), nm = __ballot(near_[r]);
-      far_w[r] = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
-      n_near += (uint32_t)__popcll(nm);
+      near_[r] = act_[r] && dec_f32((uint32_t)(kn[r] >> 32)) <= tau;
+      n_near += (uint32_t)__popcll(__ballot(near_[r]));
     }
     uint32_t base = 0;
     if (n_near) {
@@ -262,98 +569,113 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     }
     for (uint32_t r = 0; r < R; ++r) {
       const unsigned long long nm = __ballot(near_[r]);
-      if (near_[r]) a_state[base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (uint16_t)(tid + MB_THREADS * r);
+      const uint32_t pos = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+      // COLLECT: a segment holds NW_SEG entries; the rest keeps waiting (and is expanded by the next WIDE sweep)
+      const bool listed = near_[r] && (!collect || pos < NW_SEG);
+      if (listed) a_state[pos] = (uint16_t)(tid + MB_THREADS * r);
+      const bool far = act_[r] && !listed;
+      if (far) my_mind = min(my_mind, (uint32_t)(kn[r] >> 32));
+      const unsigned long long fm = __ballot(far);
+      far_w[r] = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
       base += (uint32_t)__popcll(nm);
     }
   }
   __syncthreads();
   MB_STAMP(4);
 
-  // ---- expansion: 16 lanes per state, MB_UNROLL states per group in flight; one flush of the staging slots per round
-  const uint32_t an = s_an;
-  const uint32_t sub = tid & 15u, grp = tid >> 4;  // 64 groups
-  uint2* __restrict__ msgs_out = mb.msgs[par_out];
+  const uint32_t an = collect ? min(s_an, NW_SEG) : s_an;
   uint32_t sent = 0;  // wave-uniform
   unsigned long long p_arcs = 0;
-  constexpr uint32_t ROUND = (MB_THREADS / 16) * MB_UNROLL;  // states per round
-  for (uint32_t r0 = 0; r0 < an; r0 += ROUND) {
-    uint32_t tl_[MB_UNROLL];
-    for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-      const uint32_t e = r0 + grp + (MB_THREADS / 16) * u;
-      tl_[u] = e < an ? (uint32_t)a_state[e] : 0xFFFFFFFFu;
+  if (collect) {
+    // ---- hand-over: the states this sweep would have expanded become the block's segment of the work list
+    for (uint32_t e = tid; e < an; e += MB_THREADS) {
+      const uint32_t tl = a_state[e];
+      const unsigned long long k = lkey[tl];
+      const uint32_t b = l_off[tl], c = l_off[tl + 1] - b;
+      mb.wl[(size_t)j * NW_SEG + e] = make_uint4(s0 + tl, b, (uint32_t)(k >> 32), ((uint32_t)k << MB_LOG) | min(c, NW_DEG_SAT));
+      if ((uint32_t)k >> MB_HOP_BITS) ctl->pad = 1u;
     }
-    uint32_t i_[MB_UNROLL], end_[MB_UNROLL], h1_[MB_UNROLL];
-    float d_[MB_UNROLL];
-    bool more = false;
-    for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-      i_[u] = end_[u] = h1_[u] = 0;
-      d_[u] = 0.0f;
-      if (tl_[u] != 0xFFFFFFFFu) {
-        const unsigned long long k = lkey[tl_[u]];
-        const uint32_t b = l_off[tl_[u]];
-        end_[u] = l_off[tl_[u] + 1];
-        d_[u] = dec_f32((uint32_t)(k >> 32));
-        h1_[u] = (uint32_t)k + 1u;
-        if (profile && sub == 0) p_arcs += end_[u] - b;
-        i_[u] = b + sub;
-      }
-      more |= i_[u] < end_[u];
-    }
-    more = __any(more);
-    while (more) {
-      uint2 a[MB_UNROLL];
-      bool v[MB_UNROLL];
+    if (tid == 0) mb.wl_cnt[j] = an;
+  } else {
+    // ---- expansion: 16 lanes per state, MB_UNROLL states per group in flight; one flush of the staging slots per round
+    const uint32_t sub = tid & 15u, grp = tid >> 4;  // 64 groups
+    uint2* __restrict__ msgs_out = mb.msgs[par_out];
+    constexpr uint32_t ROUND = (MB_THREADS / 16) * MB_UNROLL;  // states per round
+    for (uint32_t r0 = 0; r0 < an; r0 += ROUND) {
+      uint32_t tl_[MB_UNROLL];
       for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-        v[u] = i_[u] < end_[u];
-        a[u] = make_uint2(0x7F800000u, 0u);
-        if (v[u]) a[u] = wn[i_[u]];
+        const uint32_t e = r0 + grp + (MB_THREADS / 16) * u;
+        tl_[u] = e < an ? (uint32_t)a_state[e] : 0xFFFFFFFFu;
       }
-      // candidates: same-block targets never leave LDS; the others take a slot of their destination's region
-      uint32_t enc[MB_UNROLL], slot[MB_UNROLL];
+      uint32_t i_[MB_UNROLL], end_[MB_UNROLL], h1_[MB_UNROLL];
+      float d_[MB_UNROLL];
+      bool more = false;
       for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-        const float c = (d_[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-        v[u] = v[u] && c < INF;                                    // +inf never improves (shortest_path.rs:226)
-        enc[u] = enc_f32(c);
-        if (v[u] && (a[u].y >> MB_LOG) == j) {
-          atomicMin(&lkey[a[u].y & (MB_B - 1u)], ((unsigned long long)enc[u] << 32) | h1_[u]);
-          v[u] = false;
+        i_[u] = end_[u] = h1_[u] = 0;
+        d_[u] = 0.0f;
+        if (tl_[u] != 0xFFFFFFFFu) {
+          const unsigned long long k = lkey[tl_[u]];
+          const uint32_t b = l_off[tl_[u]];
+          end_[u] = l_off[tl_[u] + 1];
+          d_[u] = dec_f32((uint32_t)(k >> 32));
+          h1_[u] = (uint32_t)k + 1u;
+          if (profile && sub == 0) p_arcs += end_[u] - b;
+          i_[u] = b + sub;
         }
-      }
-      for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-        slot[u] = 0;
-        if (v[u]) slot[u] = atomicAdd(&l_cur[a[u].y >> MB_LOG], 1u);
-      }
-      more = false;
-      for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-        if (v[u]) {
-          const uint2 msg = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
-          const uint32_t db = a[u].y >> MB_LOG, rel = slot[u] - l_base[db];
-          if (rel < MB_STG) l_stage[db * MB_STG + rel] = msg;
-          else msgs_out[l_roff_out[db] + slot[u]] = msg;
-          if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;  // cannot happen (header); the host refuses the result if it does
-        }
-        sent += (uint32_t)__popcll(__ballot(v[u]));
-        i_[u] += 16;
         more |= i_[u] < end_[u];
       }
-      more = __any(more);  // the counter above is wave-uniform: the whole wave stays in the loop
-    }
-    MB_STAMP(12);
-    __syncthreads();
-    MB_STAMP(13);
-    // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
-    if (reg < nb) {
-      const uint32_t b0 = l_base[reg], cnt = min(l_cur[reg] - b0, MB_STG), ro = l_roff_out[reg] + b0;
-      for (uint32_t k = q; k < cnt; k += 4) {
-        const uint2 sm = l_stage[reg * MB_STG + k];
-        if (MB_WT) __hip_atomic_store((unsigned long long*)&msgs_out[ro + k], ((unsigned long long)sm.y << 32) | sm.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else msgs_out[ro + k] = sm;
+      more = __any(more);
+      while (more) {
+        uint2 a[MB_UNROLL];
+        bool v[MB_UNROLL];
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          v[u] = i_[u] < end_[u];
+          a[u] = make_uint2(0x7F800000u, 0u);
+          if (v[u]) a[u] = wn[i_[u]];
+        }
+        // candidates: same-block targets never leave LDS; the others take a slot of their destination's region
+        uint32_t enc[MB_UNROLL], slot[MB_UNROLL];
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          const float c = (d_[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+          v[u] = v[u] && c < INF;                                    // +inf never improves (shortest_path.rs:226)
+          enc[u] = enc_f32(c);
+          if (v[u] && (a[u].y >> MB_LOG) == j) {
+            atomicMin(&lkey[a[u].y & (MB_B - 1u)], ((unsigned long long)enc[u] << 32) | h1_[u]);
+            v[u] = false;
+          }
+        }
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          slot[u] = 0;
+          if (v[u]) slot[u] = atomicAdd(&l_cur[a[u].y >> MB_LOG], 1u);
+        }
+        more = false;
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          if (v[u]) {
+            const uint2 msg = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
+            const uint32_t db = a[u].y >> MB_LOG, rel = slot[u] - l_base[db];
+            if (rel < stg) l_stage[db * stg + rel] = msg;
+            else msgs_out[l_roff_out[db] + slot[u]] = msg;
+            if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;  // hop count beyond the message format: the host refuses the result
+          }
+          sent += (uint32_t)__popcll(__ballot(v[u]));
+          i_[u] += 16;
+          more |= i_[u] < end_[u];
+        }
+        more = __any(more);  // the counter above is wave-uniform: the whole wave stays in the loop
       }
-    }
-    if (r0 + ROUND < an) {  // another round: its messages are staged from the current cursors on
+      MB_STAMP(12);
       __syncthreads();
-      if (tid < nb) l_base[tid] = l_cur[tid];
-      __syncthreads();
+      MB_STAMP(13);
+      // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
+      for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / 4) {
+        const uint32_t b0 = l_base[rg], cnt = min(l_cur[rg] - b0, stg), ro = l_roff_out[rg] + b0;
+        for (uint32_t k = q; k < cnt; k += 4) msgs_out[ro + k] = l_stage[rg * stg + k];
+      }
+      if (r0 + ROUND < an) {  // another round: its messages are staged from the current cursors on
+        __syncthreads();
+        for (uint32_t d = tid; d < nb; d += MB_THREADS) l_base[d] = l_cur[d];
+        __syncthreads();
+      }
     }
   }
   if (profile)
@@ -368,7 +690,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   // ---- states improved from inside the block during the expansion: written back; they wait (expanded next sweep).
   //      The new waiting set.
   {
-    uint32_t n_pend = 0;
+    uint32_t n_pend = 0, n_far = 0;
     for (uint32_t r = 0; r < R; ++r) {
       const uint32_t tl = tid + MB_THREADS * r;
       const unsigned long long k = lkey[tl];
@@ -381,6 +703,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       const uint32_t nw = far_w[r] | ((lane & 32u) ? (uint32_t)(sm >> 32) : (uint32_t)sm);
       if ((lane & 31u) == 0) {
         n_pend += (uint32_t)__popc(nw);
+        n_far += (uint32_t)__popc(far_w[r]);
         if (nw != pw[r]) mb.pend[j * PW + (tid >> 5) + WPR * r] = nw;
       }
     }
@@ -388,8 +711,10 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     if (has) {
       my_mind = wave_min_u32(my_mind);
       n_pend += __shfl_xor(n_pend, 32);  // lanes 0 and 32 hold the two words of the wave
+      n_far += __shfl_xor(n_far, 32);
       if (lane == 0) {
         atomicAdd(&s_npend, n_pend);
+        if (n_far) atomicAdd(&s_nfar, n_far);
         atomicMin(&s_mind, my_mind);
       }
     }
@@ -397,18 +722,22 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   __syncthreads();
 
   // ---- publish: region counts, activity
-  const uint32_t total_sent = s_sent, npend = s_npend;
+  const uint32_t total_sent = s_sent, npend = s_npend, nfar = s_nfar;
   const bool any_out = total_sent != 0;  // messages that left the block (same-block candidates are not counted)
   if (any_out || wrote_out)
-    for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][d * nb + j] = l_cur[d];
+    for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = l_cur[d];
   if (tid == 0) {
     if (any_out != (wrote_out != 0)) mb.wrote[par_out][j] = any_out ? 1u : 0u;
     if (npend != bp) mb.blk_pend[j] = npend;
     if (s_mind != bmind) mb.blk_mind[j] = s_mind;
-    if ((any_out || npend) && *improved == 0u) *improved = 1u;
+    if (nfar != bfar) {  // (unsigned wrap-around: the shards sum to the number of states waiting beyond the threshold)
+      mb.blk_far[j] = nfar;
+      atomicAdd(&ctl->far[(j % NEAR_SHARDS) * NEAR_STRIDE], nfar - bfar);
+    }
+    if ((any_out || npend || (collect && an)) && *improved == 0u) *improved = 1u + mode;
     // near activations of this sweep = the states it expanded (what the threshold schedule reads next sweep)
     if (an) atomicAdd(&ctl->near[sweep % NEAR_RING][(j % NEAR_SHARDS) * NEAR_STRIDE], an);
-    if (profile) {
+    if (profile && !collect) {
       if (s_prof_arcs) atomicAdd(&ctl->arcs[(j % PROF_SHARDS) * PROF_STRIDE], s_prof_arcs);
       if (an) atomicAdd(&ctl->states[(j % PROF_SHARDS) * PROF_STRIDE], (unsigned long long)an);
     }

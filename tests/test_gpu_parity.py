@@ -468,15 +468,18 @@ def test_chasing_does_not_change_results(oracle, monkeypatch, cap, budget, low, 
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"chase small {k}")
 
 
-@pytest.mark.parametrize("mailbox", ["2", "2:1", "2:3", "1", "0"])
+@pytest.mark.parametrize("mailbox", ["1", "1:narrow=0", "1:narrow=1000000000", "1:narrow=64", "1:hint=0", "1:hint=1", "0"])
 @pytest.mark.parametrize("delta", [None, "0", "0.7", "1000"])
 def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delta):
     """The owner-computes (mailbox) sweeps and the atomic sweeps reach the same fixed point: distances, hop counts and
     the path are bit-identical to the canonical oracle on graphs of less than one block, a partial last block, many
-    blocks, a sparse deep graph, epsilons, ties everywhere, and whatever the near-far band width is."""
-    monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox.split(":")[0])  # 2 = several rounds per launch, 2:k = at most k rounds
+    blocks, a sparse deep graph, epsilons, ties everywhere, and whatever the near-far band width is — with the hand-over
+    to NARROW launches off (narrow=0), at its default, forced whenever a sweep was busy (narrow=1e9: WIDE / COLLECT /
+    NARROW in turn, segments that overflow), and with every launch / no launch gated (hint)."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox.split(":")[0])
     if ":" in mailbox:
-        monkeypatch.setenv("WFST_SSSP_MBOX_ROUNDS", mailbox.split(":")[1])
+        k, v = mailbox.split(":")[1].split("=")
+        monkeypatch.setenv({"narrow": "WFST_SSSP_NARROW", "hint": "WFST_SSSP_HINT"}[k], v)
     if delta is not None:
         monkeypatch.setenv("WFST_SSSP_DELTA", delta)
     ctx = rustfst_amd.Context(0)
@@ -485,7 +488,7 @@ def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delt
         t = synth.make_transducer(n, fan, 64, p_eps, seed=seed)
         d = to_device(t, ctx)
         can = to_oracle(oracle, t).shortest_path_canonical()
-        for q in range(2):
+        for q in range(3):
             dist, hops = d.shortest_distance(want_hops=True)
             np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
             np.testing.assert_array_equal(hops, can.hops)
@@ -495,6 +498,25 @@ def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delt
         f = random_fst_flat(rng, int(rng.integers(2, 300)), 5, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2, weight_grid=1, max_w=4)
         ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"mailbox small {k}")
+
+
+@pytest.mark.parametrize("narrow", [None, "0", "1000000000"])
+def test_mailbox_sweeps_beyond_2_20_states(oracle, monkeypatch, narrow):
+    """More than 256 blocks of 4096 states (2.1M states, 10.5M arcs): the owner-computes sweeps visit their inbox regions
+    in passes and stage fewer messages per destination; distances, hop counts and the path are bit-identical to the
+    canonical oracle, and the mailbox kernel is what ran."""
+    if narrow is not None:
+        monkeypatch.setenv("WFST_SSSP_NARROW", narrow)
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(2_100_000, 5, 64, 0.0, seed=11)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    for q in range(2):
+        dist, hops = d.shortest_distance(want_hops=True)
+        assert ctx.stats()["relax_kernel"] == 1
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"2.1M states q={q}")
 
 
 def test_kdelta_gap_on_real_valued_weights(gpu_ctx):

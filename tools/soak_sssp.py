@@ -1,6 +1,6 @@
-"""Randomised differential soak of the relaxation kernels (atomic sweeps, mailbox sweeps, multi-round mailbox launches)
+"""Randomised differential soak of the relaxation kernels (atomic sweeps, mailbox sweeps with their NARROW launches)
 against the canonical CPU oracle: python tools/soak_sssp.py [seconds] [seed0].  Every case draws a kernel, a band width
-and, for the multi-round kernel, a round limit."""
+and, for the mailbox kernel, a hand-over threshold and a gating mode."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,9 +17,14 @@ counts = {}
 ctx = rustfst_amd.Context(0)
 while time.time() < t_end:
     rng = np.random.default_rng(77_000 + seed)
-    mode = ["0", "1", "2"][int(rng.integers(0, 3))]
+    mode = ["0", "1", "1"][int(rng.integers(0, 3))]
     os.environ["WFST_SSSP_MAILBOX"] = mode
-    os.environ["WFST_SSSP_MBOX_ROUNDS"] = str(int(rng.choice([1, 2, 5, 16384])))
+    os.environ["WFST_SSSP_NARROW"] = str(int(rng.choice([0, 8, 64, 8192, 1_000_000_000])))  # hand-over threshold of the NARROW launches
+    hint = rng.choice(["", "0", "1"])
+    if hint:
+        os.environ["WFST_SSSP_HINT"] = str(hint)
+    else:
+        os.environ.pop("WFST_SSSP_HINT", None)
     d = rng.choice(["", "0", "0.3", "2.5", "40"])
     if d:
         os.environ["WFST_SSSP_DELTA"] = str(d)
@@ -75,7 +80,7 @@ while time.time() < t_end:
         print("FAILED at seed", seed, "mode", mode, "delta", d, flush=True)
         raise
     except Exception:
-        print("FAILED at seed", seed, "mode", mode, "delta", d, "rounds", os.environ["WFST_SSSP_MBOX_ROUNDS"], "kind", kind, flush=True)
+        print("FAILED at seed", seed, "mode", mode, "delta", d, "narrow", os.environ["WFST_SSSP_NARROW"], "hint", hint, "kind", kind, flush=True)
         raise
     counts[mode] = counts.get(mode, 0) + 1
     seed += 1
