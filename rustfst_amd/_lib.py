@@ -123,7 +123,8 @@ def lib():
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        L = C.CDLL(LIB_PATH)
+        # (experiments only: WFST_LIB_PATH points tools/ A/B scripts at another build of the same ABI)
+        L = C.CDLL(os.environ.get("WFST_LIB_PATH") or LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
             fn.restype = res

@@ -56,6 +56,7 @@ constexpr uint32_t NEAR_SHARDS = 16;
 constexpr uint32_t NEAR_RING = 4;     // sweep k writes slot k % 4, reads k-1 and k-2, recycles k+1
 constexpr uint32_t NEAR_STRIDE = 32;  // one shard per 128-B line: atomics on one LINE serialise like one address
 constexpr uint32_t PROF_STRIDE = 16;  // u64 counters: one shard per 128-B line
+constexpr uint32_t NF_STRIDE = 16;
 constexpr uint32_t PROF_SHARDS = 64;
 constexpr uint32_t IMP_RING = 512;  // per-sweep "something happened" flags, indexed by sweep % IMP_RING
 
@@ -69,7 +70,9 @@ struct Ctl {
   // mailbox sweeps: the mode launch k ran in (MODE_*), and the number of states waiting beyond the threshold (sharded like
   // `near`; a block adds the change of its own count, unsigned wrap-around)
   uint32_t mode[RING];
-  uint32_t far[NEAR_SHARDS * NEAR_STRIDE];
+  // mailbox sweeps: what launch k counted, sharded like `near`, one u64 per shard: low word = near activations (the
+  // states it expanded), high word = states left waiting beyond the threshold (every block reports its own, asleep or not)
+  unsigned long long nf[NEAR_RING][NEAR_SHARDS * NF_STRIDE];
   // arcs / states relaxed so far (profiling only): sharded like `near`, shard j at [j * PROF_STRIDE]
   unsigned long long arcs[PROF_SHARDS * PROF_STRIDE];
   unsigned long long states[PROF_SHARDS * PROF_STRIDE];
@@ -742,6 +745,7 @@ struct Solve {
   uint32_t narrow_t = 0;     // mailbox: near + far-waiting states below which the sweeps hand over to NARROW launches (0 = never)
   uint64_t hint_mask = ~0ull;  // mailbox: bit k = launch k of this FST's last solve was not a busy WIDE sweep (gated launch)
   size_t mb_dyn = 0;         // dynamic LDS bytes of a mailbox launch
+  bool force_big = false;    // tests: the many-blocks variant of the kernel on a small FST (WFST_SSSP_BIG=1)
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -790,7 +794,7 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
     // hint = the launch is probably NOT a busy WIDE sweep (what the last solve of this FST did in that slot, or unknown):
     // it then finds out its mode and whether it sleeps BEFORE it asks for its 48 KB of keys and offsets
     const uint32_t hint = profile || abs_sweep >= 64 ? 1u : (uint32_t)((sv.hint_mask >> abs_sweep) & 1ull);
-    if (sv.mv.nb > MB_NBMAX)
+    if (sv.mv.nb > MB_NBMAX || sv.force_big)
       sssp_mbox_kernel<true><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
                                                                       sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
                                                                       profile, hint, sv.narrow_t);
@@ -879,6 +883,8 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     mv.nb = nb;
     // staging depth: what the dynamic LDS budget leaves after the three per-destination tables
     mv.stg = std::max<uint32_t>(1u, std::min<uint32_t>(MB_STG_MAX, (MB_DYN_BUDGET - 12u * nb) / (8u * nb)));
+    if (const char* e = std::getenv("WFST_SSSP_STG")) mv.stg = std::max<uint32_t>(1u, std::min<uint32_t>(mv.stg, (uint32_t)std::atoi(e)));
+    if (const char* e = std::getenv("WFST_SSSP_BIG")) sv.force_big = std::atoi(e) != 0;
     sv.mb_dyn = (size_t)nb * mv.stg * sizeof(uint2) + 3u * (size_t)nb * sizeof(uint32_t);
     static std::once_flag lds_once[64];  // (a function attribute is per device)
     std::call_once(lds_once[(unsigned)ctx->device & 63u], [] {

@@ -44,9 +44,11 @@ constexpr uint32_t MB_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-
 // modes of a launch (also what the activity flag of a sweep holds, + 1)
 constexpr uint32_t MODE_WIDE = 0, MODE_COLLECT = 1, MODE_NARROW = 2;
 // NARROW launches
-constexpr uint32_t NW_SEG = 256;        // work-list entries a block may hand over (COLLECT) per launch
+constexpr uint32_t NW_SEG = MB_B;       // work-list segment of a block (COLLECT hands over every state it would have expanded)
 constexpr uint32_t NW_CAP = 1024;       // entries per level a workgroup keeps in LDS (two lists of 16 KB)
-constexpr uint32_t NW_GROW = 384;       // a level wider than this goes back to the WIDE sweeps
+constexpr uint32_t NW_GROW = 384;       // head of the search (one workgroup): a level wider than this goes back to the WIDE sweeps
+constexpr uint32_t NW_GROW_MANY = 48;   // ... when every workgroup follows a segment (a level then costs atomics chip-wide)
+constexpr uint32_t NW_SMALL = 1024;     // near + far-waiting states below which a sweep hands over even while it grows
 constexpr uint32_t NW_UNROLL = 4;       // entries a 16-lane group relaxes at once
 constexpr uint32_t NW_MAX_LEVELS = 4096;
 constexpr uint32_t NW_DEG_SAT = 0xFFFu;  // arc count field of an entry; saturated = read offsets[s + 1]
@@ -142,45 +144,72 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // ---- the schedule of a launch: threshold (same rules as sweep_tau) and mode, from what the previous launches left in the
 // control block.  Two halves so that the loads can be issued together with everything else a launch asks for first.
 struct SchedRaw {
-  uint32_t mine, prev_tau, prev_streak, prev_mode;
+  uint2 mine;
 };
 struct Sched {
-  float tau;
+  float tau;      // the threshold on record for this launch (what the next launch continues from)
+  float tau_use;  // the threshold this launch lists / follows by: +inf in the hand-over launches (see below)
   uint32_t streak, prev_near, far_total, mode;
 };
-// lanes 0..15: near counter of sweep-1, 16..31: of sweep-2, 32..47: states waiting beyond the threshold (all sharded)
+// ONE vector load for every word of the schedule (separate loads in separate branches, or scalar loads issued after the
+// vector ones have been waited for, each cost a dependent trip of their own): lanes 0..15 the counters of sweep-1 (near
+// activations | states waiting beyond the threshold), 16..31 those of sweep-2, lane 32 / 33 / 34 the threshold, streak and
+// mode of sweep-1.
 __device__ __forceinline__ SchedRaw mbox_sched_load(const Ctl* ctl, uint32_t sweep) {
-  SchedRaw r{0u, 0u, 0u, MODE_WIDE};
+  SchedRaw r{make_uint2(0u, 0u)};
   if (sweep == 0) return r;
   const uint32_t lane = threadIdx.x & 63u, p = (sweep - 1) % RING;
-  if (lane < NEAR_SHARDS) r.mine = ctl->near[(sweep - 1) % NEAR_RING][lane * NEAR_STRIDE];
-  else if (lane < 2 * NEAR_SHARDS) r.mine = sweep >= 2 ? ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE] : 0u;
-  else if (lane < 3 * NEAR_SHARDS) r.mine = ctl->far[(lane - 2 * NEAR_SHARDS) * NEAR_STRIDE];
-  r.prev_tau = ctl->tau[p];
-  r.prev_streak = ctl->streak[p];
-  r.prev_mode = ctl->mode[p];
+  size_t off = offsetof(Ctl, tau0);  // (lanes without a word of their own read a harmless one)
+  if (lane < NEAR_SHARDS) off = offsetof(Ctl, nf) + ((size_t)((sweep - 1) % NEAR_RING) * NEAR_SHARDS * NF_STRIDE + lane * NF_STRIDE) * 8;
+  else if (lane < 2 * NEAR_SHARDS) off = offsetof(Ctl, nf) + ((size_t)((sweep + NEAR_RING - 2) % NEAR_RING) * NEAR_SHARDS * NF_STRIDE + (lane - NEAR_SHARDS) * NF_STRIDE) * 8;
+  else if (lane == 32) off = offsetof(Ctl, tau) + (size_t)p * 4;
+  else if (lane == 33) off = offsetof(Ctl, streak) + (size_t)p * 4;
+  else if (lane == 34) off = offsetof(Ctl, mode) + (size_t)p * 4;
+  r.mine = *(const uint2*)((const unsigned char*)ctl + off);  // (dword-aligned 8-byte loads are fine in global memory)
   return r;
 }
 __device__ __forceinline__ Sched mbox_sched_eval(const Ctl* ctl, const SchedRaw& r, uint32_t sweep, float delta, uint32_t near_low,
                                                  uint32_t narrow_t) {
-  Sched s{0.0f, 0u, 0u, 0u, MODE_WIDE};
+  Sched s{0.0f, 0.0f, 0u, 0u, 0u, MODE_WIDE};
   if (sweep == 0) {
-    s.tau = ctl->tau0;
+    s.tau = s.tau_use = ctl->tau0;
     s.mode = narrow_t ? MODE_NARROW : MODE_WIDE;
     return s;
   }
-  uint32_t mine = r.mine;
-  for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
-  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
-  s.far_total = __shfl(mine, 32);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t prev_tau = (uint32_t)__builtin_amdgcn_readlane((int)r.mine.x, 32);
+  const uint32_t prev_streak = (uint32_t)__builtin_amdgcn_readlane((int)r.mine.x, 33);
+  const uint32_t prev_mode = (uint32_t)__builtin_amdgcn_readlane((int)r.mine.x, 34);
+  const bool counts = lane < NEAR_SHARDS || (lane < 2 * NEAR_SHARDS && sweep >= 2);
+  uint32_t near = counts ? r.mine.x : 0u, far = counts ? r.mine.y : 0u;
+  // sums inside each row of 16 lanes (DPP row shifts: lane 15 of a row ends up with the row's total; no LDS trips)
+  near += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)near, 0x111, 0xF, 0xF, false);  // row_shr:1
+  far += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)far, 0x111, 0xF, 0xF, false);
+  near += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)near, 0x112, 0xF, 0xF, false);  // row_shr:2
+  far += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)far, 0x112, 0xF, 0xF, false);
+  near += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)near, 0x114, 0xF, 0xF, false);  // row_shr:4
+  far += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)far, 0x114, 0xF, 0xF, false);
+  near += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)near, 0x118, 0xF, 0xF, false);  // row_shr:8
+  far += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)far, 0x118, 0xF, 0xF, false);
+  const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)near, 15), before = (uint32_t)__builtin_amdgcn_readlane((int)near, 31);
+  s.far_total = (uint32_t)__builtin_amdgcn_readlane((int)far, 15);
   s.prev_near = cnt;
-  const float prev = __uint_as_float(r.prev_tau);
-  if (r.prev_mode == MODE_COLLECT) {  // the states listed under the previous threshold are followed under the same one
+  const float prev = __uint_as_float(prev_tau);
+  if (prev_mode == MODE_COLLECT) {
+    // The hand-over launches (COLLECT, then this NARROW one) ignore the threshold: what still waits beyond it is at most
+    // narrow_t states, listed and followed with everything else, so that ONE narrow launch drains the search instead of a
+    // WIDE / COLLECT / NARROW round per remaining band.  The threshold on record stays where it was: if the frontier
+    // grows again, the WIDE sweeps continue with the bands.
     s.tau = prev;
+    s.tau_use = INF;
     s.mode = MODE_NARROW;
     return s;
   }
-  if (narrow_t && r.prev_mode == MODE_WIDE && cnt != 0u && cnt + s.far_total <= narrow_t) s.mode = MODE_COLLECT;
+  // hand over when the near set is small and shrinking (the tail of the last band: whatever still waits beyond the
+  // threshold is counted in, so the growing head of a band never qualifies), or tiny either way
+  if (narrow_t && prev_mode == MODE_WIDE && cnt != 0u && cnt + s.far_total <= narrow_t &&
+      (cnt < before || cnt + s.far_total <= min(narrow_t, NW_SMALL)))
+    s.mode = MODE_COLLECT;
   if (cnt >= near_low) {
     s.tau = prev;
   } else if (cnt) {
@@ -188,25 +217,23 @@ __device__ __forceinline__ Sched mbox_sched_eval(const Ctl* ctl, const SchedRaw&
     // widen the band by delta and keep relaxing
     s.tau = cnt < before ? prev + delta : prev;
   } else {
-    const uint32_t st = min(r.prev_streak + 1u, 30u);
+    const uint32_t st = min(prev_streak + 1u, 30u);
     s.streak = st;
     s.tau = prev + delta * (float)(1u << (st - 1u));
   }
+  s.tau_use = s.mode == MODE_COLLECT ? INF : s.tau;
   return s;
 }
 
-// a state improved by a NARROW launch that it does not follow itself: it waits in the masks for the next WIDE sweep
-__device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, uint32_t enc_d, bool is_far, uint32_t& far_new) {
-  const uint32_t bit = 1u << (t & 31u), b = t >> MB_LOG;
-  const uint32_t old = atomicOr(&mb.pend[t >> 5], bit);
-  if (!(old & bit)) {
-    atomicAdd(&mb.blk_pend[b], 1u);
-    if (is_far) {
-      atomicAdd(&mb.blk_far[b], 1u);
-      far_new += 1u;
-    }
-  }
+// A state improved by a NARROW launch that it does not follow itself: it waits in the masks for the next WIDE sweep.
+// Nothing is read back (a returned atomic would be a third dependent trip per level): the block's far count may count a
+// state twice — it only steers the schedule, and the owner recomputes it the next time it runs — and "somebody waits" is
+// blk_mind != +inf (the owner keeps blk_pend exact for itself).
+__device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, uint32_t enc_d, bool is_far) {
+  const uint32_t b = t >> MB_LOG;
+  atomicOr(&mb.pend[t >> 5], 1u << (t & 31u));
   atomicMin(&mb.blk_mind[b], enc_d);
+  if (is_far) atomicAdd(&mb.blk_far[b], 1u);
 }
 
 // One NARROW launch of workgroup j: follows the entries of its segment, and what they improve, until nothing near is
@@ -215,20 +242,28 @@ __device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, u
 __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                             uint64_t* __restrict__ key, const MboxView& mb, Ctl* __restrict__ ctl,
                                             uint32_t* __restrict__ improved, uint32_t sweep, float tau, uint32_t far_total,
-                                            uint32_t near_low, uint32_t profile, uint32_t wl_n, uint32_t bp, uint4* wl,
-                                            uint32_t* s_n /*[4]: list sizes [0..1], far_new [2], stop flag [3]*/) {
+                                            uint32_t near_low, uint32_t profile, uint32_t wl_n, bool waits, uint32_t bfar,
+                                            uint4* wl, uint32_t* s_n /*[4]: list sizes [0..1], found beyond the threshold [2]*/) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x;
   const uint32_t sub = tid & 15u, grp = tid >> 4;
-  if (tid < wl_n) wl[tid] = mb.wl[(size_t)j * NW_SEG + tid];
+  unsigned long long* const nf = &ctl->nf[sweep % NEAR_RING][(j % NEAR_SHARDS) * NF_STRIDE];
+  for (uint32_t e = tid; e < wl_n; e += MB_THREADS) {  // (a segment longer than the list: the rest keeps waiting)
+    const uint4 en = mb.wl[(size_t)j * NW_SEG + e];
+    if (e < NW_CAP) wl[e] = en;
+    else mbox_make_wait(mb, en.x, en.z, false);
+  }
   if (tid == 0) {
-    s_n[0] = wl_n;
+    s_n[0] = min(wl_n, NW_CAP);
     s_n[1] = 0;
     s_n[2] = 0;
     s_n[3] = 0;
     if (wl_n) mb.wl_cnt[j] = 0;
-    if ((wl_n || bp) && *improved == 0u) *improved = 1u + MODE_NARROW;
+    if ((wl_n || waits) && *improved == 0u) *improved = 1u + MODE_NARROW;
   }
-  if (wl_n == 0) return;  // (uniform: nothing to follow; whoever waits in this block's masks waits for a WIDE sweep)
+  if (wl_n == 0) {  // (uniform) nothing to follow; whoever waits in this block's masks waits for a WIDE sweep
+    if (tid == 0 && bfar) atomicAdd(nf, (unsigned long long)bfar << 32);
+    return;
+  }
   __syncthreads();
   uint32_t cur = 0, prev_n = 0, prev2_n = 0, far_new = 0;
   unsigned long long p_arcs = 0, p_states = 0;
@@ -237,11 +272,14 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     const uint32_t n_lv = min(s_n[cur], NW_CAP);
     const uint32_t far_seen = s_n[2];
     if (n_lv == 0) break;
-    if (n_lv > NW_GROW) {
+    if (n_lv > (sweep == 0 ? NW_GROW : NW_GROW_MANY)) {
       grew = true;
       break;
     }
-    if (level >= 2 && prev_n < prev2_n && (far_total | far_seen) != 0u) break;  // the band's tail: widen instead
+    // the head of the search is one workgroup: it applies sweep_tau's rule itself — a near set that shrinks while states
+    // wait beyond the threshold is the tail of the band: widen instead.  (Later NARROW launches follow everything they
+    // were given, whatever its distance: tau is +inf there.)
+    if (sweep == 0 && level >= 2 && prev_n < prev2_n && (far_total | far_seen) != 0u) break;
     if (level >= NW_MAX_LEVELS) {
       grew = true;  // (keeps the threshold where it is: the rest is followed after the next WIDE sweep)
       break;
@@ -308,9 +346,10 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
                 out[slot] = make_uint4(a[u].y, tb[u], enc[u], (h1_[u] << MB_LOG) | min(te[u] - tb[u], NW_DEG_SAT));
                 listed = true;
               }
-              if (!listed) mbox_make_wait(mb, a[u].y, enc[u], false, far_new);
+              if (!listed) mbox_make_wait(mb, a[u].y, enc[u], false);
             } else {
-              mbox_make_wait(mb, a[u].y, enc[u], true, far_new);
+              mbox_make_wait(mb, a[u].y, enc[u], true);
+              far_new += 1u;
             }
           }
           i_[u] += 16;
@@ -324,7 +363,6 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
       uint32_t f = far_new;
       for (int d = 32; d >= 1; d >>= 1) f += __shfl_xor(f, d);
       if (lane == 0 && f) atomicAdd(&s_n[2], f);
-      if (lane == 0 && f) atomicAdd(&ctl->far[(j % NEAR_SHARDS) * NEAR_STRIDE], f);
       far_new = 0;
     }
     __syncthreads();  // the next list is complete; the current one is free
@@ -338,11 +376,14 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
   {
     const uint32_t left = min(s_n[cur], NW_CAP);
     const uint4* __restrict__ in = wl + cur * NW_CAP;
-    uint32_t dummy = 0;
-    for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false, dummy);
+    for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false);
     // a frontier that outgrew the workgroup keeps the threshold where it is (>= near_low activations: sweep_tau's rule);
-    // otherwise the next sweep sees no near activations and widens the band
-    if (tid == 0 && grew) atomicAdd(&ctl->near[sweep % NEAR_RING][(j % NEAR_SHARDS) * NEAR_STRIDE], near_low);
+    // otherwise the next sweep sees no near activations and widens the band.  High word: the states waiting beyond the
+    // threshold in this block before the launch, and those this workgroup has made wait anywhere.
+    if (tid == 0) {
+      const unsigned long long add = ((unsigned long long)(bfar + s_n[2]) << 32) | (grew ? near_low : 0u);
+      if (add) atomicAdd(nf, add);
+    }
   }
   if (profile) {
     for (int d = 32; d >= 1; d >>= 1) {
@@ -399,21 +440,28 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
   MB_STAMP(0);
 
-  // ---- trip 1.  Inbox region i is read by threads 4i .. 4i+3 (BIG: in passes of 256 regions).
+  // ---- trip 1: every load of the prologue is ISSUED before anything is consumed (an LDS store of a loaded value waits
+  // for it, and loads come back in order: one such store in front of the schedule words makes the prologue two trips).
+  // Inbox region i is read by threads 4i .. 4i+3 (BIG: in passes of 256 regions, counts staged through LDS).
   const uint32_t reg = tid >> 2, q = tid & 3u;
+  constexpr uint32_t NBR = BIG ? MB_NBMAX_BIG / MB_THREADS : 1;  // per-destination table entries per thread
   uint32_t c_in = 0, rb_in = 0;
-  bool my_any = false;
+  uint32_t cin_r[NBR], rin_r[NBR], ro_r[NBR];
   if (!BIG) {
     if (reg < nb) {
       c_in = mb.cnt[par_in][j * nb + reg];
       rb_in = mb.roff[j * nb + reg];
     }
-  } else {
-    for (uint32_t i = tid; i < nb; i += MB_THREADS) {
-      const uint32_t c = mb.cnt[par_in][(size_t)j * nb + i];
-      l_cin[i] = c;
-      l_rin[i] = mb.roff[(size_t)j * nb + i];
-      my_any |= c != 0;
+  }
+  for (uint32_t r = 0; r < NBR; ++r) {
+    const uint32_t d = tid + MB_THREADS * r;
+    cin_r[r] = rin_r[r] = ro_r[r] = 0;
+    if (d < nb) {
+      if (BIG) {
+        cin_r[r] = mb.cnt[par_in][(size_t)j * nb + d];
+        rin_r[r] = mb.roff[(size_t)j * nb + d];
+      }
+      ro_r[r] = mb.roff_t[(size_t)j * nb + d];
     }
   }
   uint32_t pw[R];  // pending words of this thread's states (state tl = tid + 1024 r sits in word (tid >> 5) + 32 r)
@@ -444,18 +492,28 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     if (tid == 0) l_off[MB_B] = o_last;
   };
   if (!hint) bulk_load();
-  // (the sender-side tables of the expansion: 1 KB, asked for with everything else)
-  for (uint32_t d = tid; d < nb; d += MB_THREADS) {
-    l_roff_out[d] = mb.roff_t[(size_t)j * nb + d];
-    l_cur[d] = 0;
-    l_base[d] = 0;
-  }
-  // every wave works the schedule out for itself (the same few words: one trip, no LDS hand-over)
+  // every wave works the schedule out for itself (the same few words: one trip, no LDS hand-over); its load goes last,
+  // so the LDS stores below only wait for what was asked for before it
   const SchedRaw raw = mbox_sched_load(ctl, sweep);
-  const Sched sc = mbox_sched_eval(ctl, raw, sweep, delta, near_low, narrow_t);
-  const float tau = sc.tau;
-  const uint32_t mode = sc.mode;
+  bool my_any = c_in != 0;
+  for (uint32_t r = 0; r < NBR; ++r) {
+    const uint32_t d = tid + MB_THREADS * r;
+    if (d < nb) {
+      if (BIG) {
+        l_cin[d] = cin_r[r];
+        l_rin[d] = rin_r[r];
+        my_any |= cin_r[r] != 0;
+      }
+      l_roff_out[d] = ro_r[r];
+      l_cur[d] = 0;
+      l_base[d] = 0;
+    }
+  }
   if (!hint) bulk_store();
+  const Sched sc = mbox_sched_eval(ctl, raw, sweep, delta, near_low, narrow_t);
+  const float tau = sc.tau_use;
+  const uint32_t mode = sc.mode;
+  unsigned long long* const nf = &ctl->nf[sweep % NEAR_RING][(j % NEAR_SHARDS) * NF_STRIDE];
   if (tid < 64) {
     if (tid == 0) {
       s_an = 0;
@@ -467,15 +525,14 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     }
     if (j == 0) {
       if (tid == 0) {
-        ctl->tau[sweep % RING] = __float_as_uint(tau);
+        ctl->tau[sweep % RING] = __float_as_uint(sc.tau);
         ctl->streak[sweep % RING] = sc.streak;
         ctl->mode[sweep % RING] = mode;
       }
-      if (tid < NEAR_SHARDS) ctl->near[(sweep + 1) % NEAR_RING][tid * NEAR_STRIDE] = 0;  // recycle
+      if (tid < NEAR_SHARDS) ctl->nf[(sweep + 1) % NEAR_RING][tid * NF_STRIDE] = 0;  // recycle
     }
   }
   {
-    if (!BIG) my_any = c_in != 0;
     const bool wany = __ballot(my_any) != 0;
     if (lane == 0) s_wany[tid >> 6] = wany ? 1u : 0u;
   }
@@ -492,18 +549,22 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = 0;
       if (tid == 0) mb.wrote[par_out][j] = 0;
     }
-    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bp, (uint4*)lkey, s_nw);
+    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bmind != 0xFFFFFFFFu, bfar,
+                (uint4*)lkey, s_nw);
     MB_STAMP(15);
     return;
   }
-  const bool waiting = bp != 0;
+  const bool waiting = bmind != 0xFFFFFFFFu;  // (blk_mind: the least distance among the block's waiting states)
   if (!any_in && (!waiting || dec_f32(bmind) > tau)) {
     // nothing arrives and nobody who waits is near: the block sleeps through this sweep
     if (wrote_out) {
       for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = 0;
       if (tid == 0) mb.wrote[par_out][j] = 0;
     }
-    if (waiting && tid == 0 && *improved == 0u) *improved = 1u + mode;  // the solve is not over
+    if (tid == 0) {
+      if (waiting && *improved == 0u) *improved = 1u + mode;  // the solve is not over
+      if (bfar) atomicAdd(nf, (unsigned long long)bfar << 32);  // its waiting states still count in the schedule
+    }
     MB_STAMP(15);
     return;
   }
@@ -552,15 +613,20 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   unsigned long long kn[R];  // keys after the inbox (what a later change from inside the block is measured against)
   {
     for (uint32_t r = 0; r < R; ++r) kn[r] = lkey[tid + MB_THREADS * r];
-    bool near_[R], act_[R];
+    bool near_[R];
     uint32_t n_near = 0;
     for (uint32_t r = 0; r < R; ++r) {
       const uint32_t tl = tid + MB_THREADS * r, s = s0 + tl;
       const bool chg = kn[r] != kreg[r];
-      act_[r] = chg || ((pw[r] >> (tl & 31u)) & 1u) != 0;
+      const bool act = chg || ((pw[r] >> (tl & 31u)) & 1u) != 0;
       if (chg) key[s] = kn[r];
-      near_[r] = act_[r] && dec_f32((uint32_t)(kn[r] >> 32)) <= tau;
-      n_near += (uint32_t)__popcll(__ballot(near_[r]));
+      const uint32_t ed = (uint32_t)(kn[r] >> 32);
+      near_[r] = act && dec_f32(ed) <= tau;
+      const bool far = act && !near_[r];
+      if (far) my_mind = min(my_mind, ed);
+      const unsigned long long fm = __ballot(far), nm = __ballot(near_[r]);
+      far_w[r] = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+      n_near += (uint32_t)__popcll(nm);
     }
     uint32_t base = 0;
     if (n_near) {
@@ -569,21 +635,14 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     }
     for (uint32_t r = 0; r < R; ++r) {
       const unsigned long long nm = __ballot(near_[r]);
-      const uint32_t pos = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
-      // COLLECT: a segment holds NW_SEG entries; the rest keeps waiting (and is expanded by the next WIDE sweep)
-      const bool listed = near_[r] && (!collect || pos < NW_SEG);
-      if (listed) a_state[pos] = (uint16_t)(tid + MB_THREADS * r);
-      const bool far = act_[r] && !listed;
-      if (far) my_mind = min(my_mind, (uint32_t)(kn[r] >> 32));
-      const unsigned long long fm = __ballot(far);
-      far_w[r] = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+      if (near_[r]) a_state[base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (uint16_t)(tid + MB_THREADS * r);
       base += (uint32_t)__popcll(nm);
     }
   }
   __syncthreads();
   MB_STAMP(4);
 
-  const uint32_t an = collect ? min(s_an, NW_SEG) : s_an;
+  const uint32_t an = s_an;
   uint32_t sent = 0;  // wave-uniform
   unsigned long long p_arcs = 0;
   if (collect) {
@@ -730,13 +789,11 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
     if (any_out != (wrote_out != 0)) mb.wrote[par_out][j] = any_out ? 1u : 0u;
     if (npend != bp) mb.blk_pend[j] = npend;
     if (s_mind != bmind) mb.blk_mind[j] = s_mind;
-    if (nfar != bfar) {  // (unsigned wrap-around: the shards sum to the number of states waiting beyond the threshold)
-      mb.blk_far[j] = nfar;
-      atomicAdd(&ctl->far[(j % NEAR_SHARDS) * NEAR_STRIDE], nfar - bfar);
-    }
+    if (nfar != bfar) mb.blk_far[j] = nfar;
     if ((any_out || npend || (collect && an)) && *improved == 0u) *improved = 1u + mode;
-    // near activations of this sweep = the states it expanded (what the threshold schedule reads next sweep)
-    if (an) atomicAdd(&ctl->near[sweep % NEAR_RING][(j % NEAR_SHARDS) * NEAR_STRIDE], an);
+    // what the schedule of the next launch reads: near activations of this sweep = the states it expanded (low word),
+    // states of this block still waiting beyond the threshold (high word)
+    if (an | nfar) atomicAdd(nf, ((unsigned long long)nfar << 32) | an);
     if (profile && !collect) {
       if (s_prof_arcs) atomicAdd(&ctl->arcs[(j % PROF_SHARDS) * PROF_STRIDE], s_prof_arcs);
       if (an) atomicAdd(&ctl->states[(j % PROF_SHARDS) * PROF_STRIDE], (unsigned long long)an);

@@ -20,6 +20,8 @@ while time.time() < t_end:
     mode = ["0", "1", "1"][int(rng.integers(0, 3))]
     os.environ["WFST_SSSP_MAILBOX"] = mode
     os.environ["WFST_SSSP_NARROW"] = str(int(rng.choice([0, 8, 64, 8192, 1_000_000_000])))  # hand-over threshold of the NARROW launches
+    os.environ["WFST_SSSP_BIG"] = str(int(rng.integers(0, 2)))  # the many-blocks variant of the kernel
+    os.environ["WFST_SSSP_STG"] = str(int(rng.choice([1, 2, 7, 24])))  # staging slots per destination
     hint = rng.choice(["", "0", "1"])
     if hint:
         os.environ["WFST_SSSP_HINT"] = str(hint)
@@ -80,7 +82,7 @@ while time.time() < t_end:
         print("FAILED at seed", seed, "mode", mode, "delta", d, flush=True)
         raise
     except Exception:
-        print("FAILED at seed", seed, "mode", mode, "delta", d, "narrow", os.environ["WFST_SSSP_NARROW"], "hint", hint, "kind", kind, flush=True)
+        print("FAILED at seed", seed, "mode", mode, "delta", d, "narrow", os.environ["WFST_SSSP_NARROW"], "hint", hint, "big", os.environ["WFST_SSSP_BIG"], "stg", os.environ["WFST_SSSP_STG"], "kind", kind, flush=True)
         raise
     counts[mode] = counts.get(mode, 0) + 1
     seed += 1
