@@ -243,9 +243,19 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
                                             uint64_t* __restrict__ key, const MboxView& mb, Ctl* __restrict__ ctl,
                                             uint32_t* __restrict__ improved, uint32_t sweep, float tau, uint32_t far_total,
                                             uint32_t near_low, uint32_t profile, uint32_t wl_n, bool waits, uint32_t bfar,
-                                            uint4* wl, uint32_t* s_n /*[4]: list sizes [0..1], found beyond the threshold [2]*/) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x;
+                                            uint4* wl, uint32_t* s_n /*[4]: list sizes [0..1], found beyond the threshold [2]*/,
+                                            uint32_t par_out, const uint32_t* l_roff_out, uint32_t* l_cur, uint32_t* l_cap) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x, nb = mb.nb;
   const uint32_t sub = tid & 15u, grp = tid >> 4;
+  // The head of the search (sweep 0, ONE workgroup at work): a candidate beyond the threshold is not this launch's
+  // business — it leaves as a MESSAGE to the target's owner, like in a WIDE sweep (region (j -> d): nobody else writes
+  // there in this launch), instead of a global atomicMin plus three more atomics to make it wait.  Nine candidates in ten
+  // of the head are such.  A region only has room for the arcs from block j to block d; what does not fit takes the
+  // atomic path.
+  const bool head = sweep == 0;
+  uint2* __restrict__ msgs_out = mb.msgs[par_out];
+  if (head && wl_n)
+    for (uint32_t d = tid; d < nb; d += MB_THREADS) l_cap[d] = mb.roff[(size_t)d * nb + j + 1] - mb.roff[(size_t)d * nb + j];
   unsigned long long* const nf = &ctl->nf[sweep % NEAR_RING][(j % NEAR_SHARDS) * NF_STRIDE];
   for (uint32_t e = tid; e < wl_n; e += MB_THREADS) {  // (a segment longer than the list: the rest keeps waiting)
     const uint4 en = mb.wl[(size_t)j * NW_SEG + e];
@@ -328,6 +338,15 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
           ck[u] = ((unsigned long long)enc[u] << 32) | h1_[u];
           old[u] = 0;
           tb[u] = te[u] = 0;
+          if (head && v[u] && c > tau) {
+            const uint32_t db = a[u].y >> MB_LOG, slot = atomicAdd(&l_cur[db], 1u);
+            if (slot < l_cap[db]) {
+              msgs_out[l_roff_out[db] + slot] = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
+              if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;
+              far_new += 1u;
+              v[u] = false;
+            }
+          }
           if (v[u]) {  // the atomic and the target's arc range travel together: the entry it may become needs no further trip
             old[u] = atomicMin((unsigned long long*)&key[a[u].y], ck[u]);
             tb[u] = offsets[a[u].y];
@@ -377,6 +396,15 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     const uint32_t left = min(s_n[cur], NW_CAP);
     const uint4* __restrict__ in = wl + cur * NW_CAP;
     for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false);
+    if (head) {  // the messages of the head: counts of the regions, like a WIDE sweep's publish
+      bool any = false;
+      for (uint32_t d = tid; d < nb; d += MB_THREADS) {
+        const uint32_t c = min(l_cur[d], l_cap[d]);
+        mb.cnt[par_out][(size_t)d * nb + j] = c;
+        any |= c != 0;
+      }
+      if (__any(any) && lane == 0) mb.wrote[par_out][j] = 1u;
+    }
     // a frontier that outgrew the workgroup keeps the threshold where it is (>= near_low activations: sweep_tau's rule);
     // otherwise the next sweep sees no near activations and widens the band.  High word: the states waiting beyond the
     // threshold in this block before the launch, and those this workgroup has made wait anywhere.
@@ -466,7 +494,10 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   }
   uint32_t pw[R];  // pending words of this thread's states (state tl = tid + 1024 r sits in word (tid >> 5) + 32 r)
   for (uint32_t r = 0; r < R; ++r) pw[r] = mb.pend[j * PW + (tid >> 5) + WPR * r];
-  const uint32_t bp = mb.blk_pend[j], bmind = mb.blk_mind[j], bfar = mb.blk_far[j], wrote_out = mb.wrote[par_out][j];
+  // (nothing loaded here is kept for the end of the kernel: a loaded value that has to be spilled is waited for on the
+  // spot, in the middle of the prologue's loads — the waiting set and its statistics are stored unconditionally instead)
+  const uint32_t bmind = mb.blk_mind[j], bfar = mb.blk_far[j];
+  const bool wrote_out = mb.wrote[par_out][j] != 0u;
   const uint32_t wl_n = min(mb.wl_cnt[j], NW_SEG);
   unsigned long long kreg[R];
   uint32_t oreg[R], o_last = 0;
@@ -482,14 +513,20 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
         oreg[r] = offsets[n];
       }
     }
-    if (tid == 0) o_last = s0 + MB_B <= n ? offsets[s0 + MB_B] : 0u;
+    // (the block's end offset: asked for by the LAST thread through its own index — a uniform address under `tid == 0`
+    // becomes a scalar load that the first wave waits for on the spot, before it has issued the rest of its prologue)
+    if (tid == MB_THREADS - 1 && s0 + MB_B <= n) {
+      uint32_t t = tid;
+      asm volatile("" : "+v"(t));  // (opaque: keeps the address in a vector register)
+      o_last = offsets[s0 + t + MB_THREADS * (R - 1) + 1];
+    }
   };
   auto bulk_store = [&]() {
     for (uint32_t r = 0; r < R; ++r) {
       l_off[tid + MB_THREADS * r] = oreg[r];
       lkey[tid + MB_THREADS * r] = kreg[r];
     }
-    if (tid == 0) l_off[MB_B] = o_last;
+    if (tid == MB_THREADS - 1) l_off[MB_B] = o_last;
   };
   if (!hint) bulk_load();
   // every wave works the schedule out for itself (the same few words: one trip, no LDS hand-over); its load goes last,
@@ -550,7 +587,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       if (tid == 0) mb.wrote[par_out][j] = 0;
     }
     mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bmind != 0xFFFFFFFFu, bfar,
-                (uint4*)lkey, s_nw);
+                (uint4*)lkey, s_nw, par_out, l_roff_out, l_cur, l_base);
     MB_STAMP(15);
     return;
   }
@@ -763,7 +800,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       if ((lane & 31u) == 0) {
         n_pend += (uint32_t)__popc(nw);
         n_far += (uint32_t)__popc(far_w[r]);
-        if (nw != pw[r]) mb.pend[j * PW + (tid >> 5) + WPR * r] = nw;
+        mb.pend[j * PW + (tid >> 5) + WPR * r] = nw;
       }
     }
     const unsigned long long has = __ballot(n_pend != 0);
@@ -786,10 +823,10 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   if (any_out || wrote_out)
     for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = l_cur[d];
   if (tid == 0) {
-    if (any_out != (wrote_out != 0)) mb.wrote[par_out][j] = any_out ? 1u : 0u;
-    if (npend != bp) mb.blk_pend[j] = npend;
-    if (s_mind != bmind) mb.blk_mind[j] = s_mind;
-    if (nfar != bfar) mb.blk_far[j] = nfar;
+    if (any_out != wrote_out) mb.wrote[par_out][j] = any_out ? 1u : 0u;
+    mb.blk_pend[j] = npend;
+    mb.blk_mind[j] = s_mind;
+    mb.blk_far[j] = nfar;
     if ((any_out || npend || (collect && an)) && *improved == 0u) *improved = 1u + mode;
     // what the schedule of the next launch reads: near activations of this sweep = the states it expanded (low word),
     // states of this block still waiting beyond the threshold (high word)
