@@ -36,7 +36,7 @@ def kernel_sources_sha256():
     state of the kernel is flagged stale in the bench line"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_mailbox_async.h"):
+    for name in ("sssp.hip", "sssp_mailbox.h"):
         with open(os.path.join(ROOT, "rustfst_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -372,29 +372,34 @@ def main():
                 st = dict(st)
                 st["relax_ms"], st["relax_launches"] = chain[len(chain) // 2]
             if st["relax_ms"] > 0:
-                algo_bytes = 20.0 * st["relax_arcs"] + 12.0 * st["relax_states"]
-                achieved = algo_bytes / (st["relax_ms"] * 1e-3) / 1e9
+                # SURVEY §8(d) accounting (the contract figure): every arc of T counted ONCE, B_relax = 20 E + 12 N bytes
+                # per solve, over the summed relaxation-kernel time of the solve — re-relaxed arcs earn nothing
+                solve_bytes = 20.0 * e_t + 12.0 * args.states
+                achieved = solve_bytes / (st["relax_ms"] * 1e-3) / 1e9
+                # the same time against the arcs / states the launches actually relaxed (bands re-relax some arcs)
+                relaxed_bytes = 20.0 * st["relax_arcs"] + 12.0 * st["relax_states"]
+                algo_bytes = solve_bytes
                 roofline = {
                     "kernel": relax_kernel, "bound": "hbm", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "accounting": "SURVEY 8(d): B_relax = 20 E + 12 N bytes per solve (each arc once) / summed kernel time of the solve's launches",
                     "launches": int(st["relax_launches"]),
                     "avg_launch_us": round(1e3 * st["relax_ms"] / max(1, st["relax_launches"]), 2),
-                    "algorithmic_bytes_per_launch": round(algo_bytes / max(1, st["relax_launches"]), 1),
-                    "arcs_relaxed": int(st["relax_arcs"]), "frontier_states": int(st["relax_states"]),
-                    "relax_arcs_per_s": round(st["relax_arcs"] / (st["relax_ms"] * 1e-3), 1),
-                    # SURVEY §8(d)/BASELINE.md per-SOLVE accounting: every arc of T counted once (20 E + 12 N bytes)
-                    # over the summed relaxation-kernel time of the solve; rewards relaxing FEWER arcs
+                    "algorithmic_bytes_per_launch": round(solve_bytes / max(1, st["relax_launches"]), 1),
                     "solve_algorithmic_bytes": 20 * e_t + 12 * args.states,
                     "solve_relax_kernel_ms": round(st["relax_ms"], 4),
-                    "solve_achieved": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9, 2),
-                    "solve_frac": round((20.0 * e_t + 12.0 * args.states) / (st["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "solve_frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "arcs_relaxed": int(st["relax_arcs"]), "frontier_states": int(st["relax_states"]),
+                    "relax_arcs_per_s": round(st["relax_arcs"] / (st["relax_ms"] * 1e-3), 1),
                     "re_relaxation_factor": round(st["relax_arcs"] / max(1, e_t), 3),
-                    "timing": ("HIP events around the pre-queued sweep chain of un-profiled repeated queries (median of "
+                    # (round 2 quoted this one as `frac`: it credits the re-relaxed arcs)
+                    "frac_of_relaxed_arcs": round(relaxed_bytes / (st["relax_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "timing": ("HIP events around the pre-queued launch chain of un-profiled repeated queries (median of "
                                f"{len(chain)}); arcs / states counted by one separate profiled solve") if chain else
                               "HIP events around every launch of one profiled solve (synchronised after each)",
                     "profiled_solve": {"launches": int(profiled_launches), "relax_kernel_ms": round(profiled_ms, 4),
                                        "avg_launch_us": round(1e3 * profiled_ms / max(1, profiled_launches), 2),
-                                       "note": "per-launch events + a synchronisation after every sweep: each sweep starts on an idle GPU"},
+                                       "note": "per-launch events + a synchronisation after every launch: each starts on an idle GPU"},
                 }
                 # HBM-side traffic cannot be counted live: it comes from the committed rocprofv3 PMC passes of this
                 # same command (profiles/pmc_relax_traffic.json, regenerated by tools/profile_round.sh), per launch

@@ -81,7 +81,7 @@ PinnedBuf::~PinnedBuf() {
 }  // namespace wfst
 
 DeviceArena::~DeviceArena() {
-  if (base && ctx && ctx->pool) ctx->pool->free(base);
+  if (base && pool) pool->free(base);
 }
 
 using namespace wfst;
@@ -104,7 +104,7 @@ static wfst_ctx* ctx_create(int device, void* stream, bool own, const uint32_t* 
   } else {
     ctx->stream = (hipStream_t)stream;
   }
-  ctx->pool = std::make_unique<DevicePool>(device);
+  ctx->pool = std::make_shared<DevicePool>(device);
   HIP_CHECK(hipEventCreate(&ctx->ev0));
   HIP_CHECK(hipEventCreate(&ctx->ev1));
   hipDeviceProp_t prop;
@@ -267,7 +267,7 @@ wfst_status wfst_fst_download(const wfst_fst* fst, uint32_t* offsets, wfst_tr* a
 wfst_status wfst_fst_destroy(wfst_fst* fst) {
   return wrap([&] {
     if (!fst) return;
-    if (fst->ctx) (void)hipSetDevice(fst->ctx->device);
+    (void)hipSetDevice(fst->device);
     delete fst;
   });
 }

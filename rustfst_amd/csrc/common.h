@@ -107,7 +107,9 @@ struct wfst_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
-  std::unique_ptr<wfst::DevicePool> pool;
+  // shared with every FST handle created on this context (and its arenas): the device memory of a handle that outlives
+  // its context (interpreter shutdown destroys in any order) is still released to a live pool, which goes with the last owner
+  std::shared_ptr<wfst::DevicePool> pool;
   wfst::PinnedBuf pinned;      // small D2H/H2D staging
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
@@ -137,7 +139,7 @@ struct wfst_ctx {
 // Device-resident CSR. All arrays live in one arena allocation that may be
 // shared between several FSTs (wfst_fst_upload_many).
 struct DeviceArena {
-  wfst_ctx* ctx = nullptr;
+  std::shared_ptr<wfst::DevicePool> pool;
   void* base = nullptr;
   size_t bytes = 0;
   ~DeviceArena();
@@ -196,7 +198,10 @@ struct HostCsr {
 };
 
 struct wfst_fst {
-  wfst_ctx* ctx = nullptr;
+  // (first member = destroyed last: the caches below release their buffers into it)
+  std::shared_ptr<wfst::DevicePool> owner_pool;
+  int device = 0;
+  wfst_ctx* ctx = nullptr;  // the creating context: only dereferenced inside API calls, which need it alive anyway
   uint32_t n_states = 0;
   uint64_t n_arcs = 0;
   int64_t start = -1;

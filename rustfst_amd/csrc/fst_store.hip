@@ -141,7 +141,7 @@ Layout make_layout(size_t n_offsets, size_t n_states, size_t n_arcs) {
 
 std::shared_ptr<DeviceArena> make_arena(wfst_ctx* ctx, size_t bytes) {
   auto a = std::make_shared<DeviceArena>();
-  a->ctx = ctx;
+  a->pool = ctx->pool;
   a->base = ctx->pool->alloc(bytes);
   a->bytes = bytes;
   return a;
@@ -158,7 +158,7 @@ const uint2* ensure_anext(wfst_ctx* ctx, const wfst_fst* f) {
   std::lock_guard<std::mutex> lk(f->cache_mu);
   if (f->anext) return f->anext->p;
   if (!f->has_dev || f->n_arcs == 0) return nullptr;
-  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;
   auto buf = std::make_shared<DBuf<uint2>>(owner_pool, f->n_arcs);
   int blocks = (int)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 16);
   derive_anext_kernel<<<blocks, 256, 0, ctx->stream>>>(f->dev.arcs, f->dev.offsets, buf->p, f->n_arcs, f->n_states);
@@ -257,6 +257,8 @@ DeviceCsr carve(const std::shared_ptr<DeviceArena>& arena, const Layout& l) {
 wfst_fst* make_host_fst(wfst_ctx* ctx, uint32_t n_states, int64_t start, uint64_t props, HostCsr&& csr) {
   auto f = std::make_unique<wfst_fst>();
   f->ctx = ctx;
+  f->owner_pool = ctx->pool;
+  f->device = ctx->device;
   f->n_states = n_states;
   f->n_arcs = csr.arcs.size();
   f->start = start;
@@ -289,6 +291,8 @@ static wfst_fst* upload_generic(wfst_ctx* ctx, uint32_t n_states, int64_t start,
   f->mean_weight = mean_w;
   f->has_negative = has_neg;
   f->ctx = ctx;
+  f->owner_pool = ctx->pool;
+  f->device = ctx->device;
   f->n_states = n_states;
   f->n_arcs = n_arcs;
   f->start = start;
@@ -380,6 +384,8 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
   for (size_t i = 0; i < n; ++i) {
     auto f = std::make_unique<wfst_fst>();
     f->ctx = ctx;
+    f->owner_pool = ctx->pool;
+    f->device = ctx->device;
     f->n_states = n_states[i];
     f->n_arcs = (offsets_cat + state_base[i] + i)[n_states[i]];
     f->start = starts[i];

@@ -119,7 +119,7 @@ std::shared_ptr<RevFst> build_reverse(wfst_ctx* ctx, const wfst_fst* f) {
   if (E) rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.arcs, E, d_counts.p);
   if (n) HIP_CHECK(hipMemcpyAsync(finals.data(), f->dev.finals, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   // offsets of the in-arc segments (targets 0..n-1): exclusive scan of the in-degrees on the device
-  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;  // cached with the handle: the owner's pool outlives it
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
   rev->d_roff = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
   rev->d_arcs = DBuf<wfst_tr>(owner_pool, E);
   {

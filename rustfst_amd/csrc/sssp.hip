@@ -765,7 +765,7 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   if (f->mbox) return f->mbox;
   const uint32_t n = f->n_states, nb = (n + MB_B - 1) >> MB_LOG;
   hipStream_t st = ctx->stream;
-  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;
   auto p = std::make_shared<MboxPlan>();
   p->nb = nb;
   const size_t cells = (size_t)nb * nb;
@@ -1214,7 +1214,7 @@ const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   auto r = std::make_shared<RevCsr>();
-  DevicePool& owner_pool = *(f->ctx ? f->ctx : ctx)->pool;  // cached with the handle: the owner's pool outlives it
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
   r->off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
   r->arc = DBuf<uint2>(owner_pool, f->n_arcs);
   DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
