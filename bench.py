@@ -206,21 +206,21 @@ def main():
     last = {}
     phases = [0.0, 0.0, 0.0, 0.0, 0]  # host seconds in: first begin, second begin, batch finish, shortest_path finish; steps
 
-    xstream = torch.cuda.Stream(device=device) if (world > 1 or force_dist) else None
+    # the result exchange runs inside libwfst_amd (wfst_comm_* / wfst_gather_paths_*: its own RCCL communicator, stream and
+    # pinned staging); torch.distributed only carries the rendezvous id, the workload broadcast and the closing barrier
+    comm = wdist.Comm.from_torch_group(ctx, device) if (world > 1 or force_dist) else None
 
-    def exchange():
+    def exchange(outs=None):
         # RCCL all-gather of this step's batch results: packed and queued as soon as the batch is collected, WHILE the
-        # relaxation sweeps of the same step are still running (the host would only wait for them), on a stream of its
-        # own (the copies and the collective depend on host memory only: queued on the solve's stream they would sit
-        # behind its sweeps and in front of the next solve's), and collected one step later; the last one is drained
-        # before the closing barrier, inside the timed region.
-        if last.get("pending") is not None:
-            last["gathered"] = last["pending"].result()
-            last["pending"] = None
-        if last.get("to_send") is not None:
-            with torch.cuda.stream(xstream):
-                last["pending"] = wdist.gather_paths_async(last["to_send"], world, device)
-            last["to_send"] = None
+        # relaxation sweeps of the same step are still running (the host would only wait for them), on the communicator's
+        # own stream, and collected one step later; the last one is drained before the closing barrier, inside the
+        # timed region.
+        if last.get("pending"):
+            last["gathered"] = comm.gather_paths_end()
+            last["pending"] = False
+        if outs is not None:
+            comm.gather_paths_begin(outs, args.acc_len + 8)
+            last["pending"] = True
 
     def step():
         if not args.overlap:
@@ -244,15 +244,13 @@ def main():
             outs, n_arcs = job.finish()
             p3 = time.perf_counter()
             if world > 1 or force_dist:
-                last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
-                exchange()
+                exchange(outs)
             sp = sp_job.finish()
             p4 = time.perf_counter()
             phases[:] = [phases[0] + p1 - p0, phases[1] + p2 - p1, phases[2] + p3 - p2, phases[3] + p4 - p3, phases[4] + 1]
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
         if (world > 1 or force_dist) and not args.overlap:
-            last["to_send"] = wdist.pack_device_paths(outs, args.acc_len + 8)
-            exchange()
+            exchange(outs)
         return e_t + 2 * n_arcs
 
     def drain():

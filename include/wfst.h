@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 2 /* 2: wfst_stats gained relax_kernel */
+#define WFST_ABI_VERSION 3 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_* */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
 
@@ -280,6 +280,33 @@ wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
  * i.e. (4 + 4*max_arcs) u32 words.  KO if a path has more than max_arcs arcs or is not linear. */
 wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t max_arcs, uint32_t* out);
 
+/* ---- several GPUs: one process or thread per GPU, acceptor i on GPU i mod G, T uploaded on every GPU, no
+ * collective during compute; the finished results are all-gathered over RCCL / xGMI.  The reference is single-process
+ * (no distributed code to mirror): these are the calls a Rust host adds next to compose / shortest_path (INTEGRATION.md,
+ * "8 GPUs from Rust").  librccl is opened on first use; without it these calls return KO and everything else works. ---- */
+typedef struct wfst_comm wfst_comm;
+#define WFST_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (ncclGetUniqueId), to be handed to every rank by whatever channel the host has */
+wfst_status wfst_comm_unique_id(uint8_t* id /* [WFST_COMM_ID_BYTES] */);
+/* every rank, collectively (ncclCommInitRank): a communicator bound to ctx's GPU with a stream and pinned staging of its own */
+wfst_status wfst_comm_create(wfst_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t world, wfst_comm** out);
+wfst_status wfst_comm_info(const wfst_comm* comm, uint32_t* rank, uint32_t* world);
+wfst_status wfst_comm_destroy(wfst_comm* comm);
+/* All-gather of n linear path FSTs per rank as fixed-size records (layout of wfst_fst_pack_paths).  _begin packs into
+ * pinned memory and queues H2D, ncclAllGather and D2H on the communicator's stream, then returns (the exchange overlaps
+ * with whatever the caller does next: the next decoding step); _end waits and copies world * n records, rank-major, to out.
+ * One exchange in flight per communicator. */
+wfst_status wfst_gather_paths_begin(wfst_comm* comm, const wfst_fst* const* paths, size_t n, uint32_t max_arcs);
+wfst_status wfst_gather_paths_end(wfst_comm* comm, uint32_t* out /* [world * n * (4 + 4 * max_arcs)] */);
+/* the same for `bytes` opaque bytes per rank */
+wfst_status wfst_comm_allgather_begin(wfst_comm* comm, const void* send, size_t bytes);
+wfst_status wfst_comm_allgather_end(wfst_comm* comm, void* recv /* [world * bytes] */);
+/* ragged: every rank contributes `bytes` bytes (general FSTs in the OpenFST binary format: n-best trees, look-ahead
+ * compositions); sizes[r] = bytes of rank r, *recv = one block holding the payloads back to back in rank order
+ * (wfst_bytes_destroy), *total = their sum.  Two exchanges: the sizes, then the payloads padded to the largest. */
+wfst_status wfst_comm_allgatherv(wfst_comm* comm, const void* send, size_t bytes, uint64_t* sizes /* [world] */, void** recv,
+                                 size_t* total);
+
 /* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
 typedef struct {
   /* relaxation kernel (sssp_relax_*): launches, total device time from HIP events on ctx's stream,
@@ -297,7 +324,7 @@ typedef struct {
   uint64_t string_problems; /* problems of the last fused batch that took the string o T kernel (fst1 a linear,
                                epsilon-free acceptor, fst2 without input epsilons) */
   uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
-                               (owner-computes mailbox sweeps), 2 sssp_mboxa_kernel (several rounds per launch) */
+                               (owner-computes mailbox launches: WIDE / COLLECT / NARROW) */
 } wfst_stats;
 /* on = 1: every relaxation launch is bracketed by HIP events and followed by a synchronisation (per-launch trace below;
  * never on in timed runs).  on = 2: no per-launch events; the sweeps of a repeated shortest_path query (one pre-queued

@@ -77,6 +77,15 @@ SYMBOLS = [
      [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_compose_shortest_path_batch_end", C.c_int, [_vp, _P(_vp), _P(_u64)]),
     ("wfst_fst_pack_paths", C.c_int, [_P(_vp), _sz, _u32, _vp]),
+    ("wfst_comm_unique_id", C.c_int, [_vp]),
+    ("wfst_comm_create", C.c_int, [_vp, _vp, _u32, _u32, _P(_vp)]),
+    ("wfst_comm_info", C.c_int, [_vp, _P(_u32), _P(_u32)]),
+    ("wfst_comm_destroy", C.c_int, [_vp]),
+    ("wfst_gather_paths_begin", C.c_int, [_vp, _P(_vp), _sz, _u32]),
+    ("wfst_gather_paths_end", C.c_int, [_vp, _vp]),
+    ("wfst_comm_allgather_begin", C.c_int, [_vp, _vp, _sz]),
+    ("wfst_comm_allgather_end", C.c_int, [_vp, _vp]),
+    ("wfst_comm_allgatherv", C.c_int, [_vp, _vp, _sz, _vp, _P(_vp), _P(_sz)]),
     ("wfst_fst_tr_sort", C.c_int, [_vp, _vp, C.c_int]),
     ("wfst_reverse", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_vec_fst_new", C.c_int, [_P(_vp)]),

@@ -146,6 +146,122 @@ def gather_paths_async(local_packed: np.ndarray, world: int, device) -> PendingG
     return PendingGather(h_out, ev, world, shape)
 
 
+class Comm:
+    """RCCL communicator of the library itself (include/wfst.h: wfst_comm_*): the exchange runs inside libwfst_amd —
+    packing into pinned memory, H2D, ncclAllGather and D2H on a stream of the communicator's own — with no torch call on
+    the way.  `unique_id()` on rank 0, hand the 128 bytes to every rank (any channel: here `from_torch_group` broadcasts
+    them over the process group torchrun set up), then `Comm(ctx, id, rank, world)` on every rank."""
+
+    def __init__(self, ctx, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        from . import _lib
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of Comm.unique_id()")
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().wfst_comm_create(ctx._h, buf, rank, world, C.byref(h)), "wfst_comm_create")
+        self._h, self.ctx, self.rank, self.world = h, ctx, rank, world
+        self._shape = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                from . import _lib
+                _lib.lib().wfst_comm_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().wfst_comm_unique_id(buf), "wfst_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_group(cls, ctx, device=None) -> "Comm":
+        """Rendezvous through torch.distributed's default group (gloo or nccl): rank 0's id is broadcast, every rank joins."""
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        kw = {} if device is None else {"device": device}
+        t = torch.zeros(128, dtype=torch.uint8, **kw)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8).to(t.device)
+        dist.broadcast(t, 0)
+        return cls(ctx, bytes(t.cpu().numpy().tobytes()), rank, world)
+
+    def gather_paths_begin(self, paths, max_arcs: int):
+        """Queues the all-gather of this rank's path FSTs (a PathList or a list of DeviceFst) and returns at once."""
+        import ctypes as C
+
+        from . import _lib
+        n = len(paths)
+        if hasattr(paths, "_arr"):
+            arr = paths._arr
+        else:
+            arr = (C.c_void_p * n)(*[p._h.value if isinstance(p._h, C.c_void_p) else p._h for p in paths])
+        _lib.check(_lib.lib().wfst_gather_paths_begin(self._h, arr, n, max_arcs), "wfst_gather_paths_begin")
+        self._shape = (n, 4 + 4 * max_arcs)
+
+    def gather_paths_end(self) -> np.ndarray:
+        """Waits for the exchange queued by gather_paths_begin; returns [world, n_local, rec] uint32."""
+        from . import _lib
+        n, rec = self._shape
+        out = np.empty((self.world, n, rec), dtype=np.uint32)
+        _lib.check(_lib.lib().wfst_gather_paths_end(self._h, out.ctypes.data), "wfst_gather_paths_end")
+        self._shape = None
+        return out
+
+    def gather_paths(self, paths, max_arcs: int) -> np.ndarray:
+        self.gather_paths_begin(paths, max_arcs)
+        return self.gather_paths_end()
+
+    def allgather(self, block: np.ndarray) -> np.ndarray:
+        """Fixed-size all-gather of a contiguous array per rank; returns [world, ...block.shape]."""
+        from . import _lib
+        b = np.ascontiguousarray(block)
+        _lib.check(_lib.lib().wfst_comm_allgather_begin(self._h, b.ctypes.data, b.nbytes), "wfst_comm_allgather_begin")
+        out = np.empty((self.world,) + b.shape, dtype=b.dtype)
+        _lib.check(_lib.lib().wfst_comm_allgather_end(self._h, out.ctypes.data), "wfst_comm_allgather_end")
+        return out
+
+    def gather_fsts(self, local: Sequence[bytes]) -> List[List[bytes]]:
+        """Ragged all-gather of serialised FSTs (OpenFST binary): every rank gets `[rank][i] -> bytes` (same contract as
+        the module-level gather_fsts, one wfst_comm_allgatherv call: the sizes, then the payloads)."""
+        import ctypes as C
+
+        from . import _lib
+        sizes = np.array([len(local)] + [len(b) for b in local], dtype=np.int64)
+        blob = sizes.tobytes() + b"".join(local)
+        rsizes = (C.c_uint64 * self.world)()
+        recv, total = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.lib().wfst_comm_allgatherv(self._h, blob, len(blob), rsizes, C.byref(recv), C.byref(total)),
+                   "wfst_comm_allgatherv")
+        try:
+            raw = C.string_at(recv, total.value)
+        finally:
+            _lib.lib().wfst_bytes_destroy(recv)
+        res, o = [], 0
+        for r in range(self.world):
+            chunk = raw[o:o + int(rsizes[r])]
+            o += int(rsizes[r])
+            n_r = int(np.frombuffer(chunk[:8], dtype=np.int64)[0])
+            sz = np.frombuffer(chunk[8:8 + 8 * n_r], dtype=np.int64)
+            items, p = [], 8 + 8 * n_r
+            for s_ in sz:
+                items.append(chunk[p:p + int(s_)])
+                p += int(s_)
+            res.append(items)
+        return res
+
+
 def interleave(gathered: np.ndarray, n_total: int) -> np.ndarray:
     """[world, n_local, rec] (rank r holds problems r, r+world, ...) -> [n_total, rec] in problem order."""
     world, n_local, rec = gathered.shape

@@ -197,7 +197,9 @@ def test_broadcast_workload_gloo_world2():
 def test_rccl_single_rank_gather_of_hip_results():
     """The N > 1 plumbing on the hardware that exists here: a 1-rank nccl (= RCCL) process group carries the results of the
     HIP batch path through the same calls bench.py --gpus N uses (broadcast of the workload, pack_device_paths, the
-    asynchronous all-gather, interleave), and the gathered paths equal the local ones."""
+    asynchronous all-gather, interleave), and the gathered paths equal the local ones; then the same exchange through the
+    C-ABI (wfst_comm_create / wfst_gather_paths_begin / _end / wfst_comm_allgatherv: librccl called by the library on its
+    own stream), which is what bench.py --gpus N uses."""
     import subprocess
     code = r'''
 import os, sys
@@ -225,6 +227,25 @@ for o, b in zip(outs, back):
     assert f["n_states"] == b["n_states"] == 31 and np.array_equal(f["arcs"], b["arcs"]) and f["finals"][0] == b["finals"][0]
 blobs = [o.to_bytes() for o in outs[:2]]
 assert wdist.gather_fsts(blobs, 1, dev) == [blobs]
+# the same exchange through the C-ABI (wfst_comm_* / wfst_gather_paths_*): the library's own RCCL communicator, no torch
+# call between the batch result and the gathered records
+comm = wdist.Comm.from_torch_group(ctx, dev)
+assert (comm.rank, comm.world) == (0, 1)
+g3 = comm.gather_paths(outs, 30 + 8)
+assert g3.shape == g1.shape and np.array_equal(g3, g1)
+comm.gather_paths_begin(outs, 30 + 8)  # asynchronous form: something else runs meanwhile
+sp = dt.shortest_path()
+assert np.array_equal(comm.gather_paths_end(), g1) and sp.num_states > 0
+blk = np.arange(12, dtype=np.uint32).reshape(3, 4)
+assert np.array_equal(comm.allgather(blk), blk[None])
+assert comm.gather_fsts(blobs) == [blobs] and comm.gather_fsts([]) == [[]]
+import time
+best = [1e9, 1e9]
+for _ in range(20):
+    c0 = time.perf_counter(); comm.gather_paths_begin(outs, 38); c1 = time.perf_counter(); comm.gather_paths_end(); c2 = time.perf_counter()
+    best = [min(best[0], c1 - c0), min(best[1], c2 - c0)]
+print("C-ABI gather: begin %.1f us, begin+end %.1f us" % (best[0] * 1e6, best[1] * 1e6))
+del comm
 dist.barrier(); dist.destroy_process_group()
 print("RCCL-1 OK")
 ''' % ROOT

@@ -64,6 +64,15 @@ def test_compose_fst(gpu_ctx):
     assert fst1.compose(fst2, ComposeConfig(ComposeFilter.SEQUENCEFILTER, True)) == expected_fst
 
 
+def test_compose_config(gpu_ctx):
+    """rustfst-python/tests/algorithms/test_compose.py:84-154: the K1 pair under ComposeConfig(TRIVIALFILTER, connect=True)
+    — the reference's stored vector for a non-default filter — gives the same expected machine."""
+    g = golden("k1_compose.json")
+    fst1, fst2, expected_fst = (vector_fst_from_golden(g[k]) for k in ("fst1", "fst2", "expected"))
+    compose_config = ComposeConfig(ComposeFilter.TRIVIALFILTER, True)
+    assert fst1.compose(fst2, compose_config) == expected_fst
+
+
 def test_shortest_path(gpu_ctx):
     """K2: the vectors of rustfst-python/tests/algorithms/test_shortest_path.py:5-51 (tests/golden/k2_shortest_path.json)"""
     g = golden("k2_shortest_path.json")
@@ -375,6 +384,26 @@ def test_config3_properties_1m_states(gpu_ctx, oracle):
         if i < 2:
             can = to_oracle(oracle, a).compose(ot).shortest_path_canonical()
             assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")
+
+
+@pytest.mark.parametrize("kernel", ["mailbox", "mailbox_no_narrow", "atomic"])
+def test_config3_benched_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
+    """The solve bench.py times — shortest_path(T), T = 1M states / 10M arcs, seed 3 — against the canonical oracle at full
+    size: every distance, every hop count and the path itself bit-identical, for the mailbox launches (with and without
+    the NARROW hand-over) and for the atomic sweeps, on a first and on a repeated (predicted, gate-hinted) query."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0" if kernel == "atomic" else "1")
+    if kernel == "mailbox_no_narrow":
+        monkeypatch.setenv("WFST_SSSP_NARROW", "0")
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    for q in range(3):
+        dist, hops = d.shortest_distance(want_hops=True)
+        assert ctx.stats()["relax_kernel"] == (0 if kernel == "atomic" else 1)
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"benched solve, {kernel}, query {q}")
 
 
 def test_config3_512_acceptors_and_one_long_string_against_1m_states(gpu_ctx, oracle):

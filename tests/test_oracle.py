@@ -57,6 +57,14 @@ def test_k1_compose_known_answer(oracle):
     flat_matches_spec(res.to_flat(), g["expected"])
 
 
+def test_k1_compose_config_trivial_filter_known_answer(oracle):
+    """The reference's own vector for a NON-default filter: test_compose.py:84-154 composes the K1 pair with
+    ComposeConfig(ComposeFilter.TRIVIALFILTER, connect=True) and expects the same 4-state machine."""
+    g = load_golden("k1_compose.json")
+    res = build(oracle, g["fst1"]).compose(build(oracle, g["fst2"]), connect=True, compose_filter=2)
+    flat_matches_spec(res.to_flat(), g["expected"])
+
+
 # ---------------------------------------------------------------- K2: test_shortest_path.py:5-51
 def test_k2_shortest_path_known_answer(oracle):
     g = load_golden("k2_shortest_path.json")
