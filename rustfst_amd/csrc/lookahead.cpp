@@ -8,6 +8,7 @@
 // of the transformed FST discovers the per-label sink states, so the visit order is reproduced exactly; everything
 // works on flat CSR arrays with explicit stacks (decoding graphs have millions of states).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -274,6 +275,303 @@ void state_reachable(const Graph& g, ReachSets& out) {
     std::fprintf(stderr, "[wfst]   scc + condense %.1f ms, reach visit %.1f ms, copy back %.1f ms\n", ms(t1, t2), ms(t2, t3), ms(t3, now()));
 }
 
+// ---- the parallel path for operands whose epsilon structure is acyclic (decoding graphs: the usual case)
+//
+// What the reference's visit produces, restated as two facts that need no 5M-state depth-first search:
+//   * label2index[l] = 1 + the rank of label l's sink among the sinks in the order the visit DISCOVERS them.  The visit
+//     order is dfs_visit's (root = the super-initial state, whose arcs go to the states without incoming epsilon arc in
+//     increasing id, every state's arcs in stored order followed by the arc to the NO_LABEL sink if it is final; then the
+//     unvisited states 0, 1, 2, ...) — replayed here over the operand's own arrays, and ABANDONED as soon as every label
+//     of the operand has its index (a few hundred states into a decoding graph);
+//   * the set of state s = normalize(its own labels' unit intervals  U  the sets of its epsilon successors): a pure
+//     function of the index map on an acyclic epsilon graph, so the states are processed in rounds — every state whose
+//     epsilon successors are done — by all host threads, each appending to an arena of its own.
+// A round that finishes nothing means an epsilon cycle: the caller then takes the sequential path above (condensation).
+unsigned host_threads(uint64_t work_items) {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* e = std::getenv("WFST_HOST_THREADS")) n = (unsigned)std::max(1, std::atoi(e));
+  n = std::min(n, 32u);
+  if (work_items < (1u << 16) && !std::getenv("WFST_HOST_THREADS")) n = 1;  // (tests force threads on small inputs)
+  return n;
+}
+
+template <class F>
+void parallel_chunks(unsigned n_thr, uint64_t n_items, uint64_t chunk, F&& body /* (thread, begin, end) */) {
+  if (n_thr <= 1 || n_items <= chunk) {
+    if (n_items) body(0u, (uint64_t)0, n_items);
+    return;
+  }
+  std::atomic<uint64_t> next{0};
+  std::vector<std::exception_ptr> errs(n_thr);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_thr; ++t)
+    pool.emplace_back([&, t] {
+      try {
+        for (;;) {
+          const uint64_t b = next.fetch_add(chunk, std::memory_order_relaxed);
+          if (b >= n_items) break;
+          body(t, b, std::min(n_items, b + chunk));
+        }
+      } catch (...) {
+        errs[t] = std::current_exception();
+      }
+    });
+  for (auto& th : pool) th.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+struct LabelTable {  // label -> small value, a flat table in front of a map (labels of decoding graphs are small integers)
+  static constexpr uint32_t LUT_MAX = 1u << 22;
+  std::vector<uint32_t> lut;
+  std::unordered_map<uint32_t, uint32_t> big;
+  uint32_t get(uint32_t label) const {
+    if (label < lut.size()) return lut[label];
+    if (label < LUT_MAX) return UNASSIGNED;
+    auto it = big.find(label);
+    return it == big.end() ? UNASSIGNED : it->second;
+  }
+};
+
+// returns false when the epsilon structure is cyclic (nothing is written then)
+bool compute_acyclic_parallel(uint32_t ins, const uint32_t* offsets, const wfst_tr* arcs, const float* finals, bool reach_input,
+                              LabelReachData& out, bool timing) {
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = now();
+  const uint64_t n_arcs = offsets[ins];
+  const unsigned n_thr = host_threads(n_arcs);
+  auto label_of = [reach_input](const wfst_tr& a) { return reach_input ? a.ilabel : a.olabel; };
+
+  // ---- pass 1: epsilon out-degrees, the largest label, which labels occur
+  std::vector<uint32_t> eoff((size_t)ins + 1, 0);
+  uint32_t max_small = 0;
+  {
+    std::vector<uint32_t> tmax(n_thr, 0);
+    parallel_chunks(n_thr, ins, 1u << 14, [&](unsigned t, uint64_t b, uint64_t e) {
+      uint32_t m = tmax[t];
+      for (uint64_t s = b; s < e; ++s) {
+        uint32_t ne = 0;
+        for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k) {
+          const uint32_t l = label_of(arcs[k]);
+          ne += l == 0;
+          if (l < LabelTable::LUT_MAX && l > m) m = l;
+        }
+        eoff[s + 1] = ne;
+      }
+      tmax[t] = m;
+    });
+    for (uint32_t m : tmax) max_small = std::max(max_small, m);
+  }
+  for (uint32_t s = 0; s < ins; ++s) eoff[s + 1] += eoff[s];
+  const uint32_t n_eps = eoff[ins];
+  // ---- pass 2: the epsilon successors (CSR), the labels seen
+  std::vector<uint32_t> edst(n_eps);
+  std::vector<uint8_t> seen((size_t)max_small + 1, 0);
+  std::vector<std::vector<uint32_t>> big_seen(n_thr);
+  std::vector<uint8_t> any_final(n_thr, 0);
+  parallel_chunks(n_thr, ins, 1u << 14, [&](unsigned t, uint64_t b, uint64_t e) {
+    for (uint64_t s = b; s < e; ++s) {
+      uint32_t w = eoff[s];
+      for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k) {
+        const uint32_t l = label_of(arcs[k]);
+        if (l == 0) edst[w++] = arcs[k].nextstate;
+        else if (l < LabelTable::LUT_MAX) {
+          if (!seen[l]) seen[l] = 1;  // (benign race: every writer stores 1; tested first, or the line ping-pongs)
+        }
+        else big_seen[t].push_back(l);
+      }
+      if (finals[s] != INF && !any_final[t]) any_final[t] = 1;
+    }
+  });
+  uint32_t n_labels = 0;  // sinks the visit will discover
+  for (uint32_t l = 1; l <= max_small; ++l) n_labels += seen[l];
+  LabelTable idx;
+  idx.lut.assign((size_t)max_small + 1, UNASSIGNED);
+  for (auto& v : big_seen)
+    for (uint32_t l : v)
+      if (idx.big.emplace(l, UNASSIGNED).second) n_labels++;
+  bool has_final = false;
+  for (uint8_t f : any_final) has_final |= f != 0;
+  if (has_final && idx.big.emplace(NO_LABEL, UNASSIGNED).second) n_labels++;
+  const auto t1 = now();
+
+  // ---- the sets, in rounds over the epsilon dependencies (needs no label indices yet: the sets are built from LABELS
+  //      first?  no — intervals are over indices, so the index map comes first)
+  // ---- the index map: dfs_visit's order, abandoned once every label has been met
+  {
+    std::vector<uint8_t> has_in((size_t)ins, 0);
+    for (uint32_t k = 0; k < n_eps; ++k) has_in[edst[k]] = 1;
+    enum : uint8_t { White, Grey, Black };
+    std::vector<uint8_t> color((size_t)ins, White);
+    std::vector<std::pair<uint32_t, uint32_t>> stack;  // {state, next arc position; == offsets[s + 1] : the final arc}
+    uint32_t found = 0, index = 1;
+    auto meet = [&](uint32_t label) {
+      uint32_t* slot = label < LabelTable::LUT_MAX ? &idx.lut[label] : &idx.big[label];
+      if (*slot == UNASSIGNED) {
+        *slot = index++;
+        found++;
+      }
+    };
+    auto visit_from = [&](uint32_t root) {
+      color[root] = Grey;
+      stack.push_back({root, offsets[root]});
+      while (!stack.empty() && found < n_labels) {
+        const uint32_t s = stack.back().first;
+        uint32_t& pos = stack.back().second;
+        if (pos < offsets[s + 1]) {
+          const wfst_tr& a = arcs[pos++];
+          const uint32_t l = label_of(a);
+          if (l != 0) {
+            meet(l);
+          } else if (color[a.nextstate] == White) {
+            color[a.nextstate] = Grey;
+            stack.push_back({a.nextstate, offsets[a.nextstate]});
+          }
+          continue;
+        }
+        if (pos == offsets[s + 1] && finals[s] != INF) {
+          pos++;
+          meet(NO_LABEL);
+          continue;
+        }
+        color[s] = Black;
+        stack.pop_back();
+      }
+      stack.clear();
+    };
+    // the super-initial state's arcs: states nothing points at, in increasing id; then dfs_visit's remaining roots
+    for (uint32_t s = 0; s < ins && found < n_labels; ++s)
+      if (!has_in[s] && color[s] == White) visit_from(s);
+    for (uint32_t s = 0; s < ins && found < n_labels; ++s)
+      if (color[s] == White) visit_from(s);
+  }
+  const auto t2 = now();
+
+  // ---- the sets, in rounds: a state is ready when its epsilon successors are done
+  // (a thread's finished sets are read by the others in later rounds while it appends new ones: the arenas are lists of
+  // blocks that never move, and a set lies inside one block)
+  using Iv = std::pair<uint32_t, uint32_t>;
+  struct Rec {
+    const Iv* p;
+    uint32_t len;
+  };
+  struct BlockArena {
+    std::vector<std::unique_ptr<Iv[]>> blocks;
+    size_t used = 0, cap = 0;
+    Iv* alloc(size_t n) {
+      if (used + n > cap) {
+        cap = std::max<size_t>(n, (size_t)1 << 20);
+        blocks.emplace_back(new Iv[cap]);
+        used = 0;
+      }
+      Iv* r = blocks.back().get() + used;
+      used += n;
+      return r;
+    }
+  };
+  std::vector<Rec> rec((size_t)ins);
+  std::vector<uint8_t> done((size_t)ins, 0);
+  std::vector<BlockArena> arenas(n_thr);
+  std::vector<uint32_t> todo, next_todo;
+  std::vector<std::vector<uint32_t>> later(n_thr);
+  std::vector<Intervals> scratch(n_thr);
+  const uint32_t final_idx = has_final ? idx.get(NO_LABEL) : UNASSIGNED;
+  auto build = [&](unsigned t, uint32_t s) {
+    Intervals& sc = scratch[t];
+    sc.clear();
+    for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k) {
+      const uint32_t l = label_of(arcs[k]);
+      if (l != 0) {
+        const uint32_t i = idx.get(l);
+        sc.push_back({i, i + 1});
+      }
+    }
+    if (finals[s] != INF) sc.push_back({final_idx, final_idx + 1});
+    for (uint32_t k = eoff[s]; k < eoff[s + 1]; ++k) {
+      const Rec& r = rec[edst[k]];
+      sc.insert(sc.end(), r.p, r.p + r.len);
+    }
+    normalize(sc);
+    Iv* dst = sc.empty() ? nullptr : arenas[t].alloc(sc.size());
+    if (!sc.empty()) std::memcpy((void*)dst, sc.data(), sc.size() * sizeof(Iv));
+    rec[s] = Rec{dst, (uint32_t)sc.size()};
+  };
+  // round 0 over all states (no list yet); later rounds over the states that were not ready
+  {
+    parallel_chunks(n_thr, ins, 1u << 12, [&](unsigned t, uint64_t b, uint64_t e) {
+      for (uint64_t s = b; s < e; ++s) {
+        if (eoff[s] == eoff[s + 1]) build(t, (uint32_t)s);
+        else later[t].push_back((uint32_t)s);
+      }
+    });
+    // (a state finished in this round becomes visible to the others only with the next one: `done` is written after the join)
+    for (unsigned t = 0; t < n_thr; ++t) {
+      todo.insert(todo.end(), later[t].begin(), later[t].end());
+      later[t].clear();
+    }
+    parallel_chunks(n_thr, ins, 1u << 16, [&](unsigned, uint64_t b, uint64_t e) {
+      for (uint64_t s = b; s < e; ++s) done[s] = eoff[s] == eoff[s + 1];
+    });
+  }
+  std::vector<std::vector<uint32_t>> finished(n_thr);
+  while (!todo.empty()) {
+    parallel_chunks(n_thr, todo.size(), 1u << 10, [&](unsigned t, uint64_t b, uint64_t e) {
+      for (uint64_t i = b; i < e; ++i) {
+        const uint32_t s = todo[i];
+        bool ready = true;
+        for (uint32_t k = eoff[s]; k < eoff[s + 1] && ready; ++k) ready = done[edst[k]] != 0;
+        if (ready) {
+          build(t, s);
+          finished[t].push_back(s);
+        } else {
+          later[t].push_back(s);
+        }
+      }
+    });
+    next_todo.clear();
+    uint64_t fin = 0;
+    for (unsigned t = 0; t < n_thr; ++t) {
+      for (uint32_t s : finished[t]) done[s] = 1;
+      fin += finished[t].size();
+      finished[t].clear();
+      next_todo.insert(next_todo.end(), later[t].begin(), later[t].end());
+      later[t].clear();
+    }
+    if (fin == 0) return false;  // an epsilon cycle: the sequential path (condensation) takes over
+    todo.swap(next_todo);
+  }
+  const auto t3 = now();
+
+  // ---- flatten to the per-state CSR the kernels read
+  out.iv_off.assign((size_t)ins + 1, 0);
+  uint64_t total = 0;
+  for (uint32_t s = 0; s < ins; ++s) {
+    total += rec[s].len;
+    if (total > 0xFFFFFFFFull) throw Error("LabelReachable: more than 2^32 intervals");
+    out.iv_off[s + 1] = (uint32_t)total;
+  }
+  static_assert(sizeof(std::pair<uint32_t, uint32_t>) == 8, "an interval is two packed words");
+  out.iv.resize(2 * (size_t)total);
+  parallel_chunks(n_thr, ins, 1u << 14, [&](unsigned, uint64_t b, uint64_t e) {
+    for (uint64_t s = b; s < e; ++s)
+      if (rec[s].len)
+        std::memcpy(out.iv.data() + 2 * (size_t)out.iv_off[s], rec[s].p, (size_t)rec[s].len * 8);
+  });
+  out.label2index.clear();
+  out.final_label = NO_LABEL;
+  for (uint32_t l = 1; l <= max_small; ++l)
+    if (seen[l]) out.label2index[l] = idx.lut[l];
+  for (auto& kv : idx.big) out.label2index[kv.first] = kv.second;
+  if (has_final) out.final_label = final_idx;
+  if (timing)
+    std::fprintf(stderr, "[wfst] label reachability of %u states on %u host threads: scan %.1f ms, index map %.1f ms, sets %.1f ms, "
+                         "flatten %.1f ms\n", ins, n_thr, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+  return true;
+}
+
 }  // namespace
 
 // LabelReachable::compute_data (label_reachable.rs:135-150) = transform_fst (:172-248) + find_intervals (:250-273)
@@ -289,6 +587,9 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
   final_label = NO_LABEL;
   label2index.clear();
   const uint32_t ins = n_states;
+  // acyclic epsilon structure (decoding graphs): all host threads, no materialised transformed graph
+  if (!std::getenv("WFST_LOOKAHEAD_SEQUENTIAL") && ins > 0 && compute_acyclic_parallel(ins, offsets, arcs, finals, reach_input, *this, timing))
+    return;
   // labelled arcs go to a sink state per label (created in order of first appearance), final states get an arc to the
   // NO_LABEL sink, a super-initial state points at every state nothing points at
   std::unordered_map<uint32_t, uint32_t> label2state;
@@ -379,37 +680,101 @@ uint64_t LabelReachData::relabel_fst(uint32_t n_states, const uint32_t* offsets,
     if (v == UNASSIGNED) v = relabel(label);
     return v;
   };
-  for (uint64_t k = 0; k < offsets[n_states]; ++k) {
-    wfst_tr& tr = arcs[k];
-    const uint32_t oi = tr.ilabel, oo = tr.olabel;
-    if (relabel_input)
-      tr.ilabel = relabel_fast(tr.ilabel);
-    else
-      tr.olabel = relabel_fast(tr.olabel);
-    const uint32_t ni = tr.ilabel, no = tr.olabel;
-    if (oi != oo) p &= ~props::NOT_ACCEPTOR;
-    if (oi == 0) {
-      p &= ~props::I_EPSILONS;
-      if (oo == 0) p &= ~props::EPSILONS;
+  // The reference rewrites arc after arc (trs_iter_mut.rs:241-302): every arc clears and sets property bits from its old
+  // and new labels.  Each arc's effect is p -> (p & ~C) | S, and such maps compose associatively, so the arcs are cut
+  // into ranges whose (C, S) are worked out by the host threads and applied in order — bit-identical to the sequential
+  // loop.  Labels the data has not seen yet get their index in order of first appearance (label_reachable.rs:52-61),
+  // which IS sequential: an operand that brings such labels (checked first, in parallel) takes the one-thread loop.
+  struct Cs {
+    uint64_t c = 0, s = 0;
+    void clear(uint64_t x) {
+      c |= x;
+      s &= ~x;
     }
-    if (oo == 0) p &= ~props::O_EPSILONS;
+    void set(uint64_t x) { s |= x; }
+  };
+  auto arc_effect = [&](Cs& e, uint32_t oi, uint32_t oo, uint32_t ni, uint32_t no) {
+    if (oi != oo) e.clear(props::NOT_ACCEPTOR);
+    if (oi == 0) {
+      e.clear(props::I_EPSILONS);
+      if (oo == 0) e.clear(props::EPSILONS);
+    }
+    if (oo == 0) e.clear(props::O_EPSILONS);
     if (ni != no) {
-      p |= props::NOT_ACCEPTOR;
-      p &= ~props::ACCEPTOR;
+      e.set(props::NOT_ACCEPTOR);
+      e.clear(props::ACCEPTOR);
     }
     if (ni == 0) {
-      p |= props::I_EPSILONS;
-      p &= ~props::NO_I_EPSILONS;
+      e.set(props::I_EPSILONS);
+      e.clear(props::NO_I_EPSILONS);
       if (no == 0) {
-        p |= props::EPSILONS;
-        p &= ~props::NO_EPSILONS;
+        e.set(props::EPSILONS);
+        e.clear(props::NO_EPSILONS);
       }
     }
     if (no == 0) {
-      p |= props::O_EPSILONS;
-      p &= ~props::NO_O_EPSILONS;
+      e.set(props::O_EPSILONS);
+      e.clear(props::NO_O_EPSILONS);
     }
-    p &= keep;
+    e.clear(~keep);
+  };
+  const uint64_t n_arcs_all = offsets[n_states];
+  const unsigned rl_thr = host_threads(n_arcs_all);
+  bool all_known = rl_thr > 1;
+  if (rl_thr > 1) {
+    // read-only view of the map for the threads (flat table in front, as in relabel_fast)
+    uint32_t max_small = 0;
+    for (auto& kv : label2index)
+      if (kv.first < LUT_MAX && kv.first > max_small) max_small = kv.first;
+    lut.assign((size_t)max_small + 1, UNASSIGNED);
+    for (auto& kv : label2index)
+      if (kv.first < LUT_MAX) lut[kv.first] = kv.second;
+    std::atomic<int> unknown{0};
+    parallel_chunks(rl_thr, n_arcs_all, 1u << 18, [&](unsigned, uint64_t b, uint64_t e) {
+      if (unknown.load(std::memory_order_relaxed)) return;
+      for (uint64_t k = b; k < e; ++k) {
+        const uint32_t l = relabel_input ? arcs[k].ilabel : arcs[k].olabel;
+        if (l == 0) continue;
+        const bool known = l < lut.size() ? lut[l] != UNASSIGNED : (l >= LUT_MAX && label2index.count(l) != 0);
+        if (!known) {
+          unknown.store(1, std::memory_order_relaxed);
+          return;
+        }
+      }
+    });
+    all_known = unknown.load() == 0;
+  }
+  if (all_known) {
+    const uint64_t per = (n_arcs_all + rl_thr - 1) / rl_thr;
+    std::vector<Cs> eff(rl_thr);
+    parallel_chunks(rl_thr, rl_thr, 1, [&](unsigned, uint64_t tb, uint64_t te) {
+      for (uint64_t part = tb; part < te; ++part) {
+        Cs e;
+        const uint64_t b = part * per, en = std::min(n_arcs_all, b + per);
+        for (uint64_t k = b; k < en; ++k) {
+          wfst_tr& tr = arcs[k];
+          const uint32_t oi = tr.ilabel, oo = tr.olabel;
+          uint32_t& col = relabel_input ? tr.ilabel : tr.olabel;
+          if (col != 0) col = col < lut.size() ? lut[col] : label2index.find(col)->second;
+          arc_effect(e, oi, oo, tr.ilabel, tr.olabel);
+        }
+        eff[part] = e;
+      }
+    });
+    for (const Cs& e : eff) p = (p & ~e.c) | e.s;
+  } else {
+    lut.clear();
+    for (uint64_t k = 0; k < n_arcs_all; ++k) {
+      wfst_tr& tr = arcs[k];
+      const uint32_t oi = tr.ilabel, oo = tr.olabel;
+      if (relabel_input)
+        tr.ilabel = relabel_fast(tr.ilabel);
+      else
+        tr.olabel = relabel_fast(tr.olabel);
+      Cs e;
+      arc_effect(e, oi, oo, tr.ilabel, tr.olabel);
+      p = (p & ~e.c) | e.s;
+    }
   }
   // tr_sort (stable) of every state's arcs on the relabelled column: states are independent, so the range is cut over a
   // few host threads; short rows (the rule) by insertion sort — std::stable_sort allocates a buffer per call
@@ -431,7 +796,7 @@ uint64_t LabelReachData::relabel_fst(uint32_t n_states, const uint32_t* offsets,
     }
   };
   const uint64_t n_arcs = offsets[n_states];
-  unsigned n_thr = n_arcs >= (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  unsigned n_thr = n_arcs >= (1u << 20) || std::getenv("WFST_HOST_THREADS") ? host_threads(n_arcs) : 1u;
   if (n_thr <= 1) {
     sort_range(0, n_states);
   } else {

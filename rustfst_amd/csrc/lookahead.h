@@ -9,13 +9,27 @@
 
 namespace wfst {
 
+// (resize() of hundreds of MB that are overwritten at once should not zero them first, on one thread)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+
 // LabelReachableData (compose/label_reachable.rs:16-21) with the interval sets flattened to CSR
 struct LabelReachData {
   bool reach_input = false;
   uint32_t final_label = WFST_NO_LABEL;                 // index of the NO_LABEL sink (a final state is reachable)
   std::unordered_map<uint32_t, uint32_t> label2index;   // label -> relabelled label (grows in relabel())
   std::vector<uint32_t> iv_off;                         // [n+1] first interval of each state
-  std::vector<uint32_t> iv;                             // [2 * n_intervals] begin, end (half-open), sorted, disjoint
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> iv;      // [2 * n_intervals] begin, end (half-open), sorted, disjoint
 
   void compute(uint32_t n_states, const uint32_t* offsets, const wfst_tr* arcs, const float* finals, bool reach_input);
   uint32_t relabel(uint32_t label);

@@ -183,6 +183,27 @@ def test_cpp_mirror_header_compiles_and_links(tmp_path, wfst_lib):
     assert exe.exists()
 
 
+@pytest.mark.parametrize("threads", ["4", "seq"])
+@pytest.mark.parametrize("seed", range(12))
+def test_label_reachable_threads_and_sizes(wfst_lib, oracle, seed, threads, monkeypatch):
+    """The parallel path of the host precompute (acyclic epsilon structure: index map from an abandoned replay of the
+    reference's visit, interval sets in rounds over all host threads) and the sequential one (the reference's visit in
+    full) against the oracle on inputs with a few thousand states, several threads forced on them."""
+    import rustfst_amd
+    from helpers import random_fst_flat, to_oracle
+    if threads == "seq":
+        monkeypatch.setenv("WFST_LOOKAHEAD_SEQUENTIAL", "1")
+    else:
+        monkeypatch.setenv("WFST_HOST_THREADS", threads)
+    rng = np.random.default_rng(4200 + seed)
+    f = random_fst_flat(rng, int(rng.integers(500, 4000)), 5, int(rng.choice([3, 40, 3000])), p_eps_i=0.1,
+                        p_eps_o=float(rng.choice([0.05, 0.3, 0.7])), p_final=0.1, sort="olabel", acyclic=(seed % 4 != 3))
+    for reach_input in (False, True):
+        ref = to_oracle(oracle, f).label_reachable(reach_input)
+        la = rustfst_amd.LookAhead.reachable_from_arrays(f["n_states"], f["offsets"], f["arcs"], f["finals"], reach_input)
+        assert la.data() == ref
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_label_reachable_host_precompute_matches_oracle(wfst_lib, oracle, seed):
     """Product host code of look-ahead composition (rustfst_amd/csrc/lookahead.cpp: LabelReachable::compute_data on flat
