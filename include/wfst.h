@@ -275,6 +275,13 @@ wfst_status wfst_vec_fst_to_device(wfst_ctx* ctx, const wfst_vec_fst* f, wfst_fs
 /* download + rebuild (add_states / set_start / set_trs_unchecked / set_final / set_properties) == the shim's output step */
 wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
 
+/* shortest_path_with_config (shortest_path.rs:76-171) of n FSTs in one call; outs[i] = a new handle each.  With nshortest > 1
+ * (unique = false) small inputs — the composed lattices of a decoding batch: BASELINE configs[4] — are searched by ONE
+ * launch, one wavefront per input (distances, reverse, the reference's heap search, connect); larger ones, and
+ * nshortest == 1, go through the single-FST paths one after the other.  Same results as n calls of wfst_shortest_path. */
+wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, const wfst_shortest_path_config* cfg,
+                                     wfst_fst** outs);
+
 /* Packs n linear path FSTs (outputs of the calls above) into fixed-size records for one all-gather:
  * record i = [n_arcs u32, final-weight bits u32, valid u32, 0] followed by max_arcs 16-byte arcs (zero padded),
  * i.e. (4 + 4*max_arcs) u32 words.  KO if a path has more than max_arcs arcs or is not linear. */
@@ -325,6 +332,8 @@ typedef struct {
                                epsilon-free acceptor, fst2 without input epsilons) */
   uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
                                (owner-computes mailbox launches: WIDE / COLLECT / NARROW) */
+  uint64_t nbest_device_problems; /* inputs of the last wfst_shortest_path_batch (nshortest > 1) searched by the wave kernel
+                                     (the others went through the host search) */
 } wfst_stats;
 /* on = 1: every relaxation launch is bracketed by HIP events and followed by a synchronisation (per-launch trace below;
  * never on in timed runs).  on = 2: no per-launch events; the sweeps of a repeated shortest_path query (one pre-queued

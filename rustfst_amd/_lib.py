@@ -27,7 +27,7 @@ class Stats(C.Structure):
     _fields_ = [("relax_launches", C.c_uint64), ("relax_ms", C.c_double), ("relax_arcs", C.c_uint64),
                 ("relax_states", C.c_uint64), ("sweeps", C.c_uint64), ("compose_states", C.c_uint64),
                 ("compose_arcs", C.c_uint64), ("compose_retries", C.c_uint64), ("compose_ms", C.c_double),
-                ("string_problems", C.c_uint64), ("relax_kernel", C.c_uint64)]
+                ("string_problems", C.c_uint64), ("relax_kernel", C.c_uint64), ("nbest_device_problems", C.c_uint64)]
 
 
 # every symbol include/wfst.h declares: (name, restype, argtypes)
@@ -68,6 +68,7 @@ SYMBOLS = [
     ("wfst_lookahead_info", C.c_int, [_vp, _P(_u32), _P(_u64), _P(_u32), _P(_u32)]),
     ("wfst_lookahead_download", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("wfst_label_reachable_compute", C.c_int, [_u32, _vp, _vp, _vp, C.c_int, _P(_vp)]),
+    ("wfst_shortest_path_batch", C.c_int, [_vp, _P(_vp), _sz, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_path_begin", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_path_end", C.c_int, [_vp, _P(_vp)]),
     ("wfst_shortest_distance", C.c_int, [_vp, _vp, _vp, _vp]),

@@ -313,6 +313,42 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
   });
 }
 
+wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, const wfst_shortest_path_config* cfg,
+                                     wfst_fst** outs) {
+  return wrap([&] {
+    if (!ctx || (n && (!fsts || !outs))) throw Error("null pointer");
+    for (size_t i = 0; i < n; ++i) {
+      if (!fsts[i]) throw Error("null FST in batch");
+      outs[i] = nullptr;
+    }
+    wfst_shortest_path_config c = cfg ? *cfg : wfst_shortest_path_config{1e-6f, 1, 0};
+    HIP_CHECK(hipSetDevice(ctx->device));
+    try {
+      if (c.nshortest >= 2 && !c.unique) {
+        shortest_path_nbest_batch(ctx, fsts, n, c.nshortest, c.delta, outs);
+        return;
+      }
+      for (size_t i = 0; i < n; ++i) {
+        if (c.nshortest == 0) {
+          HostCsr h;
+          h.offsets.push_back(0);
+          outs[i] = make_host_fst(ctx, 0, -1, props::NULL_PROPS, std::move(h));
+        } else if (c.nshortest == 1) {
+          outs[i] = shortest_path_n1(ctx, fsts[i]);
+        } else {
+          throw Error("unsupported: unique = true with nshortest > 1 is not implemented on the GPU path; use the CPU path");
+        }
+      }
+    } catch (...) {
+      for (size_t i = 0; i < n; ++i) {
+        delete outs[i];
+        outs[i] = nullptr;
+      }
+      throw;
+    }
+  });
+}
+
 wfst_status wfst_shortest_distance(wfst_ctx* ctx, const wfst_fst* fst, float* distance, uint32_t* hops) {
   return wrap([&] {
     if (!ctx || !fst || !distance) throw Error("null pointer");

@@ -263,6 +263,8 @@ wfst_ctx* sp_job_ctx(wfst_sp_job* job);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
 // nshortest.hip
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
+// nbest_batch.hip
+void shortest_path_nbest_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, uint64_t nshortest, float delta, wfst_fst** outs);
 wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f);
 // per-arc destination ranges / input-epsilon check of an FST used as fst2 of the string o T kernel (cached on the handle)
 const uint2* ensure_anext(wfst_ctx* ctx, const wfst_fst* f);

@@ -502,6 +502,27 @@ def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
     return PathList(outs, n, ctx), na.value
 
 
+def shortest_path_batch(fsts: Sequence[DeviceFst], config: Optional["ShortestPathConfig"] = None,
+                        ctx: Optional[Context] = None) -> List[DeviceFst]:
+    """[f.shortest_path(config) for f in fsts] as ONE call (wfst_shortest_path_batch): with nshortest > 1 the small
+    inputs — the composed lattices of a decoding batch — are searched by one launch, one wavefront each."""
+    n = len(fsts)
+    if n == 0:
+        return []
+    ctx = ctx or fsts[0].ctx
+    arr = fsts._arr if isinstance(fsts, HandleArray) else (C.c_void_p * n)(*[f._h.value if isinstance(f._h, C.c_void_p) else f._h for f in fsts])
+    outs = (C.c_void_p * n)()
+    check(_lib.lib().wfst_shortest_path_batch(ctx._h, arr, n, config._c() if config is not None else None, outs),
+          "wfst_shortest_path_batch")
+    return [DeviceFst(C.c_void_p(outs[i]), ctx) for i in range(n)]
+
+
+def last_nbest_path(ctx: Optional[Context] = None) -> str:
+    """Which search the last shortest_path_batch(nshortest > 1) used (wfst_stats.nbest_device_problems)."""
+    ctx = ctx or default_context()
+    return "wave kernel: %d inputs" % int(ctx.stats()["nbest_device_problems"])
+
+
 # ------------------------------------------------------------------ configs
 class ProjectType(Enum):  # rustfst-python/rustfst/algorithms/project.py:9-24
     PROJECT_INPUT = 0

@@ -596,6 +596,47 @@ def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
         assert_flat_identical(got, exp, f"seed {seed} n={n}")
 
 
+@pytest.mark.parametrize("device", ["1", "0", "tiny_tree"])
+def test_nshortest_batch_wave_kernel_vs_oracle(gpu_ctx, oracle, device, monkeypatch):
+    """wfst_shortest_path_batch with nshortest > 1: the one-wave-per-input kernel (distances, reverse, the reference's heap
+    search, connect) against the oracle's n_shortest_path on random cyclic / acyclic FSTs with epsilons, ties (integer
+    weights) and unreachable finals, on composed lattices (the configs[4] shape) and on degenerate inputs; the host search
+    (device = 0) and the fall-back of inputs whose search tree outgrows the kernel's arena (tiny_tree) give the same FSTs."""
+    if device == "tiny_tree":
+        monkeypatch.setenv("WFST_NBEST_TREE", "40")
+    else:
+        monkeypatch.setenv("WFST_NBEST_DEVICE", device)
+    rng = np.random.default_rng(4711)
+    flats = []
+    for k in range(40):
+        flats.append(random_fst_flat(rng, int(rng.integers(1, 80)), 4, 5, p_eps_i=0.1, p_final=0.2, min_fanout=int(k % 2),
+                                     acyclic=bool(k % 3 == 0), weight_grid=int(rng.choice([512, 1])), max_w=6))
+    t = synth.make_transducer(20_000, 8, 64, 0.02, seed=5)
+    ot = to_oracle(oracle, t)
+    accs = synth.make_acceptors(t, 6, 40, seed0=1000)
+    dt = to_device(t)
+    lattices = [to_device(a).compose(dt) for a in accs]
+    flats += [d.to_flat() for d in lattices]
+    empty = dict(n_states=0, start=None, offsets=np.zeros(1, np.uint32), arcs=np.zeros(0, rustfst_amd.TR_DTYPE),
+                 finals=np.zeros(0, np.float32), props=0)
+    flats.append(empty)
+    devs = [to_device(f) for f in flats]
+    for n in (2, 10):
+        got = rustfst_amd.shortest_path_batch(devs, ShortestPathConfig(nshortest=n))
+        n_dev = int(rustfst_amd.default_context().stats()["nbest_device_problems"])
+        if device == "1":
+            assert n_dev >= len(flats) - 8, n_dev  # (inputs without a start state or a reachable final never get there)
+        elif device == "0":
+            assert n_dev == 0
+        for i, (f, g) in enumerate(zip(flats, got)):
+            exp = to_oracle(oracle, f).shortest_path_n(n).to_flat()
+            assert_flat_identical(g.to_flat(), exp, f"n-best batch ({device}) input {i} n={n}")
+    # n = 1 and n = 0 through the same call
+    one = rustfst_amd.shortest_path_batch(devs[:5], ShortestPathConfig(nshortest=1))
+    for f, g in zip(flats[:5], one):
+        assert_flat_identical(g.to_flat(), to_oracle(oracle, f).shortest_path_canonical().to_flat(), "batch n=1")
+
+
 @pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
 def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle, lazy, monkeypatch):
     monkeypatch.setenv("WFST_NBEST_LAZY", lazy)
