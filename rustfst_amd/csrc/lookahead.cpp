@@ -459,15 +459,23 @@ bool compute_acyclic_parallel(uint32_t ins, const uint32_t* offsets, const wfst_
     uint32_t len;
   };
   struct BlockArena {
-    std::vector<std::unique_ptr<Iv[]>> blocks;
+    std::vector<Iv*> blocks;  // (raw storage: `new Iv[]` would zero every block first)
     size_t used = 0, cap = 0;
+    BlockArena() = default;
+    BlockArena(const BlockArena&) = delete;
+    BlockArena(BlockArena&& o) noexcept : blocks(std::move(o.blocks)), used(o.used), cap(o.cap) { o.blocks.clear(); }
+    ~BlockArena() {
+      for (Iv* b : blocks) std::free(b);
+    }
     Iv* alloc(size_t n) {
       if (used + n > cap) {
         cap = std::max<size_t>(n, (size_t)1 << 20);
-        blocks.emplace_back(new Iv[cap]);
+        Iv* b = (Iv*)std::malloc(cap * sizeof(Iv));
+        if (!b) throw Error("out of memory");
+        blocks.push_back(b);
         used = 0;
       }
-      Iv* r = blocks.back().get() + used;
+      Iv* r = blocks.back() + used;
       used += n;
       return r;
     }

@@ -244,7 +244,7 @@ best = [1e9, 1e9]
 for _ in range(20):
     c0 = time.perf_counter(); comm.gather_paths_begin(outs, 38); c1 = time.perf_counter(); comm.gather_paths_end(); c2 = time.perf_counter()
     best = [min(best[0], c1 - c0), min(best[1], c2 - c0)]
-print("C-ABI gather: begin %.1f us, begin+end %.1f us" % (best[0] * 1e6, best[1] * 1e6))
+print("C-ABI gather: begin %%.1f us, begin+end %%.1f us" %% (best[0] * 1e6, best[1] * 1e6))
 del comm
 dist.barrier(); dist.destroy_process_group()
 print("RCCL-1 OK")
