@@ -93,7 +93,8 @@ def config5_extra(n_states, ctx, device):
     shortest paths of every result; the CPU restatement beside it on a smaller operand (the largest it finishes in a few
     seconds).  No oracle at full size: the 10 best weights of the first results are checked against the plain composition."""
     import torch
-    from rustfst_amd import ShortestPathConfig, ComposeConfig
+    import rustfst_amd
+    from rustfst_amd import ShortestPathConfig, ComposeConfig, synth
     res = {"workload": f"configs[4]: HCLG-shaped FST ({n_states} states, fan-out 10, 5 % output epsilons) as look-ahead operand, "
                        "64 linear acceptors (len 200), look-ahead composition (batch of 64) + n = 10 shortest paths each"}
 

@@ -778,13 +778,19 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       }
     }
   }
+  // ---- publish, part 1: the region counts.  The cursors are final (barrier of the last round), and an entry only needs a
+  //      store when it is non-zero or when the column still holds this workgroup's counts of two sweeps ago: issued now,
+  //      the stores are on their way while the waiting set is worked out below.
+  for (uint32_t d = tid; d < nb; d += MB_THREADS) {
+    const uint32_t c = l_cur[d];
+    if (c != 0u || wrote_out) mb.cnt[par_out][(size_t)d * nb + j] = c;
+  }
   if (profile)
     for (int d = 32; d >= 1; d >>= 1) p_arcs += __shfl_xor(p_arcs, d);
   if (lane == 0) {
     if (sent) atomicAdd(&s_sent, sent);
     if (profile && p_arcs) atomicAdd(&s_prof_arcs, p_arcs);
   }
-  __syncthreads();
   MB_STAMP(5);
 
   // ---- states improved from inside the block during the expansion: written back; they wait (expanded next sweep).
@@ -824,8 +830,6 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   // ---- publish: region counts, activity
   const uint32_t total_sent = s_sent, npend = s_npend, nfar = s_nfar;
   const bool any_out = total_sent != 0;  // messages that left the block (same-block candidates are not counted)
-  if (any_out || wrote_out)
-    for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = l_cur[d];
   if (tid == 0) {
     if (any_out != wrote_out) mb.wrote[par_out][j] = any_out ? 1u : 0u;
     mb.blk_pend[j] = npend;

@@ -7,14 +7,14 @@ sys.path.insert(0, ROOT)
 from bench import kernel_sources_sha256
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-KERNELS = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mboxa_kernel")
+KERNELS = ("sssp_relax_kernel", "sssp_mbox_kernel")
 per = {}
 for db in sorted(glob.glob(os.path.join(out_dir, "*_results.db"))):
     c = sqlite3.connect(db)
     n_solves = c.execute("select count(*) from pmc_events where name like '%setup_kernel%' group by counter_name").fetchone()
     n_solves = max(1, n_solves[0] if n_solves else 1)
     for name, cname, n, tot in c.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
-        short = name.replace("wfst::(anonymous namespace)::", "").split("(")[0]
+        short = name.replace("wfst::(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0]
         if short in KERNELS:
             per.setdefault(short, {})[cname] = (n / n_solves, tot / n_solves)
 kernel = max(per, key=lambda k: per[k].get("FETCH_SIZE", (0, 0))[1])

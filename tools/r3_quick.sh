@@ -14,3 +14,10 @@ grep -v amdgpu.ids $OUT/timing.txt
 WFST_SSSP_MBOX_TRACE=/tmp/mbox_trace.bin timeout 300 python tools/sp_repeat.py 1000000 4 > /dev/null 2>&1 && python tools/mbox_phases.py /tmp/mbox_trace.bin > $OUT/phases.txt 2>&1
 timeout 200 python tools/soak_sssp.py ${SOAK_S:-30} 30000 > $OUT/soak.txt 2>&1
 tail -1 $OUT/soak.txt
+for sz in ${BIG_SIZES:-}; do
+  for m in 1 0; do
+    echo "== states $sz WFST_SSSP_MAILBOX=$m" >> $OUT/big.txt
+    WFST_SSSP_MAILBOX=$m timeout -k 5 200 python tools/sp_repeat.py $sz 10 >> $OUT/big.txt 2>&1
+  done
+done
+[ -f $OUT/big.txt ] && grep -v amdgpu.ids $OUT/big.txt

@@ -30,8 +30,8 @@ def trace(path):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | "
               f"{a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
-    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mboxa_kernel"):
-        rel = [(e - s) for name, s, e in rows if kname + "(" in name]
+    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel"):
+        rel = [(e - s) for name, s, e in rows if kname + "(" in name or kname + "<" in name]
         if not rel:
             continue
         n_solves = sum(1 for name, _, _ in rows if "setup_kernel" in name) or 1
