@@ -314,6 +314,16 @@ wfst_status wfst_comm_allgather_end(wfst_comm* comm, void* recv /* [world * byte
 wfst_status wfst_comm_allgatherv(wfst_comm* comm, const void* send, size_t bytes, uint64_t* sizes /* [world] */, void** recv,
                                  size_t* total);
 
+/* Tie order of shortest_path (nshortest = 1).  0 (default): the canonical rule — fewest arcs, then the smallest (source
+ * state, arc position), the smallest final state; schedule-free, what every GPU path computes.  1: the REFERENCE's choice
+ * where it is well defined cheaply, i.e. on ACYCLIC inputs (composed lattices): rustfst relaxes states in the topological
+ * order of its depth-first visit (queues/auto_queue.rs:23-99 -> TopOrderQueue, top_sort.rs:12-61, dfs_visit.rs:97-187) and
+ * keeps the FIRST arc, in (order of the source, arc position), that attains the final distance (shortest_path.rs:214-232),
+ * and the first final state in that order.  The visit runs on the host (it is sequential by definition), distances and
+ * the predecessor pass on the GPU.  Cyclic inputs keep the canonical rule under either setting (the reference's FIFO order
+ * inside a cycle is a schedule, not a rule). */
+wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order);
+
 /* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
 typedef struct {
   /* relaxation kernel (sssp_relax_*): launches, total device time from HIP events on ctx's stream,

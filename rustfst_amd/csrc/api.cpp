@@ -593,6 +593,12 @@ wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t
   });
 }
 
+wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order) {
+  return wrap([&] {
+    if (!ctx) throw Error("null ctx");
+    ctx->tie_reference = reference_order != 0;
+  });
+}
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on) {
   return wrap([&] {
     if (!ctx) throw Error("null ctx");

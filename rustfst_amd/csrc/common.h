@@ -113,6 +113,7 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned;      // small D2H/H2D staging
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
+  bool tie_reference = false;  // wfst_ctx_set_tie_order: the reference's predecessor choice on acyclic inputs
   // wfst_ctx_set_profiling(ctx, 2): no per-launch events; the sweeps of a repeated (predicted) shortest_path query are timed
   // as ONE chain between two events on the stream, without any synchronisation between launches
   bool chain_timing = false;

@@ -711,6 +711,83 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   }
 }
 
+// ---- the reference's tie order on acyclic inputs (wfst_ctx_set_tie_order; include/wfst.h).  rank[s] = position of s in
+// the topological order of the reference's depth-first visit (host), r2s = its inverse.
+// f_parent: the FIRST state in that order whose d[s] (x) rho(s) attains the minimum (shortest_path.rs:214-220: only a
+// strict improvement replaces f_parent, and states are dequeued in that order)
+__global__ void __launch_bounds__(256) sssp_final_ref_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key,
+                                                            const uint32_t* __restrict__ rank, uint32_t n, Ctl* __restrict__ ctl) {
+  unsigned long long best = KEY_INF;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const float f = finals[s];
+    if (!(f < INF)) continue;
+    const uint64_t k = key[s];
+    if (k == KEY_INF) continue;
+    const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;
+    if (!(tot < INF)) continue;
+    const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | rank[s];
+    best = c < best ? c : best;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != KEY_INF) atomicMin(&ctl->best, best);
+}
+// parent[t]: the FIRST arc, in (rank of the source, arc position), whose candidate d[s] (x) w equals d[t] — every later arc
+// with the same candidate is no strict improvement and leaves the parent alone (shortest_path.rs:222-232)
+__global__ void __launch_bounds__(256) sssp_parent_ref_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
+                                                             const uint64_t* __restrict__ key, const uint32_t* __restrict__ rank,
+                                                             unsigned long long* __restrict__ parent, uint32_t n) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = tid % GROUP;
+  const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
+  for (uint32_t s = tid / GROUP; s < n; s += n_groups) {
+    const uint64_t ks = key[s];
+    if (ks == KEY_INF) continue;
+    const float d = dec_f32((uint32_t)(ks >> 32));
+    const uint32_t b = offsets[s], e = offsets[s + 1];
+    const unsigned long long rs = (unsigned long long)rank[s] << 32;
+    for (uint32_t i = b + lane; i < e; i += GROUP) {
+      const uint2 a = wn[i];
+      const float c = (d + __uint_as_float(a.x)) + 0.0f;
+      if (!(c < INF)) continue;
+      if (enc_f32(c) == (uint32_t)(key[a.y] >> 32)) atomicMin(&parent[a.y], rs | (i - b));
+    }
+  }
+}
+__global__ void sssp_backtrace_ref_kernel(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
+                                          const float* __restrict__ finals, const unsigned long long* __restrict__ parent,
+                                          const uint32_t* __restrict__ r2s, uint32_t start, Ctl* __restrict__ ctl,
+                                          wfst_tr* __restrict__ out, uint32_t out_cap) {
+  if (threadIdx.x || blockIdx.x) return;
+  const unsigned long long best = ctl->best;
+  if (best == KEY_INF) {
+    ctl->has_path = 0;
+    ctl->hops = 0;
+    return;
+  }
+  uint32_t cur = r2s[(uint32_t)best], k = 0;
+  ctl->has_path = 1;
+  ctl->f_parent = cur;
+  ctl->final_weight = finals[cur];
+  ctl->total = dec_f32((uint32_t)(best >> 32));
+  while (cur != start) {
+    const unsigned long long p = parent[cur];
+    if (p == PARENT_NONE || k >= out_cap) {
+      ctl->pad |= 4u;
+      return;
+    }
+    const uint32_t s = r2s[(uint32_t)(p >> 32)], pos = (uint32_t)p;
+    wfst_tr tr = arcs[offsets[s] + pos];
+    tr.nextstate = k;
+    out[k] = tr;
+    cur = s;
+    ++k;
+  }
+  ctl->hops = k;
+}
+
 __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __restrict__ dist, uint32_t* __restrict__ hops,
                                    uint32_t n) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -836,7 +913,11 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   if (const char* e = std::getenv("WFST_SSSP_TAU0_MULT")) tau0_mult = (float)std::atof(e);
   static_assert(sizeof(Ctl) % 4 == 0, "Ctl is cleared word by word");
   // mailbox sweeps where they pay: branching graphs (the near-far case) whose state ids fit the message format
-  bool want_mbox = delta < INF && mbox_eligible(f);
+  // ... and few enough blocks that the per-pair regions still hold runs of messages: measured on MI355X (fan-out 10), the
+  // mailbox launches win at 1M and 2M states (0.41 vs 0.50 ms, 0.84 vs 0.89), tie at 3M and lose at 5M (3.2 vs 2.4 ms: a
+  // region then receives ~3 messages per sweep, and 1221 workgroups take five turns on 256 CUs).  Beyond MB_NB_DEFAULT
+  // blocks the atomic sweeps stay the default; WFST_SSSP_MAILBOX=1 still selects the mailbox kernel up to 8M states.
+  bool want_mbox = delta < INF && mbox_eligible(f) && ((n + MB_B - 1) >> MB_LOG) <= MB_NB_DEFAULT;
   int mbox_mode = want_mbox ? 1 : 0;
   if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) mbox_mode = mbox_eligible(f) ? std::atoi(e) : 0;
   if (mbox_mode >= 1) {
@@ -1182,6 +1263,99 @@ wfst_fst* build_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float fina
   return make_host_fst(ctx, n_states, start, props::linear_path_props(has_path, hops, final_weight, path_arcs), std::move(h));
 }
 
+// The order in which the reference relaxes the states of an acyclic FST (queues/auto_queue.rs:23-99): state order when the
+// TOP_SORTED bit is set, else the topological order of dfs_visit (dfs_visit.rs:97-187: root = start, then 0, 1, 2, ...; arcs
+// in stored order) — TopOrderQueue from TopOrderVisitor (top_sort.rs:12-61) when the ACYCLIC bit is known, from the SCC
+// numbering otherwise (scc_visitors.rs:173-179): both are the reverse finishing order.  false when the reference would use
+// another discipline: LIFO (unweighted input), or an SCC queue (the input has a cycle).
+bool reference_top_rank(const wfst_fst* f, std::vector<uint32_t>& rank) {
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) return false;
+  ensure_host(f);
+  const HostCsr& h = f->host;
+  rank.resize(n);
+  if (f->props & props::TOP_SORTED) {
+    for (uint32_t s = 0; s < n; ++s) rank[s] = s;
+    return true;
+  }
+  if (!(f->props & props::ACYCLIC)) {
+    if (f->props & props::UNWEIGHTED) return false;  // LifoQueue
+    bool unweighted = true;                          // scc_queue_type's scan
+    for (const wfst_tr& a : h.arcs)
+      if (!props::is_zero(a.weight) && !props::is_one(a.weight)) {
+        unweighted = false;
+        break;
+      }
+    if (unweighted) return false;
+  }
+  enum : uint8_t { White, Grey, Black };
+  std::vector<uint8_t> color(n, White);
+  std::vector<std::pair<uint32_t, uint32_t>> stack;
+  uint32_t finished = 0;
+  uint32_t root = (uint32_t)f->start;
+  while (root < n) {
+    color[root] = Grey;
+    stack.push_back({root, h.offsets[root]});
+    while (!stack.empty()) {
+      const uint32_t s = stack.back().first;
+      uint32_t& pos = stack.back().second;
+      if (pos >= h.offsets[s + 1]) {
+        color[s] = Black;
+        rank[s] = n - 1 - finished++;
+        stack.pop_back();
+        continue;
+      }
+      const uint32_t t = h.arcs[pos++].nextstate;
+      if (color[t] == White) {
+        color[t] = Grey;
+        stack.push_back({t, h.offsets[t]});
+      } else if (color[t] == Grey) {
+        return false;  // a cycle: the reference uses an SCC queue
+      }
+    }
+    root = root == (uint32_t)f->start ? 0 : root + 1;
+    while (root < n && color[root] != White) root++;
+  }
+  return true;
+}
+
+// shortest_path (nshortest = 1) with the reference's choice among tied optima, for an acyclic input whose relaxation order
+// `rank` is known: distances on the GPU as always, then the final state and the predecessors by the rule above.
+wfst_fst* shortest_path_reference_order(wfst_ctx* ctx, const wfst_fst* f, const std::vector<uint32_t>& rank) {
+  const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
+  Solve sv;
+  run_relaxation(ctx, f, sv);
+  std::vector<uint32_t> r2s(n);
+  for (uint32_t s = 0; s < n; ++s) r2s[rank[s]] = s;
+  DBuf<uint32_t> d_rank(*ctx->pool, n), d_r2s(*ctx->pool, n);
+  HIP_CHECK(hipMemcpyAsync(d_rank.p, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(d_r2s.p, r2s.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DBuf<unsigned long long> parent(*ctx->pool, n);
+  DBuf<wfst_tr> out(*ctx->pool, n);
+  HIP_CHECK(hipMemsetAsync(parent.p, 0xFF, (size_t)n * sizeof(unsigned long long), st));
+  HIP_CHECK(hipMemsetAsync(&sv.ctl.p->best, 0xFF, sizeof(unsigned long long), st));
+  HIP_CHECK(hipMemsetAsync(&sv.ctl.p->pad, 0, sizeof(uint32_t), st));
+  sssp_final_ref_kernel<<<std::min<uint32_t>((n + 255) / 256, (uint32_t)ctx->n_cus * 4), 256, 0, st>>>(f->dev.finals, sv.key.p, d_rank.p, n,
+                                                                                                          sv.ctl.p);
+  const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
+  sssp_parent_ref_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, d_rank.p, parent.p, n);
+  sssp_backtrace_ref_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, f->dev.finals, parent.p, d_r2s.p, (uint32_t)f->start, sv.ctl.p,
+                                              out.p, n);
+  Ctl* hc = (Ctl*)ctx->pinned.get(sizeof(Ctl));
+  HIP_CHECK(hipMemcpyAsync(hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (hc->pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
+  if (hc->pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (internal error)");
+  if (!hc->has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
+  const uint32_t len = hc->hops;
+  const float final_weight = hc->final_weight;
+  std::vector<wfst_tr> path(len);
+  if (len) HIP_CHECK(hipMemcpy(path.data(), out.p, (size_t)len * sizeof(wfst_tr), hipMemcpyDeviceToHost));
+  return build_path_fst(ctx, true, len, final_weight, path.data());
+}
+
 }  // namespace
 
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops) {
@@ -1248,6 +1422,7 @@ struct wfst_sp_job {
   wfst_ctx* ctx = nullptr;
   const wfst_fst* f = nullptr;
   bool trivial = false;      // no start state: the result is the empty FST (shortest_path.rs:185-187)
+  wfst_fst* ready = nullptr;  // the result, already computed (reference tie order: a synchronous path)
   bool tail_queued = false;  // final / header / backtrace / read-back already queued behind the first batch
   bool fused_tail = false;   // ... as the one-launch sssp_tail_kernel (result header in h_tail instead of hc)
   wfst::Solve sv;
@@ -1298,6 +1473,13 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
     return j.release();
   }
   ensure_device(const_cast<wfst_fst*>(f));
+  if (ctx->tie_reference) {  // the reference's own choice among tied optima, where its relaxation order is a topological one
+    std::vector<uint32_t> rank;
+    if (reference_top_rank(f, rank)) {
+      j->ready = shortest_path_reference_order(ctx, f, rank);
+      return j.release();
+    }
+  }
   char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 128 + PATH_PINNED * sizeof(wfst_tr));
   j->hc = (Ctl*)pin;
   j->h_tail = (TailOut*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
@@ -1329,6 +1511,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   wfst_ctx* ctx = j->ctx;
   const wfst_fst* f = j->f;
   if (j->trivial) return build_path_fst(ctx, false, 0, INF, nullptr);
+  if (j->ready) return j->ready;
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   Solve& sv = j->sv;
@@ -1387,6 +1570,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
 
 void shortest_path_n1_abandon(wfst_sp_job* job) {
   std::unique_ptr<wfst_sp_job> j(job);
+  delete j->ready;
   if (!j->trivial) (void)hipStreamSynchronize(j->ctx->stream);  // the solve's buffers go back to the pool after this
 }
 

@@ -35,6 +35,7 @@ constexpr uint32_t MB_LOG = 12;
 constexpr uint32_t MB_B = 1u << MB_LOG;  // states per block
 constexpr uint32_t MB_NBMAX = 256;       // blocks handled with one inbox region per 4 lanes in one pass (n <= 2^20)
 constexpr uint32_t MB_NBMAX_BIG = 2048;  // blocks at most (n <= 2^23): inbox regions in passes of 256, shallower staging
+constexpr uint32_t MB_NB_DEFAULT = 768;  // blocks up to which the mailbox launches are the default choice (3.1M states)
 constexpr uint32_t MB_THREADS = 1024;
 constexpr uint32_t MB_HOP_BITS = 32 - MB_LOG;
 constexpr uint32_t MB_UNROLL = 8;  // active states a 16-lane group relaxes at once (independent load chains per lane)

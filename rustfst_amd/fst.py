@@ -71,6 +71,11 @@ class Context:
     def synchronize(self):
         check(_lib.lib().wfst_ctx_synchronize(self._h), "wfst_ctx_synchronize")
 
+    def set_tie_order(self, reference_order: bool):
+        """shortest_path(nshortest = 1): False = the canonical tie rule (default); True = the reference's own choice among
+        tied optima on ACYCLIC inputs (wfst_ctx_set_tie_order)."""
+        check(_lib.lib().wfst_ctx_set_tie_order(self._h, 1 if reference_order else 0), "wfst_ctx_set_tie_order")
+
     @property
     def stream(self) -> int:
         s = C.c_void_p()

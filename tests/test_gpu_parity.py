@@ -548,6 +548,59 @@ def test_mailbox_sweeps_beyond_2_20_states(oracle, monkeypatch, narrow):
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"2.1M states q={q}")
 
 
+def test_reference_tie_order_on_acyclic_inputs(oracle):
+    """wfst_ctx_set_tie_order(ctx, 1): on acyclic inputs shortest_path returns the path RUSTFST returns when optima tie —
+    first strict improver in the topological order of its depth-first visit (auto_queue.rs:23-99, top_order_queue.rs:12-94,
+    shortest_path.rs:214-232) — bit-identical to the oracle's reference-order mode on tied inputs (weights on a 1/2 grid
+    and integer weights: ties everywhere), on random DAGs in arbitrary state numbering (random permutations), on composed
+    lattices with unit-spaced weights, and with the TOP_SORTED / ACYCLIC property bits set.  Inputs on which the
+    reference uses another queue (a cycle; all weights zero / one -> LIFO) keep the canonical rule."""
+    ctx = rustfst_amd.Context(0)
+    ctx.set_tie_order(True)
+    rng = np.random.default_rng(8080)
+    n_ref = n_tied = 0
+    for k in range(60):
+        n = int(rng.integers(2, 120))
+        f = random_fst_flat(rng, n, 4, 3, p_eps_i=0.1, p_final=0.25, acyclic=(k % 6 != 5), min_fanout=1,
+                            weight_grid=int(rng.choice([2, 1])), max_w=int(rng.choice([3, 5])))
+        if k % 2:  # renumber the states at random: the topological order is then not the state order
+            perm = rng.permutation(n).astype(np.uint32)
+            inv = np.argsort(perm)
+            rows, offsets = [], [0]
+            for new in range(n):
+                old = int(inv[new])
+                seg = f["arcs"][f["offsets"][old]:f["offsets"][old + 1]].copy()
+                seg["nextstate"] = perm[seg["nextstate"]]
+                rows.append(seg)
+                offsets.append(offsets[-1] + len(seg))
+            f = dict(f, arcs=np.concatenate(rows) if rows else f["arcs"], offsets=np.array(offsets, np.uint32),
+                     finals=f["finals"][inv], start=int(perm[f["start"]]) if f["start"] is not None else None)
+        if k % 7 == 3 and k % 2 == 0 and k % 6 != 5:
+            f = dict(f, props=f["props"] | synth.ACYCLIC)
+        o = to_oracle(oracle, f)
+        ref = o.shortest_path()  # the reference's order (AutoQueue restatement, approximate ==)
+        got = to_device(f, ctx).shortest_path().to_flat()
+        if ref.queue_kind in ("top_order", "top_order_scc", "state_order"):
+            n_ref += 1
+            n_tied += o.shortest_path_canonical().n_tied_choices > 0
+            assert_flat_identical(got, ref.to_flat(), f"reference tie order, case {k} ({ref.queue_kind})")
+        else:
+            assert_flat_identical(got, o.shortest_path_canonical().to_flat(), f"canonical fallback, case {k} ({ref.queue_kind})")
+    assert n_ref >= 30 and n_tied >= 10, (n_ref, n_tied)
+    # composed lattices with integer weights (ties along the lattice)
+    t = synth.make_transducer(3000, 6, 4, 0.05, seed=12)
+    t["arcs"]["weight"] = np.round(t["arcs"]["weight"])
+    t["finals"] = np.where(np.isfinite(t["finals"]), np.round(t["finals"]), np.inf).astype(np.float32)
+    accs = synth.make_acceptors(t, 6, 25, seed0=31)
+    dt, ot = to_device(t, ctx), to_oracle(oracle, t)
+    for a in accs:
+        lat = to_device(a, ctx).compose(dt)
+        ref = to_oracle(oracle, a).compose(ot).shortest_path()
+        assert ref.queue_kind in ("top_order", "top_order_scc", "state_order")
+        assert_flat_identical(lat.shortest_path().to_flat(), ref.to_flat(), "reference tie order on a composed lattice")
+    ctx.set_tie_order(False)
+
+
 def test_kdelta_gap_on_real_valued_weights(gpu_ctx):
     """The reference relaxes only when the improvement exceeds its approximate == (KDELTA = 1/1024, semiring.rs:159-168,
     shortest_path.rs:226); this engine returns the exact (min,+) fixed point.  On real-valued weights of the BASELINE

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 TAG=${1:-q}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-for cfg in "default" "WFST_SSSP_NARROW=0" "WFST_LIB_PATH=tools/bin/libwfst_amd_r2.so" ${EXTRA_CFGS:-}; do
+for cfg in "default" "WFST_SSSP_NARROW=0" ${EXTRA_CFGS:-}; do
   if [ "$cfg" = "default" ]; then e=""; else e="${cfg//+/ }"; fi
   echo "== $cfg" >> $OUT/timing.txt
   env $e timeout 300 python tools/sp_repeat.py 1000000 30 >> $OUT/timing.txt 2>&1
