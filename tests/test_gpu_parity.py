@@ -558,11 +558,11 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
     ctx = rustfst_amd.Context(0)
     ctx.set_tie_order(True)
     rng = np.random.default_rng(8080)
-    n_ref = n_tied = 0
-    for k in range(60):
+    n_ref = n_tied = n_diff = 0
+    for k in range(90):
         n = int(rng.integers(2, 120))
         f = random_fst_flat(rng, n, 4, 3, p_eps_i=0.1, p_final=0.25, acyclic=(k % 6 != 5), min_fanout=1,
-                            weight_grid=int(rng.choice([2, 1])), max_w=int(rng.choice([3, 5])))
+                            weight_grid=int(rng.choice([2, 1])), max_w=int(rng.choice([2, 3, 5])))
         if k % 2:  # renumber the states at random: the topological order is then not the state order
             perm = rng.permutation(n).astype(np.uint32)
             inv = np.argsort(perm)
@@ -582,11 +582,15 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
         got = to_device(f, ctx).shortest_path().to_flat()
         if ref.queue_kind in ("top_order", "top_order_scc", "state_order"):
             n_ref += 1
-            n_tied += o.shortest_path_canonical().n_tied_choices > 0
-            assert_flat_identical(got, ref.to_flat(), f"reference tie order, case {k} ({ref.queue_kind})")
+            can = o.shortest_path_canonical()
+            n_tied += can.n_tied_choices > 0
+            rf, cf = ref.to_flat(), can.to_flat()
+            n_diff += not (rf["n_states"] == cf["n_states"] and np.array_equal(rf["arcs"], cf["arcs"]))
+            assert_flat_identical(got, rf, f"reference tie order, case {k} ({ref.queue_kind})")
         else:
             assert_flat_identical(got, o.shortest_path_canonical().to_flat(), f"canonical fallback, case {k} ({ref.queue_kind})")
-    assert n_ref >= 30 and n_tied >= 10, (n_ref, n_tied)
+    # (the cases are not vacuous: optima tie, and the reference's choice differs from the canonical one on some of them)
+    assert n_ref >= 45 and n_tied >= 8 and n_diff >= 3, (n_ref, n_tied, n_diff)
     # composed lattices with integer weights (ties along the lattice)
     t = synth.make_transducer(3000, 6, 4, 0.05, seed=12)
     t["arcs"]["weight"] = np.round(t["arcs"]["weight"])

@@ -6,7 +6,7 @@ TAG=${1:-t}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 T0=$(date +%s)
-timeout -k 5 420 python -m pytest tests -x -q -m gpu -k "nshortest_batch or rccl_single or config3_benched or compose_config or lookahead_compose_matches or chain_timing or lookahead_relabelling" > $OUT/new_tests.txt 2>&1
+timeout -k 5 420 python -m pytest tests -x -q -m gpu -k "reference_tie_order or nshortest or rccl_single or k2 or shortest_path" > $OUT/new_tests.txt 2>&1
 tail -15 $OUT/new_tests.txt
 echo "[t+$(( $(date +%s) - T0 ))s] tests"
 true
