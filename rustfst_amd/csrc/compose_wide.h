@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t level, Wi
 template <uint32_t G>
 __global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint32_t level, WideCtl* ctl) {
   constexpr uint32_t SPW = 64 / G;
-  __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[64];
+  __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[64], s_status;
   const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
   if (lo >= hi) {  // the search ended before this level: the levels queued behind it must see an empty range too
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -375,7 +375,11 @@ __global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint
     }
     return;
   }
-  if (ctl->status != LA_OK) return;
+  // The status is read ONCE per workgroup: block 0 of this very launch may raise it (overflow) while the others are
+  // between the two barriers below — waves of one workgroup that disagreed would sum uninitialised shares.
+  if (threadIdx.x == 0) s_status = ctl->status;
+  __syncthreads();
+  if (s_status != LA_OK) return;
   const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   uint32_t pre = 0, tot = 0;
   for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) {

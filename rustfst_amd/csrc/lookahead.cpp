@@ -132,7 +132,7 @@ struct ReachVisitor {
   uint32_t root;
   explicit ReachVisitor(const Graph& gr)
       : g(gr), set_off(gr.n(), 0), set_len(gr.n(), 0), state2index(gr.n(), UNASSIGNED), own_begin(gr.n(), 0), root(gr.start) {
-    arena.reserve(2 * gr.dst.size() + gr.n());  // (a decoding graph's sets hold ~1.5 intervals per arc; regrowing 100+ MB is a copy)
+    arena.reserve(gr.dst.size() + gr.dst.size() / 2 + gr.n() / 4);  // (~1.5 intervals per arc on decoding graphs; grows geometrically beyond)
   }
   void discover(uint32_t s) {
     if (g.is_final[s]) {
@@ -207,14 +207,16 @@ struct ReachSets {
   std::vector<uint32_t> len;
   std::vector<uint32_t> state2index;
 };
-void state_reachable(const Graph& g, ReachSets& out) {
+// `known_cyclic`: the caller has already found an epsilon cycle (the parallel path gave up): the visit of the whole graph
+// whose sets would be thrown away at its first back arc is skipped
+void state_reachable(const Graph& g, ReachSets& out, bool known_cyclic) {
   const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
   };
   const auto t0 = now();
-  {
+  if (!known_cyclic) {
     // the visit that builds the sets also answers "acyclic?" (no back arc: compute_and_update_properties(ACYCLIC),
     // label_reachable.rs:146); decoding graphs are acyclic in their epsilon structure, so this is usually all there is
     ReachVisitor rv(g);
@@ -596,8 +598,11 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
   label2index.clear();
   const uint32_t ins = n_states;
   // acyclic epsilon structure (decoding graphs): all host threads, no materialised transformed graph
-  if (!std::getenv("WFST_LOOKAHEAD_SEQUENTIAL") && ins > 0 && compute_acyclic_parallel(ins, offsets, arcs, finals, reach_input, *this, timing))
-    return;
+  bool known_cyclic = false;
+  if (!std::getenv("WFST_LOOKAHEAD_SEQUENTIAL") && ins > 0) {
+    if (compute_acyclic_parallel(ins, offsets, arcs, finals, reach_input, *this, timing)) return;
+    known_cyclic = true;
+  }
   // labelled arcs go to a sink state per label (created in order of first appearance), final states get an arc to the
   // NO_LABEL sink, a super-initial state points at every state nothing points at
   std::unordered_map<uint32_t, uint32_t> label2state;
@@ -635,7 +640,7 @@ void LabelReachData::compute(uint32_t n_states, const uint32_t* offsets, const w
 
   const auto t_graph = now();
   ReachSets sets;
-  state_reachable(g, sets);
+  state_reachable(g, sets, known_cyclic);
   const std::vector<uint32_t>& state2index = sets.state2index;
   const auto t_reach = now();
 

@@ -493,8 +493,12 @@ __global__ void sssp_backtrace_kernel(const uint32_t* __restrict__ offsets, cons
   // need not be the hop count of the final state's key)
   while ((uint32_t)key[cur] != 0u) {
     const unsigned long long p = parent[cur];
-    if (p == PARENT_NONE || k >= out_cap) {  // no admissible predecessor (inexact sums with negative weights)
+    if (p == PARENT_NONE) {  // no admissible predecessor (inexact sums with negative weights)
       ctl->pad |= 4u;
+      return;
+    }
+    if (k >= out_cap) {  // longer than the buffer the host sized from the hop count: it retries with room for n arcs
+      ctl->pad |= 16u;
       return;
     }
     const uint32_t s = (uint32_t)(p >> 32) & 0x7FFFFFFFu, pos = (uint32_t)p;
@@ -1556,10 +1560,19 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     HIP_CHECK(hipMemsetAsync(&sv.ctl.p->pad, 0, sizeof(uint32_t), st));
     const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
     sssp_parent_kernel<<<blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, parent.p, n);
-    DBuf<wfst_tr> out(*ctx->pool, n);
-    sssp_backtrace_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, sv.key.p, parent.p, sv.ctl.p, out.p, n);
-    HIP_CHECK(hipMemcpyAsync(j->hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    // the walk is as long as the final state's hop count except where class-1 predecessors lengthen it: room for four times
+    // that (not 16 B per STATE of a multi-million-state input for a path of a few thousand arcs), all of n on the rare retry
+    uint32_t cap = (uint32_t)std::min<uint64_t>(n, 4ull * hops + 1024);
+    DBuf<wfst_tr> out(*ctx->pool, cap);
+    for (;;) {
+      sssp_backtrace_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, sv.key.p, parent.p, sv.ctl.p, out.p, cap);
+      HIP_CHECK(hipMemcpyAsync(j->hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (!(hc->pad & 16u) || cap >= n) break;
+      cap = n;
+      out = DBuf<wfst_tr>(*ctx->pool, cap);
+      HIP_CHECK(hipMemsetAsync(&sv.ctl.p->pad, 0, sizeof(uint32_t), st));
+    }
     if (hc->pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
     len = hc->hops;
     path.resize(len);
