@@ -92,6 +92,7 @@ def config5_extra(n_states, ctx, device):
     look-ahead operand, 64 linear acceptors (len 200) composed with the look-ahead filter stack in one batch, n = 10
     shortest paths of every result; the CPU restatement beside it on a smaller operand (the largest it finishes in a few
     seconds).  No oracle at full size: the 10 best weights of the first results are checked against the plain composition."""
+    import numpy as np
     import torch
     import rustfst_amd
     from rustfst_amd import ShortestPathConfig, ComposeConfig, synth
