@@ -42,6 +42,7 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+SWEEP_MAX = 4096  # largest batch of the batch_sweep extra
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
 
@@ -236,11 +237,16 @@ def main():
         if rank == 0:
             t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
             flats = [t] + synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
+            if not args.no_extras:  # (before T leaves rank 0: their end states are final states of T everywhere)
+                sweep_accs = synth.make_acceptors(t, SWEEP_MAX, args.acc_len, seed0=50_000)
         flats = wdist.broadcast_flat_fsts(flats, 0, device)
         t, accs_all = flats[0], flats[1:]
     else:
         t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
         accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
+        if not args.no_extras:  # the acceptors of the batch_sweep extra: generated BEFORE T is uploaded (make_acceptors
+            # marks the walks' end states final in T: the device copy and the CPU baseline must see the same T)
+            sweep_accs = synth.make_acceptors(t, SWEEP_MAX, args.acc_len, seed0=50_000)
     dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
     daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx2))
     dt2 = dt  # T is read-only for both pipelines: one HBM copy serves both contexts
@@ -451,9 +457,8 @@ def main():
         batch_sweep = None
         if rank == 0 and not args.no_extras:
             batch_sweep = []
-            for bsz in (64, 512, 4096):
-                accs_b = synth.make_acceptors(t, bsz, args.acc_len, seed0=50_000)
-                db = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(accs_b, ctx2))
+            for bsz in (64, 512, SWEEP_MAX):
+                db = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(sweep_accs[:bsz], ctx2))
                 rustfst_amd.compose_shortest_path_batch(db, dt2, ctx=ctx2)
                 best, n_b = float("inf"), 0
                 for _ in range(5):

@@ -866,6 +866,13 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   return p;
 }
 
+// what the next solve of this FST is sized from: the launches this one needed, and how long that count has been the same
+void note_sweeps(const wfst_fst* f, uint32_t sweeps) {
+  const uint32_t prev = f->last_sweeps.exchange(sweeps, std::memory_order_relaxed);
+  if (prev == sweeps) f->stable_sweeps.fetch_add(1, std::memory_order_relaxed);
+  else f->stable_sweeps.store(0, std::memory_order_relaxed);
+}
+
 // one relaxation sweep on the stream: `j` = position inside the batch (static flag / message parity), `off` = sweep
 // index relative to the device-side base, `abs_sweep` = the absolute index (what the host has queued so far)
 void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint32_t j, uint32_t off, uint32_t abs_sweep,
@@ -1035,9 +1042,11 @@ struct SweepDriver {
     // improve it sends its old or its new key; NARROW launches follow discoveries in whatever order the atomics land), so a
     // repeated query gets the launches the last one needed, the quiet one included, plus ONE: a gated idle launch is ~3 us,
     // a second batch is a host round trip and a re-run of the fused tail.
+    // (the margin is dropped once three solves in a row needed the same count: wfst_fst::stable_sweeps)
     const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, sv->mbox ? last_sweeps + 1u : ((last_sweeps + 1 + 1) & ~1u));
-    predicted = last_sweeps != 0 && last_sweeps < first_count;
+    const uint32_t margin = f->stable_sweeps.load(std::memory_order_relaxed) >= 3 ? 0u : 1u;
+    if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, sv->mbox ? last_sweeps + margin : ((last_sweeps + 1 + 1) & ~1u));
+    predicted = last_sweeps != 0 && (sv->mbox ? last_sweeps <= first_count : last_sweeps < first_count);
     evs[0] = ctx->ev0;
     evs[1] = ctx->ev1;
   }
@@ -1139,6 +1148,7 @@ struct SweepDriver {
       sweeps_done = b.first + k + 1;
       const uint32_t v = hf[(b.first + k) % IMP_RING];
       if (!v) return true;
+      if (v == FLAG_NARROW_CLEAN) return true;  // a NARROW launch that left nothing anywhere: the fixed point, certified
       if (v == 1u && b.first + k < 64) seen_busy |= 1ull << (b.first + k);
     }
     return false;
@@ -1242,7 +1252,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   }
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
-  f->last_sweeps.store(sweeps_done, std::memory_order_relaxed);
+  note_sweeps(f, sweeps_done);
   mbox_dump_trace(ctx, sv);
 }
 
@@ -1523,7 +1533,7 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     j->drv.finish();
     sv.sweeps = j->drv.sweeps_done;
     ctx->stats.sweeps = sv.sweeps;
-    f->last_sweeps.store(sv.sweeps, std::memory_order_relaxed);
+    note_sweeps(f, sv.sweeps);
     f->last_hint_mask.store(j->drv.hint_mask(), std::memory_order_relaxed);
     mbox_dump_trace(ctx, sv);
   }

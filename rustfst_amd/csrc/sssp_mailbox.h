@@ -44,6 +44,10 @@ constexpr uint32_t MB_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-
 
 // modes of a launch (also what the activity flag of a sweep holds, + 1)
 constexpr uint32_t MODE_WIDE = 0, MODE_COLLECT = 1, MODE_NARROW = 2;
+// A NARROW launch's flag: FLAG_NARROW_CLEAN = every workgroup drained what it was given and nothing waits anywhere (no
+// message is in flight after such a launch either): the fixed point is reached and the host needs no quiet launch to see
+// it.  FLAG_NARROW_LEFT = some workgroup left states waiting (spilled, beyond the threshold, messages of the head).
+constexpr uint32_t FLAG_NARROW_CLEAN = 1u + MODE_NARROW, FLAG_NARROW_LEFT = 2u + MODE_NARROW;
 // NARROW launches
 constexpr uint32_t NW_SEG = MB_B;       // work-list segment of a block (COLLECT hands over every state it would have expanded)
 constexpr uint32_t NW_CAP = 1024;       // entries per level a workgroup keeps in LDS (two lists of 16 KB)
@@ -267,16 +271,19 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     s_n[0] = min(wl_n, NW_CAP);
     s_n[1] = 0;
     s_n[2] = 0;
-    s_n[3] = 0;
+    s_n[3] = (waits || wl_n > NW_CAP) ? 1u : 0u;  // something is left waiting after this launch
     if (wl_n) mb.wl_cnt[j] = 0;
-    if ((wl_n || waits) && *improved == 0u) *improved = 1u + MODE_NARROW;
   }
   if (wl_n == 0) {  // (uniform) nothing to follow; whoever waits in this block's masks waits for a WIDE sweep
-    if (tid == 0 && bfar) atomicAdd(nf, (unsigned long long)bfar << 32);
+    if (tid == 0) {
+      if (bfar) atomicAdd(nf, (unsigned long long)bfar << 32);
+      if (waits) atomicMax(improved, FLAG_NARROW_LEFT);
+    }
     return;
   }
   __syncthreads();
   uint32_t cur = 0, prev_n = 0, prev2_n = 0, far_new = 0;
+  bool left_any = false;
   unsigned long long p_arcs = 0, p_states = 0;
   bool grew = false;
   for (uint32_t level = 0;; ++level) {
@@ -345,6 +352,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
               msgs_out[l_roff_out[db] + slot] = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
               if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;
               far_new += 1u;
+              left_any = true;
               v[u] = false;
             }
           }
@@ -366,10 +374,14 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
                 out[slot] = make_uint4(a[u].y, tb[u], enc[u], (h1_[u] << MB_LOG) | min(te[u] - tb[u], NW_DEG_SAT));
                 listed = true;
               }
-              if (!listed) mbox_make_wait(mb, a[u].y, enc[u], false);
+              if (!listed) {
+                mbox_make_wait(mb, a[u].y, enc[u], false);
+                left_any = true;
+              }
             } else {
               mbox_make_wait(mb, a[u].y, enc[u], true);
               far_new += 1u;
+              left_any = true;
             }
           }
           i_[u] += 16;
@@ -397,6 +409,9 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     const uint32_t left = min(s_n[cur], NW_CAP);
     const uint4* __restrict__ in = wl + cur * NW_CAP;
     for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false);
+    if (__any(left_any || left != 0u) && lane == 0) s_n[3] = 1u;
+    __syncthreads();
+    if (tid == 0) atomicMax(improved, s_n[3] ? FLAG_NARROW_LEFT : FLAG_NARROW_CLEAN);
     if (head) {  // the messages of the head: counts of the regions, like a WIDE sweep's publish
       bool any = false;
       for (uint32_t d = tid; d < nb; d += MB_THREADS) {
