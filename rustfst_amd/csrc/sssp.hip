@@ -1149,7 +1149,8 @@ struct SweepDriver {
       const uint32_t v = hf[(b.first + k) % IMP_RING];
       if (!v) return true;
       if (v == FLAG_NARROW_CLEAN) return true;  // a NARROW launch that left nothing anywhere: the fixed point, certified
-      if (v == 1u && b.first + k < 64) seen_busy |= 1ull << (b.first + k);
+      // (WIDE and COLLECT launches have every block awake and loading its keys: no gate next time)
+      if ((v == 1u + MODE_WIDE || v == 1u + MODE_COLLECT) && b.first + k < 64) seen_busy |= 1ull << (b.first + k);
     }
     return false;
   }
