@@ -605,6 +605,33 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
     ctx.set_tie_order(False)
 
 
+def test_handles_outlive_their_context():
+    """wfst_ctx_destroy before wfst_fst_destroy (interpreter shutdown destroys in any order; a Rust host may drop a context
+    first): a handle shares ownership of the context's memory pool, so its arena and its cached derived data (mailbox
+    plan, transpose) are still released into a live pool."""
+    import ctypes as C
+    from rustfst_amd import _lib
+    L = _lib.lib()
+    t = synth.make_transducer(70_000, 8, 64, 0.0, seed=1)
+    ctx = C.c_void_p()
+    _lib.check(L.wfst_ctx_create(0, C.byref(ctx)))
+    h = C.c_void_p()
+    _lib.check(L.wfst_fst_upload(ctx, t["n_states"], t["start"], t["offsets"].ctypes.data, t["arcs"].ctypes.data,
+                                 t["finals"].ctypes.data, t["props"], C.byref(h)))
+    outs = []
+    for _ in range(3):  # region plan on the first solve, transpose on the second
+        o = C.c_void_p()
+        _lib.check(L.wfst_shortest_path(ctx, h, None, C.byref(o)))
+        outs.append(o)
+    _lib.check(L.wfst_ctx_destroy(ctx))
+    for o in outs:
+        _lib.check(L.wfst_fst_destroy(o))
+    _lib.check(L.wfst_fst_destroy(h))
+    # and a fresh context still works afterwards
+    ctx2 = rustfst_amd.Context(0)
+    assert to_device(t, ctx2).shortest_path().num_states > 0
+
+
 def test_kdelta_gap_on_real_valued_weights(gpu_ctx):
     """The reference relaxes only when the improvement exceeds its approximate == (KDELTA = 1/1024, semiring.rs:159-168,
     shortest_path.rs:226); this engine returns the exact (min,+) fixed point.  On real-valued weights of the BASELINE
