@@ -330,6 +330,9 @@ def main():
             last["gathered"] = comm.gather_paths_end()
             last["pending"] = False
         if outs is not None:
+            # behind this step's relaxation (already queued on ctx's stream): its sweeps need every compute unit, the
+            # all-gather kernel runs beside the one-workgroup head of the NEXT solve instead
+            comm.order_after(ctx)
             comm.gather_paths_begin(outs, args.acc_len + 8)
             last["pending"] = True
 

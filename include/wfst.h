@@ -305,6 +305,10 @@ wfst_status wfst_comm_destroy(wfst_comm* comm);
  * One exchange in flight per communicator. */
 wfst_status wfst_gather_paths_begin(wfst_comm* comm, const wfst_fst* const* paths, size_t n, uint32_t max_arcs);
 wfst_status wfst_gather_paths_end(wfst_comm* comm, uint32_t* out /* [world * n * (4 + 4 * max_arcs)] */);
+/* Orders the communicator's stream behind everything queued on ctx's stream so far: the next exchange then runs AFTER
+ * that work (a step's relaxation sweeps need every compute unit; the all-gather kernel is better off beside the start of
+ * the next step than in the middle of this one).  Optional; without it an exchange starts as soon as it is queued. */
+wfst_status wfst_comm_order_after(wfst_comm* comm, wfst_ctx* ctx);
 /* the same for `bytes` opaque bytes per rank */
 wfst_status wfst_comm_allgather_begin(wfst_comm* comm, const void* send, size_t bytes);
 wfst_status wfst_comm_allgather_end(wfst_comm* comm, void* recv /* [world * bytes] */);

@@ -83,6 +83,7 @@ SYMBOLS = [
     ("wfst_comm_create", C.c_int, [_vp, _vp, _u32, _u32, _P(_vp)]),
     ("wfst_comm_info", C.c_int, [_vp, _P(_u32), _P(_u32)]),
     ("wfst_comm_destroy", C.c_int, [_vp]),
+    ("wfst_comm_order_after", C.c_int, [_vp, _vp]),
     ("wfst_gather_paths_begin", C.c_int, [_vp, _P(_vp), _sz, _u32]),
     ("wfst_gather_paths_end", C.c_int, [_vp, _vp]),
     ("wfst_comm_allgather_begin", C.c_int, [_vp, _vp, _sz]),

@@ -81,6 +81,7 @@ struct wfst_comm {
     size_t bytes = 0;     // bytes per rank of the exchange in flight
     bool in_flight = false;
   } sets[2];
+  hipEvent_t order_ev = nullptr;  // wfst_comm_order_after
   int next = 0, pending = -1;
   uint32_t paths_n = 0, paths_max_arcs = 0;  // shape of a wfst_gather_paths_begin in flight
 };
@@ -185,8 +186,20 @@ wfst_status wfst_comm_destroy(wfst_comm* c) {
       if (s.d_out) (void)hipFree(s.d_out);
       if (s.done) (void)hipEventDestroy(s.done);
     }
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+  });
+}
+
+wfst_status wfst_comm_order_after(wfst_comm* c, wfst_ctx* ctx) {
+  return wrap([&] {
+    if (!c || !ctx) throw Error("null pointer");
+    if (ctx->device != c->device) throw Error("wfst_comm_order_after: the context lives on another GPU");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->order_ev) HIP_CHECK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(c->order_ev, ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->order_ev, 0));
   });
 }
 

@@ -197,6 +197,11 @@ class Comm:
         dist.broadcast(t, 0)
         return cls(ctx, bytes(t.cpu().numpy().tobytes()), rank, world)
 
+    def order_after(self, ctx):
+        """The next exchange starts after everything queued on ctx's stream so far (wfst_comm_order_after)."""
+        from . import _lib
+        _lib.check(_lib.lib().wfst_comm_order_after(self._h, ctx._h), "wfst_comm_order_after")
+
     def gather_paths_begin(self, paths, max_arcs: int):
         """Queues the all-gather of this rank's path FSTs (a PathList or a list of DeviceFst) and returns at once."""
         import ctypes as C

@@ -233,6 +233,7 @@ comm = wdist.Comm.from_torch_group(ctx, dev)
 assert (comm.rank, comm.world) == (0, 1)
 g3 = comm.gather_paths(outs, 30 + 8)
 assert g3.shape == g1.shape and np.array_equal(g3, g1)
+comm.order_after(ctx)  # (the exchange queued next starts after what the context has queued so far)
 comm.gather_paths_begin(outs, 30 + 8)  # asynchronous form: something else runs meanwhile
 sp = dt.shortest_path()
 assert np.array_equal(comm.gather_paths_end(), g1) and sp.num_states > 0
