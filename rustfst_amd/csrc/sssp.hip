@@ -983,6 +983,10 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_DYN_BUDGET));
       HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_DYN_BUDGET));
     });
+    // A mailbox sweep costs its ~10 us chain of dependent trips whatever it expands, up to ~256 states per block: the
+    // threshold moves on as soon as the near set is below 1/16 of the states (measured, tools/param_sweep.py: 4096 ->
+    // 65536 at 1M / 2M states is 0.407 -> 0.386 and 0.817 -> 0.741 ms; at 300 k states 16384 is the best)
+    if (!std::getenv("WFST_SSSP_NEAR_LOW")) sv.near_low = std::min<uint32_t>(65536u, std::max<uint32_t>(4096u, n / 16u));
     // hand-over to NARROW launches when the near set plus everything waiting beyond the threshold is this small
     sv.narrow_t = 8192;
     if (const char* e = std::getenv("WFST_SSSP_NARROW")) sv.narrow_t = (uint32_t)std::atol(e);
