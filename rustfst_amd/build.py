@@ -42,6 +42,8 @@ def build(force=False, verbose=False):
                "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, s), "-o", obj]
         if os.environ.get("WFST_PHASE_TIMING") == "1":
             cmd.insert(-4, "-DWFST_PHASE_TIMING")
+        for d in os.environ.get("WFST_CXX_DEFS", "").split():  # experiments: e.g. -DWFST_MB_THREADS=512
+            cmd.insert(-4, d)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -36,9 +36,13 @@ constexpr uint32_t MB_B = 1u << MB_LOG;  // states per block
 constexpr uint32_t MB_NBMAX = 256;       // blocks handled with one inbox region per 4 lanes in one pass (n <= 2^20)
 constexpr uint32_t MB_NBMAX_BIG = 2048;  // blocks at most (n <= 2^23): inbox regions in passes of 256, shallower staging
 constexpr uint32_t MB_NB_DEFAULT = 768;  // blocks up to which the mailbox launches are the default choice (3.1M states)
-constexpr uint32_t MB_THREADS = 1024;
+#ifndef WFST_MB_THREADS
+#define WFST_MB_THREADS 1024
+#endif
+constexpr uint32_t MB_THREADS = WFST_MB_THREADS;
+constexpr uint32_t MB_LPR = MB_THREADS / 256;  // lanes that share an inbox region / a destination's staged run
 constexpr uint32_t MB_HOP_BITS = 32 - MB_LOG;
-constexpr uint32_t MB_UNROLL = 8;  // active states a 16-lane group relaxes at once (independent load chains per lane)
+constexpr uint32_t MB_UNROLL = 8 * (1024 / MB_THREADS);  // active states a 16-lane group relaxes at once (independent load chains per lane)
 constexpr uint32_t MB_STG_MAX = 24;  // messages per destination staged in LDS between two flushes (the rest is stored directly)
 constexpr uint32_t MB_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-destination cursors) next to 57 KB static
 
@@ -54,7 +58,7 @@ constexpr uint32_t NW_CAP = 1024;       // entries per level a workgroup keeps i
 constexpr uint32_t NW_GROW = 384;       // head of the search (one workgroup): a level wider than this goes back to the WIDE sweeps
 constexpr uint32_t NW_GROW_MANY = 48;   // ... when every workgroup follows a segment (a level then costs atomics chip-wide)
 constexpr uint32_t NW_SMALL = 1024;     // near + far-waiting states below which a sweep hands over even while it grows
-constexpr uint32_t NW_UNROLL = 4;       // entries a 16-lane group relaxes at once
+constexpr uint32_t NW_UNROLL = 4 * (1024 / MB_THREADS);       // entries a 16-lane group relaxes at once
 constexpr uint32_t NW_MAX_LEVELS = 4096;
 constexpr uint32_t NW_DEG_SAT = 0xFFFu;  // arc count field of an entry; saturated = read offsets[s + 1]
 
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   // ---- trip 1: every load of the prologue is ISSUED before anything is consumed (an LDS store of a loaded value waits
   // for it, and loads come back in order: one such store in front of the schedule words makes the prologue two trips).
   // Inbox region i is read by threads 4i .. 4i+3 (BIG: in passes of 256 regions, counts staged through LDS).
-  const uint32_t reg = tid >> 2, q = tid & 3u;
+  const uint32_t reg = tid / MB_LPR, q = tid % MB_LPR;
   constexpr uint32_t NBR = BIG ? MB_NBMAX_BIG / MB_THREADS : 1;  // per-destination table entries per thread
   uint32_t c_in = 0, rb_in = 0;
   uint32_t cin_r[NBR], rin_r[NBR], ro_r[NBR];
@@ -636,27 +640,27 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   const uint2* __restrict__ msgs_in = mb.msgs[par_in];
   constexpr uint32_t MU = 8;  // messages a thread requests at once (a region of up to 32 messages is one trip)
   if (!BIG) {
-    for (uint32_t k0 = q; k0 < c_in; k0 += 4u * MU) {
+    for (uint32_t k0 = q; k0 < c_in; k0 += MB_LPR * MU) {
       uint2 m[MU];
       for (uint32_t u = 0; u < MU; ++u) {
         m[u] = make_uint2(0u, 0u);
-        if (k0 + 4u * u < c_in) m[u] = msgs_in[rb_in + k0 + 4u * u];
+        if (k0 + MB_LPR * u < c_in) m[u] = msgs_in[rb_in + k0 + MB_LPR * u];
       }
       for (uint32_t u = 0; u < MU; ++u)
-        if (k0 + 4u * u < c_in)
+        if (k0 + MB_LPR * u < c_in)
           atomicMin(&lkey[m[u].x & (MB_B - 1u)], ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
     }
   } else {
-    for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / 4) {
+    for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / MB_LPR) {
       const uint32_t c = l_cin[rg], rb = l_rin[rg];
-      for (uint32_t k0 = q; k0 < c; k0 += 4u * MU) {
+      for (uint32_t k0 = q; k0 < c; k0 += MB_LPR * MU) {
         uint2 m[MU];
         for (uint32_t u = 0; u < MU; ++u) {
           m[u] = make_uint2(0u, 0u);
-          if (k0 + 4u * u < c) m[u] = msgs_in[rb + k0 + 4u * u];
+          if (k0 + MB_LPR * u < c) m[u] = msgs_in[rb + k0 + MB_LPR * u];
         }
         for (uint32_t u = 0; u < MU; ++u)
-          if (k0 + 4u * u < c)
+          if (k0 + MB_LPR * u < c)
             atomicMin(&lkey[m[u].x & (MB_B - 1u)], ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
       }
     }
@@ -783,9 +787,9 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       __syncthreads();
       MB_STAMP(13);
       // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
-      for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / 4) {
+      for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / MB_LPR) {
         const uint32_t b0 = l_base[rg], cnt = min(l_cur[rg] - b0, stg), ro = l_roff_out[rg] + b0;
-        for (uint32_t k = q; k < cnt; k += 4) msgs_out[ro + k] = l_stage[rg * stg + k];
+        for (uint32_t k = q; k < cnt; k += MB_LPR) msgs_out[ro + k] = l_stage[rg * stg + k];
       }
       if (r0 + ROUND < an) {  // another round: its messages are staged from the current cursors on
         __syncthreads();
