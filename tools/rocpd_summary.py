@@ -12,7 +12,7 @@ def short(name, n=96):
     return name if len(name) < n else name[:n - 3] + "..."
 
 
-def trace(path):
+def trace(path, alg_bytes=212e6):
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end from kernels").fetchall()
     agg = {}
@@ -41,8 +41,8 @@ def trace(path):
         print(f"{kname}: {len(rel)} launches in {n_solves} solves ({len(rel) / n_solves:.1f} per solve); "
               f"avg over all launches {sum(rel) / len(rel) / 1e3:.2f} us; "
               f"{len(work)} launches >= 5.5 us avg {sum(work) / max(1, len(work)) / 1e3:.2f} us; "
-              f"kernel time per solve {per_solve:.1f} us -> 212 MB (20 E + 12 N) / that = {212e6 / per_solve / 1e3:.1f} GB/s "
-              f"= {212e6 / per_solve / 1e3 / 8000:.4f} of the 8 TB/s peak")
+              f"kernel time per solve {per_solve:.1f} us -> {alg_bytes / 1e6:.0f} MB (20 E + 12 N) / that = {alg_bytes / per_solve / 1e3:.1f} GB/s "
+              f"= {alg_bytes / per_solve / 1e3 / 8000:.4f} of the 8 TB/s peak")
 
 
 def pmc(fetch_db, write_db):
