@@ -282,6 +282,16 @@ wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
 wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, const wfst_shortest_path_config* cfg,
                                      wfst_fst** outs);
 
+/* wfst_compose_shortest_path_batch with the results as RECORDS (the layout of wfst_fst_pack_paths below) instead of handles:
+ * out[i * (4 + 4 * max_arcs) ...] = path i, written straight from the kernel's result buffers — for hosts that read the
+ * paths as a table (a decoder taking the output labels, the exchange between GPUs).  A path FST handle costs ~0.5 us of
+ * host time to build and as much to destroy: beyond a few hundred acceptors per call that, not the GPU, is the batch's
+ * time (bench.py `batch_sweep`).  KO if a path has more than max_arcs arcs. */
+wfst_status wfst_compose_shortest_path_batch_packed(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n, const wfst_fst* t,
+                                                    const wfst_compose_config* compose_cfg,
+                                                    const wfst_shortest_path_config* sp_cfg, uint32_t max_arcs, uint32_t* out,
+                                                    uint64_t* composed_arcs);
+
 /* Packs n linear path FSTs (outputs of the calls above) into fixed-size records for one all-gather:
  * record i = [n_arcs u32, final-weight bits u32, valid u32, 0] followed by max_arcs 16-byte arcs (zero padded),
  * i.e. (4 + 4*max_arcs) u32 words.  KO if a path has more than max_arcs arcs or is not linear. */

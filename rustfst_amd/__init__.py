@@ -18,6 +18,7 @@ from .fst import (  # noqa: F401
     compose,
     compose_shortest_path_batch,
     compose_shortest_path_batch_begin,
+    compose_shortest_path_batch_packed,
     shortest_path_batch,
     last_nbest_path,
     HandleArray,
@@ -33,6 +34,6 @@ from .fst import (  # noqa: F401
 
 __all__ = [
     "ComposeConfig", "ComposeFilter", "Context", "DeviceFst", "ShortestPathConfig", "Tr", "VectorFst", "acceptor",
-    "compose", "compose_shortest_path_batch", "compose_shortest_path_batch_begin", "shortest_path_batch", "last_nbest_path", "HandleArray", "LookAhead", "ProjectType", "project", "compose_with_config", "default_context", "set_default_context",
+    "compose", "compose_shortest_path_batch", "compose_shortest_path_batch_begin", "compose_shortest_path_batch_packed", "shortest_path_batch", "last_nbest_path", "HandleArray", "LookAhead", "ProjectType", "project", "compose_with_config", "default_context", "set_default_context",
     "shortestpath", "shortestpath_with_config", "WfstError", "TR_DTYPE", "LIB_PATH",
 ]

@@ -79,6 +79,8 @@ SYMBOLS = [
      [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_compose_shortest_path_batch_end", C.c_int, [_vp, _P(_vp), _P(_u64)]),
     ("wfst_fst_pack_paths", C.c_int, [_P(_vp), _sz, _u32, _vp]),
+    ("wfst_compose_shortest_path_batch_packed", C.c_int,
+     [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _u32, _vp, _P(_u64)]),
     ("wfst_comm_unique_id", C.c_int, [_vp]),
     ("wfst_comm_create", C.c_int, [_vp, _vp, _u32, _u32, _P(_vp)]),
     ("wfst_comm_info", C.c_int, [_vp, _P(_u32), _P(_u32)]),

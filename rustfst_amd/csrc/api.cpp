@@ -573,23 +573,27 @@ wfst_status wfst_fst_pack_paths(const wfst_fst* const* paths, size_t n, uint32_t
   return wrap([&] {
     if ((n && !paths) || !out) throw Error("null pointer");
     const size_t rec = 4 + 4 * (size_t)max_arcs;
-    std::memset(out, 0, n * rec * sizeof(uint32_t));
     for (size_t i = 0; i < n; ++i) {
-      const wfst_fst* f = paths[i];
-      if (!f) throw Error("null path in batch");
-      ensure_host(f);
-      uint32_t* r = out + i * rec;
-      const float inf = INF;
-      std::memcpy(&r[1], &inf, 4);
-      if (f->n_states == 0) continue;
-      const uint64_t n_arcs = f->n_arcs;
-      if (n_arcs + 1 != f->n_states) throw Error("wfst_fst_pack_paths: not a linear path FST");
-      if (n_arcs > max_arcs) throw Error("wfst_fst_pack_paths: path longer than the record");
-      r[0] = (uint32_t)n_arcs;
-      std::memcpy(&r[1], &f->host.finals[0], 4);
-      r[2] = 1;
-      if (n_arcs) std::memcpy(&r[4], f->host.arcs.data(), n_arcs * sizeof(wfst_tr));
+      if (!paths[i]) throw Error("null path in batch");
+      pack_path_record(out + i * rec, max_arcs, paths[i]);
     }
+  });
+}
+
+wfst_status wfst_compose_shortest_path_batch_packed(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n, const wfst_fst* t,
+                                                    const wfst_compose_config* ccfg, const wfst_shortest_path_config* scfg,
+                                                    uint32_t max_arcs, uint32_t* out, uint64_t* composed_arcs) {
+  return wrap([&] {
+    if (!ctx || !t || (n && (!acceptors || !out))) throw Error("null pointer");
+    wfst_compose_config c = ccfg ? *ccfg : wfst_compose_config{0, 1};
+    wfst_shortest_path_config s = scfg ? *scfg : wfst_shortest_path_config{1e-6f, 1, 0};
+    if (c.compose_filter > 6) throw Error("unknown compose_filter");
+    if (s.nshortest != 1) throw Error("unsupported: nshortest != 1 in the fused batch");
+    if (ctx->batch_in_flight) throw Error("a batch is in flight on this context");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const PackedSink sink{max_arcs, out};
+    compose_shortest_path_batch_end(compose_shortest_path_batch_begin(ctx, acceptors, n, t, c.compose_filter), nullptr, composed_arcs,
+                                    &sink);
   });
 }
 

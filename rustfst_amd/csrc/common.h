@@ -282,7 +282,15 @@ void compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* accs, siz
                                  wfst_fst** outs, uint64_t* composed_arcs, uint32_t filter = 0);
 wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* accs, size_t n, const wfst_fst* t,
                                                   uint32_t filter = 0);
-void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs);
+// `sink`: the results as fixed-size records (layout of wfst_fst_pack_paths) instead of handles (outs may then be null)
+struct PackedSink {
+  uint32_t max_arcs;
+  uint32_t* out;
+};
+void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint64_t* composed_arcs, const PackedSink* sink = nullptr);
+// one record of wfst_fst_pack_paths: [n_arcs, final-weight bits, valid, 0] + max_arcs arcs, zero padded
+void pack_path_record(uint32_t* rec, uint32_t max_arcs, bool valid, uint32_t n_arcs, float final_weight, const wfst_tr* arcs);
+void pack_path_record(uint32_t* rec, uint32_t max_arcs, const wfst_fst* path);
 void compose_shortest_path_batch_abandon(wfst_batch_job* job);
 wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 // compose_wide.hip

@@ -30,6 +30,7 @@
 #include "common.h"
 #include "compose_filters.h"
 #include "fst_props.h"
+#include "host_parallel.h"
 
 namespace wfst {
 
@@ -1263,6 +1264,10 @@ struct BatchRun {
   bool zero_copy = false;
 };
 constexpr uint32_t ZERO_COPY_ARCS = 1u << 18;  // 4 MB of pinned memory per run
+// ... of the string o T kernel, whose path buffer is exact (a path through A_i o T has |A_i| - 1 arcs at most when T has no
+// input epsilons): 64 MB of pinned memory — a batch of 4096 strings of 200 labels writes its 13 MB of path arcs to the host
+// while it runs, instead of a copy command behind the kernel
+constexpr uint32_t ZERO_COPY_ARCS_STRING = 1u << 22;
 
 inline size_t run_pinned_bytes(size_t n, uint32_t eager) {
   return ((n * (sizeof(ProblemDesc) + sizeof(Result)) + 64 + (size_t)eager * sizeof(wfst_tr)) + 255) & ~(size_t)255;
@@ -1274,7 +1279,7 @@ inline size_t run_pinned_bytes(size_t n, uint32_t eager) {
 template <uint32_t FLAGS>
 void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const FstView& f2, const Caps& caps, BatchRun& run,
                   bool want_paths, uint32_t eager_paths = 0, char* pinned = nullptr, bool string_kernel = false,
-                  uint32_t max_f1_states = 0) {
+                  uint32_t max_f1_states = 0, uint32_t exact_path_cap = 0) {
   const size_t n = descs.size();
   DevicePool& pool = *ctx->pool;
   hipStream_t st = ctx->stream;
@@ -1287,7 +1292,8 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
   run.d_desc = DBuf<ProblemDesc>(pool, n);
   run.d_res = DBuf<Result>(pool, n);
   run.d_cursor = DBuf<uint32_t>(pool, 1);
-  const uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
+  uint32_t path_cap = want_paths ? (uint32_t)std::min<uint64_t>((uint64_t)caps.S * n, 0x7FFFFFFFull) : 1u;
+  if (exact_path_cap && want_paths) path_cap = std::min(path_cap, exact_path_cap);  // (see ZERO_COPY_ARCS_STRING)
   run.path_cap = path_cap;
   run.eager = want_paths ? std::min(eager_paths, path_cap) : 0u;
   run.zero_copy = want_paths && pinned && run.eager == path_cap && !ctx->profiling;
@@ -1557,25 +1563,34 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
     const uint64_t cap_s = (uint64_t)c0.S * d_str.size(), cap_g = (uint64_t)c0.S * d_gen.size();
     const bool allow = !std::getenv("WFST_BATCH_COPY");  // tests: the copy-command path
     if (allow && cap_s && cap_s <= ZERO_COPY_ARCS) e_s = (uint32_t)cap_s;
+    else if (allow && eager_s && eager_s <= ZERO_COPY_ARCS_STRING) e_s = (uint32_t)eager_s;  // = the run's whole path buffer
     if (allow && cap_g && cap_g <= ZERO_COPY_ARCS) e_g = (uint32_t)cap_g;
   }
   const size_t pin_s = d_str.empty() ? 0 : run_pinned_bytes(d_str.size(), e_s);
   const size_t pin_g = d_gen.empty() ? 0 : run_pinned_bytes(d_gen.size(), e_g);
   char* pin = (char*)ctx->pinned_big.get(pin_s + pin_g + 256);
   if (!d_str.empty())
-    launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true, max_str_states);
+    launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true, max_str_states,
+                          (uint32_t)std::min<uint64_t>(eager_s, 0x7FFFFFFFull));
   if (!d_gen.empty())
     launch_begin<FLAG_SP>(ctx, d_gen, job->v2, make_caps(job->est_s, job->est_a), job->run, true, e_g, pin + pin_s, false);
   return job.release();
 }
 
-void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, uint64_t* composed_arcs) {
+void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, uint64_t* composed_arcs, const PackedSink* sink) {
   std::unique_ptr<wfst_batch_job> job(job_raw);  // consumed whatever happens
   wfst_ctx* ctx = job->ctx;
   const size_t n = job->n;
   if (composed_arcs) *composed_arcs = 0;
   if (n == 0) return;
-  for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
+  if (!sink)
+    for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
+  // result i: a path FST handle, or (sink) its record — straight from the kernel's result and path buffers
+  const size_t rec_words = sink ? 4 + 4 * (size_t)sink->max_arcs : 0;
+  auto emit = [&](size_t i, const Result& r, const wfst_tr* arcs) {
+    if (sink) pack_path_record(sink->out + i * rec_words, sink->max_arcs, r.has_path != 0, r.hops, r.final_weight, arcs);
+    else outs[i] = path_to_fst(ctx, r, arcs);
+  };
   uint64_t tot_arcs = 0, tot_states = 0, n_string_ok = 0;
   double ms = 0;
   const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
@@ -1584,8 +1599,9 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
   try {
     if (!job->todo_s.empty()) {  // results of the string o T kernel; what it did not cover joins the general list
       launch_end(ctx, job->run_s);
+      const auto t_w = tnow();
       ms += ctx->stats.compose_ms;
-      std::vector<size_t> more;
+      std::vector<size_t> more, ok;
       for (size_t k = 0; k < job->todo_s.size(); ++k) {
         const Result& r = job->run_s.results[k];
         if (r.status != ST_OK) {
@@ -1595,8 +1611,23 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
         tot_arcs += r.n_arcs;
         tot_states += r.n_states;
         n_string_ok += 1;
-        outs[job->todo_s[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run_s.host_paths + r.path_off : nullptr);
+        ok.push_back(k);
       }
+      // the path FSTs (three small vectors and a handle each: ~0.4 us): a large batch shares them out among host threads
+      // (records are a copy of ~3 KB each: fewer threads than for handles — creating a thread costs as much as ~50 records)
+      const unsigned n_thr = std::getenv("WFST_HOST_THREADS")
+                                 ? host_threads(ok.size())
+                                 : (unsigned)std::min<size_t>(std::min(sink ? 8u : 16u, host_threads(1u << 16)), ok.size() / (sink ? 512 : 256));
+      parallel_chunks(n_thr, ok.size(), 64, [&](unsigned, uint64_t b, uint64_t e) {
+        for (uint64_t q = b; q < e; ++q) {
+          const Result& r = job->run_s.results[ok[q]];
+          emit(job->todo_s[ok[q]], r, r.has_path && r.hops ? job->run_s.host_paths + r.path_off : nullptr);
+        }
+      });
+      if (timing)
+        std::fprintf(stderr, "[batch_end] string run: wait %.1f us, %zu results on %u thread(s) %.1f us\n",
+                     std::chrono::duration<double, std::micro>(t_w - t_a).count(), ok.size(), std::max(1u, n_thr),
+                     std::chrono::duration<double, std::micro>(tnow() - t_w).count());
       if (!more.empty()) {
         if (!job->todo.empty()) {  // the general run of this job is still in flight: collect it first
           launch_end(ctx, job->run);
@@ -1609,7 +1640,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
             }
             tot_arcs += r.n_arcs;
             tot_states += r.n_states;
-            outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
+            emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
           }
           more.insert(more.end(), again.begin(), again.end());
         }
@@ -1634,7 +1665,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
         }
         tot_arcs += r.n_arcs;
         tot_states += r.n_states;
-        outs[job->todo[k]] = path_to_fst(ctx, r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
+        emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
       }
       if (timing) std::fprintf(stderr, "[batch_end] assemble %.1f us\n", std::chrono::duration<double, std::micro>(tnow() - t_b).count());
       job->todo.swap(again);
@@ -1652,13 +1683,20 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
       std::unique_ptr<wfst_fst> c(compose(ctx, job->accs[idx], job->t, true, job->filter));
       tot_arcs += c->n_arcs;
       tot_states += c->n_states;
-      outs[idx] = shortest_path_n1(ctx, c.get());
+      if (sink) {
+        std::unique_ptr<wfst_fst> p(shortest_path_n1(ctx, c.get()));
+        pack_path_record(sink->out + idx * rec_words, sink->max_arcs, p.get());
+      } else {
+        outs[idx] = shortest_path_n1(ctx, c.get());
+      }
     }
   } catch (...) {
-    for (size_t i = 0; i < n; ++i) {
-      delete outs[i];
-      outs[i] = nullptr;
-    }
+    (void)hipStreamSynchronize(ctx->stream);  // (a run of this job may still be in flight: its buffers go with the job)
+    if (!sink)
+      for (size_t i = 0; i < n; ++i) {
+        delete outs[i];
+        outs[i] = nullptr;
+      }
     throw;
   }
   ctx->stats.compose_states = tot_states;

@@ -456,6 +456,25 @@ void ensure_device(wfst_fst* f) {
   f->has_dev = true;
 }
 
+void pack_path_record(uint32_t* rec, uint32_t max_arcs, bool valid, uint32_t n_arcs, float final_weight, const wfst_tr* arcs) {
+  if (valid && n_arcs > max_arcs) throw Error("wfst_fst_pack_paths: path longer than the record");
+  const float w = valid ? final_weight : INF;
+  rec[0] = valid ? n_arcs : 0u;
+  std::memcpy(&rec[1], &w, 4);
+  rec[2] = valid ? 1u : 0u;
+  rec[3] = 0;
+  const size_t used = valid ? n_arcs : 0;
+  if (used) std::memcpy(&rec[4], arcs, used * sizeof(wfst_tr));
+  if (used < max_arcs) std::memset(&rec[4 + 4 * used], 0, (max_arcs - used) * sizeof(wfst_tr));
+}
+
+void pack_path_record(uint32_t* rec, uint32_t max_arcs, const wfst_fst* f) {
+  ensure_host(f);
+  if (f->n_states && f->n_arcs + 1 != f->n_states) throw Error("wfst_fst_pack_paths: not a linear path FST");
+  pack_path_record(rec, max_arcs, f->n_states != 0, (uint32_t)f->n_arcs, f->n_states ? f->host.finals[0] : INF,
+                   f->n_arcs ? f->host.arcs.data() : nullptr);
+}
+
 void ensure_host(const wfst_fst* cf) {
   if (cf->has_host) return;
   wfst_fst* f = const_cast<wfst_fst*>(cf);  // cache fill only

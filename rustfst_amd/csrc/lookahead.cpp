@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "fst_props.h"
+#include "host_parallel.h"
 #include "lookahead.h"
 
 namespace wfst {
@@ -289,40 +290,6 @@ void state_reachable(const Graph& g, ReachSets& out, bool known_cyclic) {
 //     function of the index map on an acyclic epsilon graph, so the states are processed in rounds — every state whose
 //     epsilon successors are done — by all host threads, each appending to an arena of its own.
 // A round that finishes nothing means an epsilon cycle: the caller then takes the sequential path above (condensation).
-unsigned host_threads(uint64_t work_items) {
-  unsigned n = std::max(1u, std::thread::hardware_concurrency());
-  if (const char* e = std::getenv("WFST_HOST_THREADS")) n = (unsigned)std::max(1, std::atoi(e));
-  n = std::min(n, 32u);
-  if (work_items < (1u << 16) && !std::getenv("WFST_HOST_THREADS")) n = 1;  // (tests force threads on small inputs)
-  return n;
-}
-
-template <class F>
-void parallel_chunks(unsigned n_thr, uint64_t n_items, uint64_t chunk, F&& body /* (thread, begin, end) */) {
-  if (n_thr <= 1 || n_items <= chunk) {
-    if (n_items) body(0u, (uint64_t)0, n_items);
-    return;
-  }
-  std::atomic<uint64_t> next{0};
-  std::vector<std::exception_ptr> errs(n_thr);
-  std::vector<std::thread> pool;
-  for (unsigned t = 0; t < n_thr; ++t)
-    pool.emplace_back([&, t] {
-      try {
-        for (;;) {
-          const uint64_t b = next.fetch_add(chunk, std::memory_order_relaxed);
-          if (b >= n_items) break;
-          body(t, b, std::min(n_items, b + chunk));
-        }
-      } catch (...) {
-        errs[t] = std::current_exception();
-      }
-    });
-  for (auto& th : pool) th.join();
-  for (auto& e : errs)
-    if (e) std::rethrow_exception(e);
-}
-
 struct LabelTable {  // label -> small value, a flat table in front of a map (labels of decoding graphs are small integers)
   static constexpr uint32_t LUT_MAX = 1u << 22;
   std::vector<uint32_t> lut;

@@ -507,6 +507,30 @@ def compose_shortest_path_batch(acceptors: Sequence[DeviceFst], t: DeviceFst,
     return PathList(outs, n, ctx), na.value
 
 
+def compose_shortest_path_batch_packed(acceptors: Sequence[DeviceFst], t: DeviceFst, max_arcs: int,
+                                       compose_config: Optional["ComposeConfig"] = None,
+                                       shortest_path_config: Optional["ShortestPathConfig"] = None,
+                                       ctx: Optional[Context] = None, out: Optional[np.ndarray] = None):
+    """compose_shortest_path_batch with the results as one table instead of handles
+    (wfst_compose_shortest_path_batch_packed): returns (uint32 array [n, 4 + 4 * max_arcs] in the record layout of
+    dist.pack_paths / dist.unpack_paths, total composed arcs).  No per-path host object is built: the form for large batches.
+    `out`: a C-contiguous uint32 array of that shape to fill (a caller that decodes batch after batch reuses one)."""
+    n = len(acceptors)
+    ctx = ctx or t.ctx
+    arr = acceptors._arr if isinstance(acceptors, HandleArray) else HandleArray(acceptors)._arr
+    shape = (n, 4 + 4 * int(max_arcs))
+    if out is None:
+        out = np.empty(shape, dtype=np.uint32)
+    elif out.shape != shape or out.dtype != np.uint32 or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous uint32 array of shape {shape}")
+    na = C.c_uint64()
+    check(_lib.lib().wfst_compose_shortest_path_batch_packed(
+        ctx._h, arr, n, t._h, compose_config._c() if compose_config else None,
+        shortest_path_config._c() if shortest_path_config else None, int(max_arcs), out.ctypes.data, C.byref(na)),
+        "wfst_compose_shortest_path_batch_packed")
+    return out, na.value
+
+
 def shortest_path_batch(fsts: Sequence[DeviceFst], config: Optional["ShortestPathConfig"] = None,
                         ctx: Optional[Context] = None) -> List[DeviceFst]:
     """[f.shortest_path(config) for f in fsts] as ONE call (wfst_shortest_path_batch): with nshortest > 1 the small

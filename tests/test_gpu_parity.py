@@ -1313,6 +1313,48 @@ def test_string_batch_packed_workgroups(gpu_ctx, oracle, seed):
     assert n_arcs == want_arcs
 
 
+@pytest.mark.parametrize("n_acc", [27, 700], ids=["one_thread", "host_threads"])
+def test_fused_batch_as_packed_records(gpu_ctx, n_acc):
+    """wfst_compose_shortest_path_batch_packed: the same batch with its results as one table (the record layout of
+    wfst_fst_pack_paths) instead of path handles — word for word what packing the handles gives, for strings the string
+    kernel takes, strings with no match in T (empty results), strings that outgrow their slice and are redone by the
+    general kernel, a branching first operand, and enough results for the host threads (> 512); a record too short for a
+    path is an error, not a truncation."""
+    from rustfst_amd import dist
+    rng = np.random.default_rng(77 + n_acc)
+    sigma = 3
+    t = random_fst_flat(rng, 40, 5, sigma, p_final=0.3, sort="ilabel", min_fanout=1, weight_grid=512)
+    def walk(length):  # the input labels along a random walk through T: a string that matches at least that far
+        s, labs = int(t["start"]), []
+        for _ in range(length):
+            b, e = int(t["offsets"][s]), int(t["offsets"][s + 1])
+            k = int(rng.integers(b, e))
+            labs.append(int(t["arcs"]["ilabel"][k]))
+            s = int(t["arcs"]["nextstate"][k])
+        return np.array(labs, dtype=np.uint32)
+
+    accs = [synth.linear_acceptor_flat(walk(int(rng.integers(0, 90))) if k % 2 else rng.integers(1, sigma + 1, int(rng.integers(0, 90))).astype(np.uint32),
+                                       final_weight=0.25 * (k % 3)) for k in range(n_acc - 2)]
+    accs.append(synth.linear_acceptor_flat(np.array([1, 9, 1], dtype=np.uint32)))  # label 9 is not in T: no path
+    accs.append(random_fst_flat(rng, 12, 2, sigma, p_final=0.4, sort="olabel"))  # not a string: the general kernel
+    ctx = rustfst_amd.default_context()
+    dacc, dt = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(accs, ctx)), to_device(t)
+    outs, n_arcs = rustfst_amd.compose_shortest_path_batch(dacc, dt)
+    want = dist.pack_device_paths(outs, 96)
+    got, n_arcs_p = rustfst_amd.compose_shortest_path_batch_packed(dacc, dt, 96)
+    assert n_arcs_p == n_arcs and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    assert got[-2, 2] == 0 and got[:, 2].sum() >= 3 and got[:, 0].max() > 8  # an empty record for the unmatched string; real paths
+    flats = dist.unpack_paths(got[:5])
+    for k in range(5):
+        f = outs[k].to_flat()
+        np.testing.assert_array_equal(flats[k]["arcs"], f["arcs"])
+    with pytest.raises(rustfst_amd.WfstError, match="longer than the record"):
+        rustfst_amd.compose_shortest_path_batch_packed(dacc, dt, 8)
+    again, _ = rustfst_amd.compose_shortest_path_batch_packed(dacc, dt, 96)  # (the context is usable after the error)
+    np.testing.assert_array_equal(again, want)
+
+
 def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
     """Levels wider than one wave, input epsilons in T, epsilons or branching in fst1, explicit non-sequence filters: the
     batch silently takes the general kernel (per problem) and still matches the oracle."""
