@@ -173,7 +173,7 @@ struct RevFst {
 };
 struct RevCsr {
   DBuf<uint32_t> off;  // [n+1]
-  DBuf<uint2> arc;     // [E] {source state, position of the arc in the source's arc list}
+  DBuf<uint4> arc;     // [E] {source state, position of the arc in the source's arc list, weight bits, 0}
 };
 // Message-region plan of the mailbox relaxation sweeps (sssp_mailbox.h): offsets of the region reserved for every
 // (source block, destination block) pair, sized by the number of arcs between the two blocks.

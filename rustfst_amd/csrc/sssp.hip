@@ -519,71 +519,116 @@ __global__ void __launch_bounds__(256) rev_count_kernel(const uint2* __restrict_
     atomicAdd(&indeg[wn[i].y], 1u);
 }
 __global__ void __launch_bounds__(256) rev_fill_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
-                                                      uint32_t n, uint32_t* __restrict__ cursor, uint2* __restrict__ rev_arc) {
+                                                      uint32_t n, uint32_t* __restrict__ cursor, uint4* __restrict__ rev_arc) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = tid % GROUP;
   const uint32_t n_groups = gridDim.x * blockDim.x / GROUP;
   for (uint32_t s = tid / GROUP; s < n; s += n_groups) {
     const uint32_t b = offsets[s], e = offsets[s + 1];
-    for (uint32_t i = b + lane; i < e; i += GROUP) rev_arc[atomicAdd(&cursor[wn[i].y], 1u)] = make_uint2(s, i - b);
+    for (uint32_t i = b + lane; i < e; i += GROUP) {
+      const uint2 a = wn[i];
+      rev_arc[atomicAdd(&cursor[a.y], 1u)] = make_uint4(s, i - b, a.x, 0u);
+    }
   }
 }
 
-// single_shortest_path_backtrace (shortest_path.rs:241-282) over the transpose: one wave; at every step the
-// lanes test the in-arcs of the current state for tightness, (d[s] (x) w, hops[s] + 1) == (d[t], hops[t]), and the
-// smallest (s, pos) wins — the same predecessor sssp_parent_kernel selects.  Arcs go straight to pinned host
-// memory when the path fits in it.
-__global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* __restrict__ offsets,
-                                                               const wfst_tr* __restrict__ arcs,
-                                                               const uint2* __restrict__ wn, const uint64_t* __restrict__ key,
-                                                               const uint32_t* __restrict__ rev_off,
-                                                               const uint2* __restrict__ rev_arc, Ctl* __restrict__ ctl,
-                                                               wfst_tr* __restrict__ out, uint32_t out_cap) {
-  const uint32_t lane = threadIdx.x;
-  if (!ctl->has_path) return;
-  uint32_t cur = ctl->f_parent, k = 0;
-  if (ctl->hops > out_cap) {  // the host falls back to the parent pass
-    if (lane == 0) ctl->pad |= 8u;
-    return;
-  }
-  for (;; ++k) {
-    const uint64_t kt = key[cur];
+// single_shortest_path_backtrace (shortest_path.rs:241-282) over the transpose, by ONE wave: at every step the lanes test
+// the in-arcs of the current state for tightness, (d[s] (x) w, hops[s] + 1) == (d[t], hops[t]), and the smallest
+// (class, s, pos) wins — the same predecessor sssp_parent_kernel selects.  A step is TWO dependent trips: the in-arc
+// entries (source, position, weight: nothing else of the arc is needed), then the sources' keys together with their own
+// in-arc ranges (the winner's is the next step's).  The arcs of the walk themselves are fetched afterwards, all at once
+// (their (state, position) wait in LDS), and go straight to `out` (pinned host memory when the path fits in it).
+// Returns the number of steps taken; pad |= 4: no admissible predecessor, pad |= 8: longer than out_cap.
+constexpr uint32_t WALK_LDS = 1024;
+__device__ __forceinline__ uint32_t sssp_walk_back(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
+                                                   const uint64_t* __restrict__ key, const uint32_t* __restrict__ rev_off,
+                                                   const uint4* __restrict__ rev_arc, uint32_t fp, wfst_tr* __restrict__ out,
+                                                   uint32_t out_cap, uint32_t& pad, uint2* s_walk /* LDS [WALK_LDS] */) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t k = 0;
+  uint64_t kt = key[fp];
+  uint32_t rb = rev_off[fp], re = rev_off[fp + 1];
+  for (;;) {
     if ((uint32_t)kt == 0u) break;  // the start state
     if (k >= out_cap) {
-      if (lane == 0) ctl->pad |= 8u;
-      return;
+      pad |= 8u;
+      break;
     }
-    unsigned long long best = ~0ull;
-    for (uint32_t j = rev_off[cur] + lane; j < rev_off[cur + 1]; j += 64) {
-      const uint2 ra = rev_arc[j];
+    unsigned long long bp = PARENT_NONE;
+    uint64_t my_ks = 0;
+    uint32_t my_rb = 0, my_re = 0;
+    for (uint32_t j = rb + lane; j < re; j += 64) {
+      const uint4 ra = rev_arc[j];
       const uint64_t ks = key[ra.x];
+      const uint32_t sb = rev_off[ra.x], se = rev_off[ra.x + 1];
       if (ks == KEY_INF) continue;
-      const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(wn[offsets[ra.x] + ra.y].x)) + 0.0f;
+      const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(ra.z)) + 0.0f;
       if (!(c < INF)) continue;
       const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
       const unsigned long long cls = parent_class(ck, ks, kt);
       if (cls != PARENT_NONE) {
         const unsigned long long cand = cls | ((unsigned long long)ra.x << 32) | ra.y;
-        best = cand < best ? cand : best;
+        if (cand < bp) {
+          bp = cand;
+          my_ks = ks;
+          my_rb = sb;
+          my_re = se;
+        }
       }
     }
+    unsigned long long best = bp;
     for (int d = 32; d >= 1; d >>= 1) {
       const unsigned long long o = __shfl_xor(best, d);
       best = o < best ? o : best;
     }
     if (best == PARENT_NONE) {  // no admissible predecessor: reported, not followed
-      if (lane == 0) ctl->pad |= 4u;
-      return;
+      pad |= 4u;
+      break;
     }
+    const int wl = __ffsll((unsigned long long)__ballot(bp == best)) - 1;  // (source, position) is unique: one lane holds it
+    kt = __shfl(my_ks, wl);
+    rb = __shfl(my_rb, wl);
+    re = __shfl(my_re, wl);
     const uint32_t s = (uint32_t)(best >> 32) & 0x7FFFFFFFu, pos = (uint32_t)best;
     if (lane == 0) {
-      wfst_tr tr = arcs[offsets[s] + pos];
-      tr.nextstate = k;
-      out[k] = tr;
+      if (k < WALK_LDS) {
+        s_walk[k] = make_uint2(s, pos);
+      } else {  // (a path longer than the list: its arcs are fetched on the way, one dependent trip more per step)
+        wfst_tr tr = arcs[offsets[s] + pos];
+        tr.nextstate = k;
+        out[k] = tr;
+      }
     }
-    cur = s;
+    ++k;
   }
-  if (lane == 0) ctl->hops = k;  // the real length of the walk
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's list is in LDS before the wave reads it back
+  for (uint32_t i = lane; i < min(k, WALK_LDS); i += 64) {
+    const uint2 e = s_walk[i];
+    wfst_tr tr = arcs[offsets[e.x] + e.y];
+    tr.nextstate = i;
+    out[i] = tr;
+  }
+  return k;
+}
+
+__global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* __restrict__ offsets,
+                                                               const wfst_tr* __restrict__ arcs, const uint64_t* __restrict__ key,
+                                                               const uint32_t* __restrict__ rev_off,
+                                                               const uint4* __restrict__ rev_arc, Ctl* __restrict__ ctl,
+                                                               wfst_tr* __restrict__ out, uint32_t out_cap) {
+  __shared__ uint2 s_walk[WALK_LDS];
+  const uint32_t lane = threadIdx.x;
+  if (!ctl->has_path) return;
+  if (ctl->hops > out_cap) {  // the host falls back to the parent pass
+    if (lane == 0) ctl->pad |= 8u;
+    return;
+  }
+  uint32_t pad = 0;
+  const uint32_t k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, ctl->f_parent, out, out_cap, pad, s_walk);
+  if (lane == 0) {
+    if (pad) ctl->pad |= pad;
+    else ctl->hops = k;  // the real length of the walk
+  }
 }
 
 // The tail of a repeated query in ONE launch: arg-min over the final states (sssp_final_kernel), the header
@@ -595,12 +640,13 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
 __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict__ finals, const uint64_t* __restrict__ key,
                                                          uint32_t n, Ctl* __restrict__ ctl,
                                                          const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
-                                                         const uint2* __restrict__ wn, const uint32_t* __restrict__ rev_off,
-                                                         const uint2* __restrict__ rev_arc, wfst_tr* __restrict__ out,
+                                                         const uint32_t* __restrict__ rev_off,
+                                                         const uint4* __restrict__ rev_arc, wfst_tr* __restrict__ out,
                                                          uint32_t out_cap, TailOut* __restrict__ hout,
                                                          uint32_t* __restrict__ improved_ring, uint32_t adv_count,
                                                          uint32_t* __restrict__ host_ring) {
   __shared__ unsigned long long s_best[16];
+  __shared__ uint2 s_walk[WALK_LDS];
   __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
   if (adv_count && blockIdx.x == 0 && threadIdx.x < 64) {
@@ -664,46 +710,9 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   }
   const uint32_t fp = (uint32_t)best;
   const float final_weight = finals[fp], total = dec_f32((uint32_t)(best >> 32));
-  uint32_t cur = fp, k = 0;
+  uint32_t k = 0;
   if ((uint32_t)key[fp] > out_cap) pad |= 8u;  // the host falls back to the parent pass
-  while (!(pad & 12u)) {
-    const uint64_t kt = key[cur];
-    if ((uint32_t)kt == 0u) break;  // the start state
-    if (k >= out_cap) {
-      pad |= 8u;
-      break;
-    }
-    unsigned long long bp = ~0ull;
-    for (uint32_t j = rev_off[cur] + lane; j < rev_off[cur + 1]; j += 64) {
-      const uint2 ra = rev_arc[j];
-      const uint64_t ks = key[ra.x];
-      if (ks == KEY_INF) continue;
-      const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(wn[offsets[ra.x] + ra.y].x)) + 0.0f;
-      if (!(c < INF)) continue;
-      const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
-      const unsigned long long cls = parent_class(ck, ks, kt);
-      if (cls != PARENT_NONE) {
-        const unsigned long long cand = cls | ((unsigned long long)ra.x << 32) | ra.y;
-        bp = cand < bp ? cand : bp;
-      }
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-      const unsigned long long o = __shfl_xor(bp, d);
-      bp = o < bp ? o : bp;
-    }
-    if (bp == PARENT_NONE) {  // no admissible predecessor: reported, not followed
-      pad |= 4u;
-      break;
-    }
-    const uint32_t s = (uint32_t)(bp >> 32) & 0x7FFFFFFFu, pos = (uint32_t)bp;
-    if (lane == 0) {
-      wfst_tr tr = arcs[offsets[s] + pos];
-      tr.nextstate = k;
-      out[k] = tr;
-    }
-    cur = s;
-    ++k;
-  }
+  else k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, fp, out, out_cap, pad, s_walk);
   if (lane == 0) {
     ctl->has_path = 1;
     ctl->f_parent = fp;
@@ -1409,7 +1418,7 @@ const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
   auto r = std::make_shared<RevCsr>();
   DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
   r->off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
-  r->arc = DBuf<uint2>(owner_pool, f->n_arcs);
+  r->arc = DBuf<uint4>(owner_pool, f->n_arcs);
   DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
   HIP_CHECK(hipMemsetAsync(indeg.p, 0, (size_t)n * sizeof(uint32_t), st));
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
@@ -1465,7 +1474,7 @@ void queue_tail(wfst_sp_job* j, const SweepBatch* adv = nullptr) {
   Solve& sv = j->sv;
   if (j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL")) {  // one launch, header straight into pinned memory
     sssp_tail_kernel<<<std::min<uint32_t>(TAIL_BLOCKS, (n + 1023) / 1024), 1024, 0, st>>>(
-        f->dev.finals, sv.key.p, n, sv.ctl.p, f->dev.offsets, f->dev.arcs, f->dev.wn, j->rev->off.p, j->rev->arc.p, j->h_path,
+        f->dev.finals, sv.key.p, n, sv.ctl.p, f->dev.offsets, f->dev.arcs, j->rev->off.p, j->rev->arc.p, j->h_path,
         PATH_PINNED, j->h_tail, sv.improved.p, adv ? adv->count : 0u, adv ? j->drv.host_flags(*adv) : nullptr);
     j->fused_tail = true;
     return;
@@ -1476,7 +1485,7 @@ void queue_tail(wfst_sp_job* j, const SweepBatch* adv = nullptr) {
                                                                                                           n, sv.ctl.p);
   sssp_header_kernel<<<1, 1, 0, st>>>(f->dev.finals, sv.key.p, sv.ctl.p);
   if (j->rev)
-    sssp_backtrace_rev_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, f->dev.wn, sv.key.p, j->rev->off.p,
+    sssp_backtrace_rev_kernel<<<1, 64, 0, st>>>(f->dev.offsets, f->dev.arcs, sv.key.p, j->rev->off.p,
                                                 j->rev->arc.p, sv.ctl.p, j->h_path, PATH_PINNED);
   HIP_CHECK(hipMemcpyAsync(j->hc, sv.ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, st));
 }
