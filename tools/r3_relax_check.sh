@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 T0=$(date +%s)
 stamp() { echo "[t+$(( $(date +%s) - T0 ))s] $1"; }
-for cfg in "default" "WFST_SSSP_NARROW=0" "WFST_LIB_PATH=tools/bin/libwfst_amd_r2.so" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0"; do
+for cfg in "default" "WFST_SSSP_NARROW=0" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0"; do
   if [ "$cfg" = "default" ]; then e=""; else e="$cfg"; fi
   echo "== $cfg" >> $OUT/timing.txt
   env $e timeout 300 python tools/sp_repeat.py 1000000 30 >> $OUT/timing.txt 2>&1
