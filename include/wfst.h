@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 3 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_* */
+#define WFST_ABI_VERSION 3 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
 
