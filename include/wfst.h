@@ -133,7 +133,11 @@ wfst_status wfst_compose(wfst_ctx* ctx, const wfst_fst* fst1, const wfst_fst* fs
  *      relaxation + backtrace on the GPU; output = linear FST numbered backwards, state 0 final (:241-282).
  *      nshortest > 1, unique = false (:135-170): shortest_distance and reverse() on the GPU, the sequential
  *      n_shortest_path heap search (:409-518) + connect on the host; output = the reference's path tree.
- *      nshortest > 1 with unique = true (needs determinize) -> KO "unsupported". ---- */
+ *      nshortest > 1 with unique = true (:157-165): the reversed FST is determinized first (determinize_with_distance,
+ *      determinize/determinize_static.rs:24-39; host code, input must be an ACCEPTOR by its property word or the call is
+ *      KO "DeterminizeFsaImpl : expected acceptor as argument", as in the reference), then the same search: the n best
+ *      DISTINCT strings.  Where the reference keeps a weighted subset in HashMap order (unspecified, and part of a
+ *      state's identity there) this library keeps it in ascending state order. ---- */
 typedef struct {
   float delta;
   uint64_t nshortest;

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -55,6 +56,11 @@ inline float wtimes(float a, float b) {                          // times_assign
   return a + b;
 }
 inline bool wis_zero(float a) { return weq(a, INF); }  // semiring.rs:71-73
+// quantize — semirings/semiring.rs:132-145
+inline float quantize(float v, float delta) {
+  if (std::isinf(v)) return v;
+  return std::floor((v / delta) + 0.5f) * delta;
+}
 inline bool wis_one(float a) { return weq(a, 0.0f); }  // semiring.rs:68-70
 
 // ---------------------------------------------------------------- FstProperties (properties.rs:22-103)
@@ -1601,6 +1607,112 @@ bool shortest_path_n_impl(const Fst& ifst, size_t nshortest, float delta, Fst& o
   return true;
 }
 
+// ---------------------------------------------------------------- determinize_with_distance (the `unique` branch)
+// DeterminizeFsa<DefaultCommonDivisor> materialised by LazyFst::compute, with the distance of every new state to the final
+// states — determinize/determinize_static.rs:24-39, determinize_fsa_op.rs:43-196, state_table.rs:17-96,
+// lazy/lazy_fst.rs:226-269.  One deliberate choice: after merging the duplicates of a destination subset the reference
+// collects them from a std HashMap (determinize_fsa_op.rs:156-168), i.e. in an unspecified order that takes part in the
+// identity of the tuple (Vec equality, element.rs:20-23) — the same weighted subset may become several states there, and
+// which ones differs from run to run.  Here the elements stay in the order the sort above them left (ascending state id):
+// every weighted subset is one state.  Strings and their weights are the same either way.
+struct DetElt {
+  uint32_t state;
+  float w;
+};
+bool determinize_with_distance_impl(const Fst& ifst, const std::vector<float>& in_dist, float delta, Fst& dfst,
+                                    std::vector<float>& out_dist) {
+  dfst = Fst();
+  out_dist.clear();
+  if (!(ifst.properties & P::ACCEPTOR)) {  // determinize_fsa_op.rs:138-140
+    t_err = "DeterminizeFsaImpl : expected acceptor as argument";
+    return false;
+  }
+  std::vector<std::vector<DetElt>> tuples;  // DeterminizeStateTable: id <-> (subset, filter_state = start, always)
+  std::unordered_map<uint64_t, std::vector<uint32_t>> by_states;  // candidates with the same state ids
+  auto states_hash = [](const std::vector<DetElt>& t) {
+    uint64_t h = 1469598103934665603ull;
+    for (const DetElt& e : t) h = (h ^ e.state) * 1099511628211ull;
+    return h;
+  };
+  auto find_state = [&](const std::vector<DetElt>& t) -> uint32_t {  // state_table.rs:79-96
+    std::vector<uint32_t>& cand = by_states[states_hash(t)];
+    for (uint32_t id : cand) {
+      const std::vector<DetElt>& o = tuples[id];
+      bool same = o.size() == t.size();
+      for (size_t k = 0; same && k < t.size(); ++k) same = o[k].state == t[k].state && weq(o[k].w, t[k].w);
+      if (same) return id;
+    }
+    const uint32_t n = (uint32_t)tuples.size();
+    tuples.push_back(t);
+    cand.push_back(n);
+    float outd = INF;  // compute_distance, state_table.rs:25-39
+    for (const DetElt& e : t) outd = wplus(outd, wtimes(e.w, e.state < in_dist.size() ? in_dist[e.state] : INF));
+    out_dist.push_back(outd);
+    return n;
+  };
+  if (!ifst.has_start) return true;  // compute_start -> None: the empty FST (lazy_fst.rs:229-232)
+  find_state({DetElt{ifst.start, 0.0f}});  // determinize_fsa_op.rs:45-55
+  dfst.add_state();
+  dfst.set_start(0);
+  // lazy_fst.rs:235-259: ids are handed out in the order find_state first sees a tuple, and the queue pops them in that order
+  for (uint32_t s = 0; s < tuples.size(); ++s) {
+    std::map<uint32_t, std::vector<DetElt>> label_map;  // BTreeMap: ascending label (determinize_fsa_op.rs:59-84)
+    {
+      const std::vector<DetElt> src = tuples[s];
+      for (const DetElt& e : src)
+        for (const Tr& tr : ifst.states[e.state].trs) label_map[tr.ilabel].push_back(DetElt{tr.nextstate, wtimes(e.w, tr.weight)});
+    }
+    std::vector<Tr> trs;
+    for (auto& kv : label_map) {  // norm_tr, determinize_fsa_op.rs:149-179
+      std::vector<DetElt>& pairs = kv.second;
+      std::stable_sort(pairs.begin(), pairs.end(), [](const DetElt& a, const DetElt& b) { return a.state < b.state; });
+      float weight = INF;
+      for (const DetElt& e : pairs) weight = wplus(weight, e.w);  // DefaultCommonDivisor = plus (divisors.rs:17-21)
+      std::vector<DetElt> merged;
+      for (const DetElt& e : pairs) {
+        if (!merged.empty() && merged.back().state == e.state) merged.back().w = wplus(merged.back().w, e.w);
+        else merged.push_back(e);
+      }
+      for (DetElt& e : merged) e.w = quantize(e.w - weight, delta);  // divide (tropical_weight.rs:128-131), quantize
+      trs.push_back(Tr{kv.first, kv.first, weight, find_state(merged)});
+    }
+    while (dfst.states.size() < tuples.size()) dfst.add_state();
+    dfst.states[s].trs = trs;  // set_trs_unchecked: no per-arc property updates (lazy_fst.rs:255)
+    float fw = INF;  // compute_final_weight, determinize_fsa_op.rs:101-118
+    for (const DetElt& e : tuples[s]) {
+      const State& st = ifst.states[e.state];
+      fw = wplus(fw, wtimes(e.w, st.has_final ? st.final_w : INF));
+    }
+    if (!wis_zero(fw)) {
+      dfst.states[s].has_final = true;
+      dfst.states[s].final_w = fw;
+    }
+  }
+  dfst.properties = 0;  // DeterminizeFsaOp::properties(): empty (determinize_fsa_op.rs:120-123)
+  return true;
+}
+
+// shortest_path_with_config, nshortest > 1, unique = true — shortest_path.rs:135-170 (the else branch at :157-165)
+bool shortest_path_n_unique_impl(const Fst& ifst, size_t nshortest, float delta, Fst& out) {
+  std::vector<float> distance = shortest_distance_impl(ifst, delta);
+  Fst rfst;
+  reverse_impl(ifst, rfst);
+  float d = INF;
+  for (const Tr& rarc : rfst.states[0].trs) {
+    const uint32_t state = rarc.nextstate - 1;
+    if ((size_t)state < distance.size()) d = wplus(d, wtimes(rarc.weight, distance[state]));
+  }
+  std::vector<float> distance_2;
+  distance_2.reserve(distance.size() + 1);
+  distance_2.push_back(d);
+  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+  Fst dfst;
+  std::vector<float> distance_3;  // (TropicalWeight::ReverseWeight = TropicalWeight: the conversions are identities)
+  if (!determinize_with_distance_impl(rfst, distance_2, delta, dfst, distance_3)) return false;
+  n_shortest_path_impl(dfst, distance_3, nshortest, delta, out);
+  return true;
+}
+
 // ---------------------------------------------------------------- canonical (deterministic-tie) shortest path
 struct Canon {
   std::vector<float> d;
@@ -2411,11 +2523,6 @@ bool lookahead_fst(const LabelReachableData& data, uint32_t matcher_state, const
   return false;
 }
 
-// quantize — semirings/semiring.rs:132-145
-inline float quantize(float v, float delta) {
-  if (std::isinf(v)) return v;
-  return std::floor((v / delta) + 0.5f) * delta;
-}
 
 // filter state of PushLabels(PushWeights(LookAhead(AltSequence))):
 // PairFilterState<PairFilterState<IntegerFilterState, WeightFilterState>, IntegerFilterState>
@@ -3005,6 +3112,15 @@ int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta,
   }
   if (nshortest == 1) return oracle_shortest_path(f, eq_mode, out, nullptr, nullptr);
   if (!shortest_path_n_impl(*f, (size_t)nshortest, delta, *res)) return 1;
+  *out = res.release();
+  return 0;
+}
+
+int oracle_shortest_path_n_unique(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out) {
+  DeltaGuard g(eq_mode);
+  if (nshortest <= 1) return oracle_shortest_path_n(f, nshortest, delta, eq_mode, out);  // `unique` is not looked at
+  auto res = std::make_unique<oracle_fst>();
+  if (!shortest_path_n_unique_impl(*f, (size_t)nshortest, delta, *res)) return 1;
   *out = res.release();
   return 0;
 }

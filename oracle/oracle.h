@@ -19,10 +19,12 @@
  * OpenFST-generated goldens cannot be produced here (no rustc/cargo, no OpenFST,
  * no network), so parity AT SCALE is unpinned and rests on line-faithfulness
  * plus invariants (see tests/test_oracle.py).  UNPINNED restatements: the five
- * non-default compose filters (Null, Trivial, AltSequence, Match, NoMatch) and the
- * n > 1 shortest-path search — no reference output for them exists in the repository;
- * they are checked through invariants only (same best weight under every epsilon
- * filter, path membership, n = 1 agreement).  Look-ahead composition (row A12:
+ * non-default compose filters (Null, AltSequence, Match, NoMatch; Trivial is pinned on the
+ * reference's second K1 test, test_compose.py:84-154) and the n > 1 shortest-path search,
+ * with and without `unique` (determinize_with_distance) — no reference output for them
+ * exists in the repository; they are checked through invariants only (same best weight
+ * under every epsilon filter, path membership, n = 1 agreement, the n lightest paths /
+ * the n lightest DISTINCT strings against brute force).  Look-ahead composition (row A12:
  * LabelReachable, relabelling, LabelLookAheadMatcher, the PushLabels(PushWeights(
  * LookAhead(AltSequence))) filter stack as wired in rustfst-cli/src/cmds/compose.rs:77-181):
  * IntervalSet is pinned on the reference's unit tests (interval_set.rs:208-275), the rest
@@ -122,6 +124,8 @@ int oracle_shortest_path(const oracle_fst* f, int eq_mode, oracle_fst** out, flo
 /* shortest_path_with_config(nshortest = n, unique = false): shortest_path.rs:107-170,284-518
  * (shortest_distance.rs:153-237 + reverse.rs:33-87 + n_shortest_path heap search + connect). */
 int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out);
+/* the same with unique = true (shortest_path.rs:157-165: determinize_with_distance of the reversed FST first; acceptors only) */
+int oracle_shortest_path_n_unique(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out);
 /* shortest_distance_with_config(fst, reverse = false, delta): shortest_distance.rs:313-323.  Writes
  * min(cap, len) values (unreached = +inf beyond the reference's shorter vector); returns the reference length. */
 uint64_t oracle_shortest_distance(const oracle_fst* f, float delta, float* distance, uint64_t cap);

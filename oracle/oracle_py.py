@@ -85,6 +85,7 @@ def lib():
         L.oracle_shortest_path.argtypes = [vp, C.c_int, C.POINTER(vp), vp, C.POINTER(f32)]
         L.oracle_shortest_path_canonical.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(f32), C.POINTER(u32)]
         L.oracle_shortest_path_n.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
+        L.oracle_shortest_path_n_unique.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
         L.oracle_shortest_distance.argtypes = [vp, f32, vp, u64]
         L.oracle_shortest_distance.restype = u64
         L.oracle_reverse.argtypes = [vp, C.POINTER(vp)]
@@ -271,9 +272,10 @@ class OracleFst:
             res.distance = dist
         return res
 
-    def shortest_path_n(self, nshortest, delta=1e-6, eq_mode=EQ_REF_KDELTA):
+    def shortest_path_n(self, nshortest, delta=1e-6, eq_mode=EQ_REF_KDELTA, unique=False):
         out = C.c_void_p()
-        if lib().oracle_shortest_path_n(self._h, nshortest, delta, eq_mode, C.byref(out)):
+        fn = lib().oracle_shortest_path_n_unique if unique else lib().oracle_shortest_path_n
+        if fn(self._h, nshortest, delta, eq_mode, C.byref(out)):
             raise _err()
         return OracleFst(out.value)
 

@@ -307,9 +307,8 @@ wfst_status wfst_shortest_path(wfst_ctx* ctx, const wfst_fst* fst, const wfst_sh
       *out = shortest_path_n1(ctx, fst);
       return;
     }
-    if (c.unique)  // needs determinize_with_distance (shortest_path.rs:157-165): not on the GPU path
-      throw Error("unsupported: unique = true with nshortest > 1 is not implemented on the GPU path; use the CPU path");
-    *out = shortest_path_nbest(ctx, fst, c.nshortest, c.delta);
+    // unique: the reversed FST is determinized on the host first (shortest_path.rs:157-165); acceptors only, as there
+    *out = shortest_path_nbest(ctx, fst, c.nshortest, c.delta, c.unique != 0);
   });
 }
 
@@ -336,7 +335,7 @@ wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts,
         } else if (c.nshortest == 1) {
           outs[i] = shortest_path_n1(ctx, fsts[i]);
         } else {
-          throw Error("unsupported: unique = true with nshortest > 1 is not implemented on the GPU path; use the CPU path");
+          outs[i] = shortest_path_nbest(ctx, fsts[i], c.nshortest, c.delta, true);  // unique: one after the other
         }
       }
     } catch (...) {

@@ -264,7 +264,7 @@ void shortest_path_n1_abandon(wfst_sp_job* job);
 wfst_ctx* sp_job_ctx(wfst_sp_job* job);
 void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32_t* hops);
 // nshortest.hip
-wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta);
+wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta, bool unique = false);
 // nbest_batch.hip
 void shortest_path_nbest_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, uint64_t nshortest, float delta, wfst_fst** outs);
 wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f);

@@ -18,6 +18,7 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <cstdlib>
+#include <unordered_map>
 
 #include "common.h"
 #include "fst_props.h"
@@ -474,51 +475,13 @@ wfst_fst* reverse_fst(wfst_ctx* ctx, const wfst_fst* f) {
   return adopt_device(ctx, n + 1, (uint64_t)n_super + E, 0, p, off_out.p, arcs_out.p, fin_out.p);
 }
 
-wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta) {
-  OutFst ofst;
-  auto finish = [&]() {
-    HostCsr h;
-    h.offsets.push_back(0);
-    for (const OutFst::St& st : ofst.states) {
-      h.arcs.insert(h.arcs.end(), st.trs.begin(), st.trs.end());
-      h.offsets.push_back((uint32_t)h.arcs.size());
-      h.finals.push_back(st.has_final ? st.final_w : INF);
-    }
-    return make_host_fst(ctx, (uint32_t)ofst.states.size(), ofst.start, ofst.p, std::move(h));
-  };
-  const uint32_t n = f->n_states;
-  if (f->start < 0 || n == 0) return finish();  // shortest_distance -> [] ; istart check fails -> FO::new()
-  // 1. forward distances (GPU relaxation; exact fixed point == the reference's on grid weights)
-  const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
-  auto tnow = [] { return std::chrono::steady_clock::now(); };
-  auto t_0 = tnow();
-  std::vector<float> distance(n);
-  shortest_distance(ctx, f, distance.data(), nullptr);
-  auto t_1 = tnow();
-  // 2. reversed FST (GPU transpose, cached on the handle)
-  wfst_fst* mf = const_cast<wfst_fst*>(f);
-  std::shared_ptr<RevFst> rev_keep;
-  {
-    std::lock_guard<std::mutex> lk(f->cache_mu);
-    if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
-    rev_keep = mf->rev_host;
-  }
-  RevFst& r = *rev_keep;
-  std::vector<wfst_tr> scratch;
-  auto t_2 = tnow();
-  // 3. distance of the super-initial state (shortest_path.rs:143-153)
-  float d = INF;
-  for (const wfst_tr& a : r.super) {
-    const uint32_t state = a.nextstate - 1;
-    if (state < distance.size()) d = wplus(d, wtimes(a.weight, distance[state]));
-  }
-  std::vector<float> distance_2;
-  distance_2.reserve((size_t)n + 1);
-  distance_2.push_back(d);
-  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
-  // 4. n_shortest_path(rfst, distance_2, nshortest, delta)   shortest_path.rs:409-518
+// n_shortest_path (shortest_path.rs:409-518) over an FST given by two accessors (its start state is 0): the reversed input
+// (arcs fetched lazily from the GPU transpose), or its determinization (`unique`).  Leaves the un-trimmed tree in ofst.
+template <class ArcsOf, class FinalOf>
+void nbest_search(ArcsOf&& arcs_of, FinalOf&& final_of, const std::vector<float>& distance_2, uint64_t nshortest, float delta,
+                  OutFst& ofst) {
   const uint32_t istart = 0;  // rfst.start()
-  if (distance_2.size() <= istart || props::is_zero(distance_2[istart])) return finish();
+  if (distance_2.size() <= istart || props::is_zero(distance_2[istart])) return;
   const uint32_t ostart = ofst.add_state();
   ofst.set_start(ostart);
   const uint32_t final_state = ofst.add_state();
@@ -545,7 +508,7 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
     if (rcount[(size_t)p_first_real] > nshortest) continue;
     if (!p.some) continue;
     uint32_t n_in = 0;
-    const wfst_tr* in = rev_arcs_of(ctx, r, p.state, &n_in, scratch);
+    const wfst_tr* in = arcs_of(p.state, &n_in);
     for (uint32_t i = 0; i < n_in; ++i) {
       wfst_tr tr = in[i];
       const float weight = wtimes(p.w, tr.weight);
@@ -555,7 +518,7 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
       ofst.add_tr(next, tr);
       heap.push(next);
     }
-    const float fw = r.finals[p.state];
+    const float fw = final_of(p.state);
     if (fw != INF && !props::is_zero(fw)) {
       const float weight = wtimes(p.w, fw);
       const uint32_t next = ofst.add_state();
@@ -564,6 +527,161 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
       heap.push(next);
     }
   }
+}
+
+// determinize_with_distance (determinize/determinize_static.rs:24-39): DeterminizeFsa with the default common divisor
+// (determinize_fsa_op.rs:43-196) materialised in discovery order (lazy/lazy_fst.rs:226-269), with the distance of every
+// new state to the final states (state_table.rs:25-39,79-96).  Host code: the `unique` branch of shortest_path determinizes
+// the REVERSED input, a lattice in the decoding case; subsets are a handful of states.  After merging duplicate
+// destinations the reference collects a subset from a std HashMap — an order that is unspecified yet part of the tuple's
+// identity (the same weighted subset can become several states, differently from run to run); here a subset is kept in
+// ascending state order, so every weighted subset is one state.  Strings and weights are the same either way.
+struct DetElt {
+  uint32_t state;
+  float w;
+};
+inline float quantize(float v, float delta) {  // semirings/semiring.rs:132-145
+  if (std::isinf(v)) return v;
+  return std::floor((v / delta) + 0.5f) * delta;
+}
+void determinize_with_distance(const HostCsr& in, int64_t start, uint64_t in_props, const std::vector<float>& in_dist, float delta,
+                               HostCsr& out, std::vector<float>& out_dist) {
+  if (!(in_props & props::ACCEPTOR)) throw Error("DeterminizeFsaImpl : expected acceptor as argument");  // determinize_fsa_op.rs:138-140
+  out = HostCsr{};
+  out.offsets.push_back(0);
+  out_dist.clear();
+  if (start < 0) return;
+  std::vector<std::vector<DetElt>> tuples;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> by_states;  // tuples with the same state ids (weights compare by ==, KDELTA)
+  auto find_state = [&](const std::vector<DetElt>& t) -> uint32_t {
+    uint64_t h = 1469598103934665603ull;
+    for (const DetElt& e : t) h = (h ^ e.state) * 1099511628211ull;
+    std::vector<uint32_t>& cand = by_states[h];
+    for (uint32_t id : cand) {
+      const std::vector<DetElt>& o = tuples[id];
+      bool same = o.size() == t.size();
+      for (size_t k = 0; same && k < t.size(); ++k) same = o[k].state == t[k].state && weq(o[k].w, t[k].w);
+      if (same) return id;
+    }
+    const uint32_t id = (uint32_t)tuples.size();
+    if (id == 0xFFFFFFFFu) throw Error("determinize: too many states");
+    tuples.push_back(t);
+    cand.push_back(id);
+    float outd = INF;
+    for (const DetElt& e : t) outd = wplus(outd, wtimes(e.w, e.state < in_dist.size() ? in_dist[e.state] : INF));
+    out_dist.push_back(outd);
+    return id;
+  };
+  find_state({DetElt{(uint32_t)start, 0.0f}});
+  std::vector<std::pair<uint32_t, DetElt>> cand;  // (label, destination element) of the state being expanded
+  std::vector<DetElt> merged;
+  for (uint32_t s = 0; s < tuples.size(); ++s) {
+    cand.clear();
+    {
+      const std::vector<DetElt>& src = tuples[s];
+      for (const DetElt& e : src)
+        for (uint32_t k = in.offsets[e.state]; k < in.offsets[e.state + 1]; ++k)
+          cand.push_back({in.arcs[k].ilabel, DetElt{in.arcs[k].nextstate, wtimes(e.w, in.arcs[k].weight)}});
+    }
+    // ascending label (the BTreeMap), then ascending state (norm_tr's stable sort): one stable sort on (label, state)
+    std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) {
+      return a.first != b.first ? a.first < b.first : a.second.state < b.second.state;
+    });
+    float fw = INF;  // compute_final_weight (determinize_fsa_op.rs:101-118)
+    for (const DetElt& e : tuples[s]) fw = wplus(fw, wtimes(e.w, in.finals[e.state]));
+    for (size_t i = 0; i < cand.size();) {
+      size_t j = i;
+      float weight = INF;  // common divisor = plus over the label's candidates
+      while (j < cand.size() && cand[j].first == cand[i].first) weight = wplus(weight, cand[j++].second.w);
+      merged.clear();
+      for (size_t k = i; k < j; ++k) {
+        if (!merged.empty() && merged.back().state == cand[k].second.state) merged.back().w = wplus(merged.back().w, cand[k].second.w);
+        else merged.push_back(cand[k].second);
+      }
+      for (DetElt& e : merged) e.w = quantize(e.w - weight, delta);  // divide left (tropical_weight.rs:128-131), quantize
+      const uint32_t label = cand[i].first;
+      out.arcs.push_back(wfst_tr{label, label, weight, find_state(merged)});
+      i = j;
+    }
+    out.offsets.push_back((uint32_t)out.arcs.size());
+    out.finals.push_back(props::is_zero(fw) ? INF : fw);
+  }
+}
+
+wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta, bool unique) {
+  OutFst ofst;
+  auto finish = [&]() {
+    HostCsr h;
+    h.offsets.push_back(0);
+    for (const OutFst::St& st : ofst.states) {
+      h.arcs.insert(h.arcs.end(), st.trs.begin(), st.trs.end());
+      h.offsets.push_back((uint32_t)h.arcs.size());
+      h.finals.push_back(st.has_final ? st.final_w : INF);
+    }
+    return make_host_fst(ctx, (uint32_t)ofst.states.size(), ofst.start, ofst.p, std::move(h));
+  };
+  const uint32_t n = f->n_states;
+  if (f->start < 0 || n == 0) return finish();  // shortest_distance -> [] ; istart check fails -> FO::new()
+  // 1. forward distances (GPU relaxation; exact fixed point == the reference's on grid weights)
+  const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_0 = tnow();
+  std::vector<float> distance(n);
+  shortest_distance(ctx, f, distance.data(), nullptr);
+  auto t_1 = tnow();
+  if (unique) {
+    // shortest_path.rs:157-165: the reversed FST is determinized (with the distances to its final states) first, so that
+    // every string has ONE path; the search then runs on that acceptor.  Acceptors only, as in the reference.
+    std::unique_ptr<wfst_fst> rf(reverse_fst(ctx, f));
+    ensure_host(rf.get());
+    const HostCsr& rh = rf->host;
+    float d0 = INF;
+    for (uint32_t k = rh.offsets[0]; k < rh.offsets[1]; ++k) {
+      const uint32_t state = rh.arcs[k].nextstate - 1;
+      if (state < distance.size()) d0 = wplus(d0, wtimes(rh.arcs[k].weight, distance[state]));
+    }
+    std::vector<float> distance_2;
+    distance_2.reserve((size_t)n + 1);
+    distance_2.push_back(d0);
+    distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+    HostCsr dh;
+    std::vector<float> distance_3;
+    determinize_with_distance(rh, rf->start, rf->props, distance_2, delta, dh, distance_3);
+    nbest_search([&](uint32_t st, uint32_t* cnt) {
+                   *cnt = dh.offsets[st + 1] - dh.offsets[st];
+                   return dh.arcs.data() + dh.offsets[st];
+                 },
+                 [&](uint32_t st) { return dh.finals[st]; }, distance_3, nshortest, delta, ofst);
+    if (ofst.states.empty()) return finish();
+    ofst.connect();
+    ofst.p = props::shortest_path(ofst.p, false) & props::ALL;
+    return finish();
+  }
+  // 2. reversed FST (GPU transpose, cached on the handle)
+  wfst_fst* mf = const_cast<wfst_fst*>(f);
+  std::shared_ptr<RevFst> rev_keep;
+  {
+    std::lock_guard<std::mutex> lk(f->cache_mu);
+    if (!mf->rev_host) mf->rev_host = build_reverse(ctx, f);
+    rev_keep = mf->rev_host;
+  }
+  RevFst& r = *rev_keep;
+  std::vector<wfst_tr> scratch;
+  auto t_2 = tnow();
+  // 3. distance of the super-initial state (shortest_path.rs:143-153)
+  float d = INF;
+  for (const wfst_tr& a : r.super) {
+    const uint32_t state = a.nextstate - 1;
+    if (state < distance.size()) d = wplus(d, wtimes(a.weight, distance[state]));
+  }
+  std::vector<float> distance_2;
+  distance_2.reserve((size_t)n + 1);
+  distance_2.push_back(d);
+  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+  // 4. n_shortest_path(rfst, distance_2, nshortest, delta)   shortest_path.rs:409-518
+  nbest_search([&](uint32_t st, uint32_t* cnt) { return rev_arcs_of(ctx, r, st, cnt, scratch); },
+               [&](uint32_t st) { return r.finals[st]; }, distance_2, nshortest, delta, ofst);
+  if (ofst.states.empty()) return finish();
   auto t_3 = tnow();
   if (timing) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

@@ -110,8 +110,10 @@ def test_error_behaviour(gpu_ctx):
     b.add_tr(0, Tr(2, 1, 0.0, 1))
     with pytest.raises(rustfst_amd.WfstError, match=r"sort\?"):  # compose_fst_op.rs:194
         a.compose(b)
-    with pytest.raises(rustfst_amd.WfstError, match="unsupported"):
-        rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=3, unique=True))
+    with pytest.raises(rustfst_amd.WfstError, match="expected acceptor"):  # determinize_fsa_op.rs:138-140
+        b.shortest_path(ShortestPathConfig(nshortest=3, unique=True))
+    one = rustfst_amd.acceptor([1])  # a single string: `unique` changes nothing
+    assert one.shortest_path(ShortestPathConfig(nshortest=3, unique=True)).num_states() == one.shortest_path(ShortestPathConfig(nshortest=3)).num_states()
     assert rustfst_amd.acceptor([1]).shortest_path(ShortestPathConfig(nshortest=0)).num_states() == 0
     # invalid CSR is rejected at the boundary, not on the device
     with pytest.raises(rustfst_amd.WfstError, match="nextstate"):
@@ -678,6 +680,26 @@ def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
         exp = to_oracle(oracle, flat).shortest_path_n(n).to_flat()
         got = to_device(flat).shortest_path(ShortestPathConfig(nshortest=n)).to_flat()
         assert_flat_identical(got, exp, f"seed {seed} n={n}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nshortest_unique_vs_oracle(gpu_ctx, oracle, seed):
+    """nshortest > 1 with unique = true (shortest_path.rs:157-165): distances and reverse() on the GPU, determinization of the
+    reversed acceptor and the search on the host — bit-identical to the oracle's restatement of that branch (both keep a
+    weighted subset in ascending state order where the reference's order is unspecified), single call and batch call."""
+    rng = np.random.default_rng(4300 + seed)
+    flat = random_fst_flat(rng, int(rng.integers(3, 40)), 4, 2 + seed % 3, p_eps_i=0.1 * (seed % 2), p_final=0.3, min_fanout=1,
+                           acyclic=True, weight_grid=4 if seed % 2 else 512, max_w=12 if seed % 2 else 2560, sort="none")
+    flat["arcs"]["olabel"] = flat["arcs"]["ilabel"]
+    flat["props"] = 0x0000_0000_0001_0000  # ACCEPTOR
+    d, o = to_device(flat), to_oracle(oracle, flat)
+    for n in (2, 5, 20):
+        exp = o.shortest_path_n(n, unique=True).to_flat()
+        got = d.shortest_path(ShortestPathConfig(nshortest=n, unique=True)).to_flat()
+        assert_flat_identical(got, exp, f"unique, seed {seed} n={n}")
+    outs = rustfst_amd.shortest_path_batch([d, d], ShortestPathConfig(nshortest=5, unique=True))
+    for out in outs:
+        assert_flat_identical(out.to_flat(), o.shortest_path_n(5, unique=True).to_flat(), f"unique batch, seed {seed}")
 
 
 @pytest.mark.parametrize("device", ["1", "0", "tiny_tree"])

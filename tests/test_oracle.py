@@ -310,6 +310,67 @@ def test_nshortest_weights_are_the_n_smallest(oracle, seed):
         np.testing.assert_allclose(got, exp, atol=1e-5)
 
 
+def acceptor_flat(rng, n_states, max_fanout, sigma, **kw):
+    """random_fst_flat with olabel = ilabel and the ACCEPTOR property bit (what `unique` asks for)."""
+    flat = random_fst_flat(rng, n_states, max_fanout, sigma, sort="none", **kw)
+    flat["arcs"]["olabel"] = flat["arcs"]["ilabel"]
+    flat["props"] = 0x0000_0000_0001_0000  # ACCEPTOR; sortedness left unknown
+    return flat
+
+
+def all_strings(flat, max_len=64):
+    """{label string: least weight} over all successful paths of a small acyclic acceptor (epsilons dropped)."""
+    best = {}
+    off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
+
+    def rec(s, labs, acc, depth):
+        if np.isfinite(fin[s]):
+            w = float(np.float32(acc + fin[s]))
+            if labs not in best or w < best[labs]:
+                best[labs] = w
+        if depth == max_len:
+            return
+        for a in arcs[off[s]:off[s + 1]]:
+            rec(int(a["nextstate"]), labs + ((int(a["ilabel"]),) if a["ilabel"] else ()), np.float32(acc + a["weight"]), depth + 1)
+
+    if flat["start"] is not None:
+        rec(flat["start"], (), np.float32(0.0), 0)
+    return best
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_nshortest_unique_gives_the_n_best_distinct_strings(oracle, seed):
+    """unique = true (shortest_path.rs:157-165: determinize_with_distance of the reversed FST, then the same search).  Unpinned
+    by reference output (its goldens need OpenFST), so checked through what the branch is for: every string of the result
+    appears once, with the least weight any of its paths has in the input, and the n strings are the n lightest."""
+    rng = np.random.default_rng(4200 + seed)
+    flat = acceptor_flat(rng, int(rng.integers(3, 10)), 4, 2 + seed % 2, p_final=0.4, acyclic=True, min_fanout=1,
+                         weight_grid=4, max_w=12)  # few labels, coarse weights: many paths share a string
+    f = to_oracle(oracle, flat)
+    truth = all_strings(flat)
+    ranked = sorted(truth.values())
+    for n in (2, 3, 6, 50):
+        out = f.shortest_path_n(n, unique=True).to_flat()
+        got = all_strings(out)
+        n_paths = len(all_path_weights(out, max_len=64))
+        assert n_paths == len(got) == min(n, len(truth)), (n, n_paths, len(got), len(truth))  # one path per string
+        for labs, w in got.items():
+            assert labs in truth and abs(truth[labs] - w) < 1e-4, (labs, w, truth.get(labs))
+        np.testing.assert_allclose(sorted(got.values()), ranked[:len(got)], atol=1e-4)
+    # without `unique` the same input returns strings more than once (that is what the flag is for)
+    if len(all_path_weights(flat)) > len(truth):
+        many = f.shortest_path_n(50).to_flat()
+        assert len(all_path_weights(many, max_len=64)) > len(all_strings(many))
+
+
+def test_nshortest_unique_needs_an_acceptor(oracle):
+    rng = np.random.default_rng(5)
+    flat = random_fst_flat(rng, 6, 3, 3, p_final=0.5, acyclic=True, min_fanout=1)  # a transducer: no ACCEPTOR bit
+    with pytest.raises(Exception, match="expected acceptor"):  # determinize_fsa_op.rs:138-140
+        to_oracle(oracle, flat).shortest_path_n(3, unique=True)
+    assert to_oracle(oracle, flat).shortest_path_n(1, unique=True).num_states >= 0  # nshortest == 1: `unique` is not looked at
+
+
 def test_shortest_distance_and_reverse(oracle):
     rng = np.random.default_rng(31)
     flat = random_fst_flat(rng, 40, 4, 5, p_final=0.2, min_fanout=1)
