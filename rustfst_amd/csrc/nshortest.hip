@@ -552,6 +552,7 @@ void determinize_with_distance(const HostCsr& in, int64_t start, uint64_t in_pro
   out_dist.clear();
   if (start < 0) return;
   std::vector<std::vector<DetElt>> tuples;
+  uint64_t n_elts = 0;
   std::unordered_map<uint64_t, std::vector<uint32_t>> by_states;  // tuples with the same state ids (weights compare by ==, KDELTA)
   auto find_state = [&](const std::vector<DetElt>& t) -> uint32_t {
     uint64_t h = 1469598103934665603ull;
@@ -564,7 +565,10 @@ void determinize_with_distance(const HostCsr& in, int64_t start, uint64_t in_pro
       if (same) return id;
     }
     const uint32_t id = (uint32_t)tuples.size();
-    if (id == 0xFFFFFFFFu) throw Error("determinize: too many states");
+    // (a cyclic weighted acceptor without the twins property has no finite determinization: the reference runs out of
+    // memory on it; this library stops at 16 M states / 256 M subset elements)
+    n_elts += t.size();
+    if (id >= (1u << 24) || n_elts > (1ull << 28)) throw Error("determinize: more than 16 M states (the input does not determinize?)");
     tuples.push_back(t);
     cand.push_back(id);
     float outd = INF;
