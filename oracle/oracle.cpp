@@ -3116,6 +3116,17 @@ int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta,
   return 0;
 }
 
+// determinize_fsa::<DefaultCommonDivisor> (determinize_static.rs:41-53), what `determinize` does to an acceptor
+// (:176-181) before it sets the property word (not restated: the reference's tests compare states and start only)
+int oracle_determinize_fsa(const oracle_fst* f, float delta, int eq_mode, oracle_fst** out) {
+  DeltaGuard g(eq_mode);
+  auto res = std::make_unique<oracle_fst>();
+  std::vector<float> no_dist, out_dist;
+  if (!determinize_with_distance_impl(*f, no_dist, delta, *res, out_dist)) return 1;
+  *out = res.release();
+  return 0;
+}
+
 int oracle_shortest_path_n_unique(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out) {
   DeltaGuard g(eq_mode);
   if (nshortest <= 1) return oracle_shortest_path_n(f, nshortest, delta, eq_mode, out);  // `unique` is not looked at

@@ -21,8 +21,8 @@
  * plus invariants (see tests/test_oracle.py).  UNPINNED restatements: the five
  * non-default compose filters (Null, AltSequence, Match, NoMatch; Trivial is pinned on the
  * reference's second K1 test, test_compose.py:84-154) and the n > 1 shortest-path search,
- * with and without `unique` (determinize_with_distance) — no reference output for them
- * exists in the repository; they are checked through invariants only (same best weight
+ * with and without `unique` — no reference output for them exists in the repository (the
+ * determinization the `unique` branch rests on IS pinned: determinize_static.rs:210-270, K12); they are checked through invariants only (same best weight
  * under every epsilon filter, path membership, n = 1 agreement, the n lightest paths /
  * the n lightest DISTINCT strings against brute force).  Look-ahead composition (row A12:
  * LabelReachable, relabelling, LabelLookAheadMatcher, the PushLabels(PushWeights(
@@ -125,6 +125,8 @@ int oracle_shortest_path(const oracle_fst* f, int eq_mode, oracle_fst** out, flo
  * (shortest_distance.rs:153-237 + reverse.rs:33-87 + n_shortest_path heap search + connect). */
 int oracle_shortest_path_n(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out);
 /* the same with unique = true (shortest_path.rs:157-165: determinize_with_distance of the reversed FST first; acceptors only) */
+/* determinize_fsa with the default common divisor (determinize_static.rs:41-53): acceptors only */
+int oracle_determinize_fsa(const oracle_fst* f, float delta, int eq_mode, oracle_fst** out);
 int oracle_shortest_path_n_unique(const oracle_fst* f, uint64_t nshortest, float delta, int eq_mode, oracle_fst** out);
 /* shortest_distance_with_config(fst, reverse = false, delta): shortest_distance.rs:313-323.  Writes
  * min(cap, len) values (unreached = +inf beyond the reference's shorter vector); returns the reference length. */

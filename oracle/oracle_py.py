@@ -86,6 +86,7 @@ def lib():
         L.oracle_shortest_path_canonical.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(f32), C.POINTER(u32)]
         L.oracle_shortest_path_n.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
         L.oracle_shortest_path_n_unique.argtypes = [vp, u64, f32, C.c_int, C.POINTER(vp)]
+        L.oracle_determinize_fsa.argtypes = [vp, f32, C.c_int, C.POINTER(vp)]
         L.oracle_shortest_distance.argtypes = [vp, f32, vp, u64]
         L.oracle_shortest_distance.restype = u64
         L.oracle_reverse.argtypes = [vp, C.POINTER(vp)]
@@ -276,6 +277,13 @@ class OracleFst:
         out = C.c_void_p()
         fn = lib().oracle_shortest_path_n_unique if unique else lib().oracle_shortest_path_n
         if fn(self._h, nshortest, delta, eq_mode, C.byref(out)):
+            raise _err()
+        return OracleFst(out.value)
+
+    def determinize_fsa(self, delta=1.0 / 1024.0, eq_mode=EQ_REF_KDELTA):
+        """determinize() of an acceptor (DeterminizeConfig::default(): delta = KDELTA)."""
+        out = C.c_void_p()
+        if lib().oracle_determinize_fsa(self._h, delta, eq_mode, C.byref(out)):
             raise _err()
         return OracleFst(out.value)
 

@@ -77,6 +77,15 @@ def test_k2_shortest_path_known_answer(oracle):
     assert spc.n_tied_choices == 0
 
 
+# ---------------------------------------------------------------- K12: determinize_static.rs:210-270
+def test_k12_determinize_known_answers(oracle):
+    """The reference's two known answers for `determinize` of a tropical acceptor (DeterminizeFsa, default common divisor,
+    delta = KDELTA): the determinization that the `unique` branch of shortest_path rests on (shortest_path.rs:157-165)."""
+    g = load_golden("k12_determinize.json")
+    for case in g["cases"]:
+        flat_matches_spec(build(oracle, case["fst"]).determinize_fsa().to_flat(), case["expected"])
+
+
 # ---------------------------------------------------------------- K3: doctest compose_static.rs:282-289
 def test_k3_linear_compose(oracle):
     a = oracle.OracleFst()
