@@ -437,7 +437,7 @@ def test_config3_512_acceptors_and_one_long_string_against_1m_states(gpu_ctx, or
     assert_flat_identical(one[0].to_flat(), can, "fused A(1000) o T(1M)")
 
 
-def test_config5_lookahead_compose_and_nbest_at_scale():
+def test_config5_lookahead_compose_and_nbest_at_scale_invariants_only():
     """BASELINE configs[4] end to end (tools/config5_lookahead.py): the 5M-state / 50M-arc HCLG-shaped FST with 5 %
     epsilons as the look-ahead operand (reachability data built once), 64 linear acceptors of 200 labels — relabel,
     look-ahead composition (one by one and as ONE batch), n = 10 shortest paths of every result.  Checked without an
