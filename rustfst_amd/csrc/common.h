@@ -252,6 +252,17 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
 // adopt freshly produced device arrays (compose output) as a new FST; arrays are copied into one arena
 wfst_fst* adopt_device(wfst_ctx* ctx, uint32_t n_states, uint64_t n_arcs, int64_t start, uint64_t props,
                        const uint32_t* d_offsets, const wfst_tr* d_arcs, const float* d_finals);
+// ... of the m results of one batch in one allocation and one synchronisation (fst_store.hip)
+struct AdoptDesc {
+  uint32_t n_states;
+  uint64_t n_arcs;
+  int64_t start;
+  uint64_t props;
+  const uint32_t* off;
+  const wfst_tr* arcs;
+  const float* fin;
+};
+void adopt_device_many(wfst_ctx* ctx, size_t m, const AdoptDesc* descs, wfst_fst** outs);
 // openfst_io.cpp
 wfst_fst* fst_from_openfst_bytes(wfst_ctx* ctx, const uint8_t* data, size_t len);
 void fst_to_openfst_bytes(const wfst_fst* f, std::vector<uint8_t>& out);

@@ -650,6 +650,8 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
       std::vector<LaResult> res(m);
       HIP_CHECK(hipMemcpyAsync(res.data(), d_res.p, m * sizeof(LaResult), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<AdoptDesc> ok;
+      std::vector<size_t> ok_i;
       for (size_t k = 0; k < m; ++k) {
         const size_t i = todo[k];
         const LaResult& r = res[k];
@@ -658,10 +660,16 @@ void compose_lookahead_batch(wfst_ctx* ctx, const wfst_lookahead* la, const wfst
           continue;
         }
         const LaArena ar = la_carve(arena.p + k * stride, caps, nullptr);
-        done[i].reset(adopt_device(ctx, r.n_states, r.n_arcs, r.n_states ? 0 : -1,
-                                   lookahead_result_props(f1->props, fst2s[i]->props, true), ar.off, ar.arcs, ar.fin));
+        ok.push_back(AdoptDesc{r.n_states, r.n_arcs, r.n_states ? 0 : -1, lookahead_result_props(f1->props, fst2s[i]->props, true),
+                               ar.off, ar.arcs, ar.fin});
+        ok_i.push_back(i);
         ctx->stats.compose_states = r.n_states;
         ctx->stats.compose_arcs = r.n_arcs;
+      }
+      if (!ok.empty()) {  // the finished results leave the problem arenas together (one allocation, one synchronisation)
+        std::vector<wfst_fst*> made(ok.size(), nullptr);
+        adopt_device_many(ctx, ok.size(), ok.data(), made.data());
+        for (size_t q = 0; q < ok.size(); ++q) done[ok_i[q]].reset(made[q]);
       }
     } else {
       for (size_t k = 0; k < todo.size(); ++k) redo.push_back(k);

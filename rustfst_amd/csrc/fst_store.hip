@@ -302,6 +302,19 @@ static wfst_fst* upload_generic(wfst_ctx* ctx, uint32_t n_states, int64_t start,
   return f.release();
 }
 
+// A small FST uploaded from host arrays keeps them as its host mirror: host-side steps on it (the look-ahead relabelling
+// of an acceptor, packing, downloads) then cost no device read-back and no synchronisation.  (In-place device operations
+// drop the mirror: project_device, tr_sort_device.)
+static void keep_small_host_copy(wfst_fst* f, const uint32_t* offsets, const wfst_tr* arcs, const float* finals) {
+  constexpr uint64_t SMALL_ARCS = 4096;
+  if (f->n_arcs > SMALL_ARCS || f->n_states > SMALL_ARCS) return;
+  if (f->n_states) f->host.offsets.assign(offsets, offsets + f->n_states + 1);
+  else f->host.offsets.assign(1, 0u);
+  if (f->n_arcs) f->host.arcs.assign(arcs, arcs + f->n_arcs);
+  if (f->n_states) f->host.finals.assign(finals, finals + f->n_states);
+  f->has_host = true;
+}
+
 wfst_fst* upload_from_host(wfst_ctx* ctx, uint32_t n_states, int64_t start, const uint32_t* offsets, const wfst_tr* arcs,
                            const float* finals, uint64_t props) {
   uint64_t n_arcs = n_states ? offsets[n_states] : 0;
@@ -309,6 +322,7 @@ wfst_fst* upload_from_host(wfst_ctx* ctx, uint32_t n_states, int64_t start, cons
   if (n_arcs && !arcs) throw Error("null arcs array");
   wfst_fst* f = upload_generic(ctx, n_states, start, offsets, arcs, finals, props, hipMemcpyHostToDevice, n_arcs);
   f->is_string = n_states <= 65536 && detect_string(n_states, start, offsets, arcs, finals);
+  keep_small_host_copy(f, offsets, arcs, finals);
   return f;
 }
 
@@ -326,6 +340,102 @@ wfst_fst* upload_from_device(wfst_ctx* ctx, uint32_t n_states, int64_t start, co
 wfst_fst* adopt_device(wfst_ctx* ctx, uint32_t n_states, uint64_t n_arcs, int64_t start, uint64_t props,
                        const uint32_t* d_offsets, const wfst_tr* d_arcs, const float* d_finals) {
   return upload_generic(ctx, n_states, start, d_offsets, d_arcs, d_finals, props, hipMemcpyDeviceToDevice, n_arcs);
+}
+
+namespace {
+struct AdoptJob {
+  const uint32_t* off;
+  const wfst_tr* arcs;
+  const float* fin;
+  uint32_t* d_off;
+  wfst_tr* d_arcs;
+  float* d_fin;
+  uint32_t n_states, n_arcs;
+};
+// block k copies result k (offsets, finals, arcs) out of its problem arena into the batch's shared allocation
+__global__ void __launch_bounds__(256) adopt_gather_kernel(const AdoptJob* __restrict__ jobs) {
+  const AdoptJob j = jobs[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i <= j.n_states; i += 256) j.d_off[i] = j.n_states ? j.off[i] : 0u;
+  for (uint32_t i = threadIdx.x; i < j.n_states; i += 256) j.d_fin[i] = j.fin[i];
+  const uint4* src = reinterpret_cast<const uint4*>(j.arcs);
+  uint4* dst = reinterpret_cast<uint4*>(j.d_arcs);
+  for (uint32_t i = threadIdx.x; i < j.n_arcs; i += 256) dst[i] = src[i];
+}
+}  // namespace
+
+// adopt_device for the m results of one batch: ONE allocation, one gather launch, the derive kernels queued without a
+// host round trip in between, ONE synchronisation (per result adopt_device costs ~40 us: three copy commands, two small
+// kernels and a read-back of the weight statistics each).
+void adopt_device_many(wfst_ctx* ctx, size_t m, const AdoptDesc* descs, wfst_fst** outs) {
+  if (m == 0) return;
+  HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  size_t tot_states = 0, tot_arcs = 0;
+  std::vector<size_t> state_base(m), arc_base(m);
+  for (size_t i = 0; i < m; ++i) {
+    check_header(descs[i].n_states, descs[i].start);
+    if (descs[i].n_arcs >= 0xFFFFFFFFull) throw Error("adopt_device_many: a result with 2^32 arcs");
+    state_base[i] = tot_states;
+    arc_base[i] = tot_arcs;
+    tot_states += descs[i].n_states;
+    tot_arcs += descs[i].n_arcs;
+  }
+  Layout l = make_layout(tot_states + m, tot_states, tot_arcs);
+  auto arena = make_arena(ctx, l.total);
+  DeviceCsr all = carve(arena, l);
+  std::vector<AdoptJob> jobs(m);
+  for (size_t i = 0; i < m; ++i)
+    jobs[i] = AdoptJob{descs[i].off, descs[i].arcs, descs[i].fin, const_cast<uint32_t*>(all.offsets) + state_base[i] + i,
+                       const_cast<wfst_tr*>(all.arcs) + arc_base[i], const_cast<float*>(all.finals) + state_base[i],
+                       descs[i].n_states, (uint32_t)descs[i].n_arcs};
+  DBuf<AdoptJob> d_jobs(*ctx->pool, m);
+  DBuf<uint32_t> err(*ctx->pool, 1);
+  DBuf<WeightStats> ws(*ctx->pool, m);
+  HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), m * sizeof(AdoptJob), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(err.p, 0, sizeof(uint32_t), st));
+  HIP_CHECK(hipMemsetAsync(ws.p, 0, m * sizeof(WeightStats), st));
+  adopt_gather_kernel<<<(uint32_t)m, 256, 0, st>>>(d_jobs.p);
+  for (size_t i = 0; i < m; ++i) {
+    const uint32_t ns = descs[i].n_states;
+    const uint64_t na = descs[i].n_arcs;
+    if (na)
+      derive_wn_kernel<<<(int)std::min<uint64_t>((na + 255) / 256, 64), 256, 0, st>>>(all.arcs + arc_base[i],
+                                                                                         const_cast<uint2*>(all.wn) + arc_base[i], na, ns,
+                                                                                         err.p, ws.p + i);
+    if (ns)
+      derive_noeps_kernel<<<(ns + 255) / 256, 256, 0, st>>>(all.offsets + state_base[i] + i, all.arcs + arc_base[i],
+                                                            all.finals + state_base[i], const_cast<uint32_t*>(all.noeps) + state_base[i],
+                                                            const_cast<uint4*>(all.srec) + state_base[i], ns, err.p);
+  }
+  HIP_CHECK(hipGetLastError());
+  std::vector<WeightStats> hws(m);
+  uint32_t herr = 0;
+  HIP_CHECK(hipMemcpyAsync(&herr, err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(hws.data(), ws.p, m * sizeof(WeightStats), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));  // (also: jobs / the sources may go now)
+  if (herr & 1u) throw Error("invalid FST: an arc's nextstate is >= num_states");
+  if (herr & 2u) throw Error("invalid FST: offsets are not non-decreasing");
+  for (size_t i = 0; i < m; ++i) {
+    auto f = std::make_unique<wfst_fst>();
+    f->mean_weight = hws[i].count ? (float)(hws[i].sum / (double)hws[i].count) : 0.0f;
+    f->has_negative = hws[i].negative != 0;
+    f->ctx = ctx;
+    f->owner_pool = ctx->pool;
+    f->device = ctx->device;
+    f->n_states = descs[i].n_states;
+    f->n_arcs = descs[i].n_arcs;
+    f->start = descs[i].start;
+    f->props = descs[i].props & props::ALL;
+    f->dev.arena = arena;
+    f->dev.offsets = all.offsets + state_base[i] + i;
+    f->dev.arcs = all.arcs + arc_base[i];
+    f->dev.finals = all.finals + state_base[i];
+    f->dev.noeps = all.noeps + state_base[i];
+    f->dev.wn = all.wn + arc_base[i];
+    f->dev.srec = all.srec + state_base[i];
+    f->has_dev = true;
+    outs[i] = f.release();
+  }
 }
 
 void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_t* starts, const uint32_t* offsets_cat,
@@ -400,6 +510,7 @@ void upload_many(wfst_ctx* ctx, size_t n, const uint32_t* n_states, const int64_
     f->has_dev = true;
     f->is_string = n_states[i] <= 65536 && detect_string(n_states[i], starts[i], offsets_cat + state_base[i] + i,
                                                          arcs_cat + arc_base[i], finals_cat + state_base[i]);
+    keep_small_host_copy(f.get(), offsets_cat + state_base[i] + i, arcs_cat + arc_base[i], finals_cat + state_base[i]);
     outs[i] = f.release();
   }
 }
