@@ -281,8 +281,9 @@ wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
 
 /* shortest_path_with_config (shortest_path.rs:76-171) of n FSTs in one call; outs[i] = a new handle each.  With nshortest > 1
  * (unique = false) small inputs — the composed lattices of a decoding batch: BASELINE configs[4] — are searched by ONE
- * launch, one wavefront per input (distances, reverse, the reference's heap search, connect); larger ones, and
- * nshortest == 1, go through the single-FST paths one after the other.  Same results as n calls of wfst_shortest_path. */
+ * launch, one wavefront per input (distances, reverse, the reference's heap search, connect); with nshortest == 1 small
+ * inputs (<= 4096 states) are likewise solved by one launch (keys in LDS, the canonical predecessor rule, the walk); larger
+ * ones go through the single-FST paths one after the other.  Same results as n calls of wfst_shortest_path. */
 wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, const wfst_shortest_path_config* cfg,
                                      wfst_fst** outs);
 

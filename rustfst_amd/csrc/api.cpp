@@ -327,6 +327,10 @@ wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts,
         shortest_path_nbest_batch(ctx, fsts, n, c.nshortest, c.delta, outs);
         return;
       }
+      if (c.nshortest == 1) {  // small inputs in one launch (one wavefront each), the others one after the other
+        shortest_path_n1_batch(ctx, fsts, n, outs);
+        return;
+      }
       for (size_t i = 0; i < n; ++i) {
         if (c.nshortest == 0) {
           HostCsr h;

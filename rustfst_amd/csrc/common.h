@@ -302,6 +302,10 @@ void compose_shortest_path_batch_end(wfst_batch_job* job, wfst_fst** outs, uint6
 // one record of wfst_fst_pack_paths: [n_arcs, final-weight bits, valid, 0] + max_arcs arcs, zero padded
 void pack_path_record(uint32_t* rec, uint32_t max_arcs, bool valid, uint32_t n_arcs, float final_weight, const wfst_tr* arcs);
 void pack_path_record(uint32_t* rec, uint32_t max_arcs, const wfst_fst* path);
+wfst_fst* make_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final_weight, const wfst_tr* path_arcs);  // fst_store.hip
+// nbest_batch.hip: nshortest == 1 for many small FSTs in one launch (one wavefront each); the others one after the other
+void shortest_path_n1_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, wfst_fst** outs, bool lone = false);
+bool shortest_path_n1_tiny(wfst_ctx* ctx, const wfst_fst* f, wfst_fst** out);  // a lone tiny FST: one wavefront (false: not applicable)
 void compose_shortest_path_batch_abandon(wfst_batch_job* job);
 wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 // compose_wide.hip

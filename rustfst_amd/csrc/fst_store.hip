@@ -567,6 +567,27 @@ void ensure_device(wfst_fst* f) {
   f->has_dev = true;
 }
 
+// The reference's linear shortest-path FST (single_shortest_path_backtrace, shortest_path.rs:241-282) from the walk's arcs:
+// hops + 1 states numbered backwards (state 0 final, start = hops), arc k enters state k; no path = the empty FST.
+wfst_fst* make_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final_weight, const wfst_tr* path_arcs) {
+  HostCsr h;
+  uint32_t n_states = 0;
+  int64_t start = -1;
+  if (has_path) {
+    n_states = hops + 1;
+    h.finals.assign(n_states, INF);
+    h.finals[0] = final_weight;
+    if (hops) h.arcs.assign(path_arcs, path_arcs + hops);
+    h.offsets.resize((size_t)n_states + 1);
+    h.offsets[0] = 0;
+    for (uint32_t k = 0; k <= hops; ++k) h.offsets[k + 1] = k;  // state 0 has no arc, state k >= 1 one
+    start = hops;
+  } else {
+    h.offsets.push_back(0);
+  }
+  return make_host_fst(ctx, n_states, start, props::linear_path_props(has_path, hops, final_weight, path_arcs), std::move(h));
+}
+
 void pack_path_record(uint32_t* rec, uint32_t max_arcs, bool valid, uint32_t n_arcs, float final_weight, const wfst_tr* arcs) {
   if (valid && n_arcs > max_arcs) throw Error("wfst_fst_pack_paths: path longer than the record");
   const float w = valid ? final_weight : INF;

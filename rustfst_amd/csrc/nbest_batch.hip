@@ -469,4 +469,258 @@ void shortest_path_nbest_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_
     if (!outs[i]) outs[i] = shortest_path_nbest(ctx, fsts[i], nshortest, delta);
 }
 
+namespace {
+
+// ---------------------------------------------------------------- nshortest == 1 for many small FSTs
+// single_shortest_path + backtrace (shortest_path.rs:173-282) of one small FST per wavefront, everything in one launch:
+//   keys      (distance, hops) of every state in LDS, relaxed to the least fixed point (the canonical rule of sssp.hip:
+//             among equal distances the fewer arcs) by label-correcting rounds over the arcs;
+//   final     arg-min of d[s] (x) rho(s) over the final states, ties to the smaller state id;
+//   parents   one pass over the arcs: the predecessor sssp_parent_kernel would select for every state (class, source,
+//             position), kept in LDS next to the keys;
+//   walk      one lane follows the parents from the final state; the arcs of the walk go to pinned memory in the order
+//             build_path_fst expects (arc k enters the k-th created state).
+// The result is what shortest_path_n1 returns for the same FST, bit for bit.  A lone solve through the relaxation kernels
+// costs ~0.5 ms whatever the size (a dozen launches and three synchronisations): 64 composed lattices one after the
+// other were 36 ms; here they are one launch.
+constexpr uint32_t SP1_MAX_STATES = 4096;
+constexpr unsigned long long SP1_KEY_INF = ~0ull;
+constexpr unsigned long long SP1_PARENT_NONE = ~0ull;
+struct Sp1Out {
+  uint32_t has_path, hops, status, pad;
+  float final_weight, total;
+  uint64_t payload;  // byte offset of the walk's arcs in the pinned payload area
+};
+__device__ __forceinline__ unsigned long long sp1_parent_class(unsigned long long cand, unsigned long long key_s, unsigned long long key_t) {
+  if (cand == key_t) return 0ull;  // (same rule as parent_class in sssp.hip)
+  if ((cand >> 32) == (key_t >> 32) && key_s < key_t) return 1ull << 63;
+  return SP1_PARENT_NONE;
+}
+
+// LDS: key[n] u64 | parent[n] u64 | (staged inputs) off[n + 1] u32 | wn[n_arcs] {weight bits, nextstate}
+constexpr uint32_t SP1_STAGE_STATES = 2048, SP1_STAGE_ARCS = 4096;
+__host__ __device__ inline bool sp1_staged(uint32_t n, uint32_t n_arcs) { return n <= SP1_STAGE_STATES && n_arcs <= SP1_STAGE_ARCS; }
+__host__ __device__ inline size_t sp1_lds_bytes(uint32_t n, uint32_t n_arcs) {
+  size_t b = 16 * (size_t)(n ? n : 1);
+  if (sp1_staged(n, n_arcs)) b += nb_al(4 * ((size_t)n + 1)) + 8 * (size_t)n_arcs;
+  return nb_al(b);
+}
+
+__global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__ probs, Sp1Out* __restrict__ outs,
+                                                      uint8_t* __restrict__ payload) {
+  extern __shared__ __align__(16) unsigned char nb_lds[];
+  const uint32_t lane = threadIdx.x;
+  const NbProb pr = probs[blockIdx.x];
+  const uint32_t n = pr.n;
+  unsigned long long* const key = (unsigned long long*)nb_lds;  // [n]
+  unsigned long long* const parent = key + n;                   // [n]  (during the relaxation: the key a state was last expanded with)
+  uint32_t* const l_off = (uint32_t*)(parent + n);              // [n + 1]   staged inputs only
+  uint2* const l_wn = (uint2*)((unsigned char*)l_off + nb_al(4 * ((size_t)n + 1)));  // [n_arcs]
+  wfst_tr* const path = (wfst_tr*)(payload + pr.scratch);
+  Sp1Out o{0u, 0u, 0u, 0u, INF, INF, pr.scratch};
+  if (pr.start < 0 || n == 0) {
+    if (lane == 0) outs[blockIdx.x] = o;
+    return;
+  }
+  const bool staged = sp1_staged(n, pr.n_arcs);
+  for (uint32_t s = lane; s < n; s += 64) {
+    key[s] = s == (uint32_t)pr.start ? ((unsigned long long)nb_enc(0.0f) << 32) : SP1_KEY_INF;
+    parent[s] = SP1_KEY_INF;
+  }
+  if (staged) {
+    for (uint32_t s = lane; s <= n; s += 64) l_off[s] = pr.off[s];
+    for (uint32_t k = lane; k < pr.n_arcs; k += 64) {
+      const uint4 a = reinterpret_cast<const uint4*>(pr.arcs)[k];
+      l_wn[k] = make_uint2(a.z, a.w);
+    }
+  }
+  __syncthreads();
+  if (staged) {
+    // Offsets and arcs in LDS: the states are taken IN ORDER by the whole wave (lanes over the arcs of one state), so a
+    // sweep carries an improvement along every forward arc at once — a lattice numbered in BFS order needs one sweep and
+    // a second that finds nothing to do (a state is expanded again only if its key changed since it last was).
+    for (;;) {
+      bool changed = false;
+      for (uint32_t s = 0; s < n; ++s) {
+        const unsigned long long ks = key[s];
+        if (ks != SP1_KEY_INF && ks != parent[s]) {  // (uniform: every lane reads the same words)
+          if (lane == 0) parent[s] = ks;
+          const float ds = nb_dec((uint32_t)(ks >> 32));
+          const uint32_t h1 = (uint32_t)ks + 1u;
+          for (uint32_t k = l_off[s] + lane; k < l_off[s + 1]; k += 64) {
+            const uint2 a = l_wn[k];
+            const float c = (ds + __uint_as_float(a.x)) + 0.0f;  // w1 (x) w2 (tropical_weight.rs:60-70)
+            if (!(c < INF)) continue;                            // +inf never improves (shortest_path.rs:226)
+            const unsigned long long ck = ((unsigned long long)nb_enc(c) << 32) | h1;
+            if (ck < key[a.y]) changed |= atomicMin(&key[a.y], ck) > ck;
+          }
+        }
+        __syncthreads();  // (one wave: this state's LDS atomics are done before the next state's key is read)
+      }
+      if (!__any(changed)) break;
+    }
+  } else {
+    for (;;) {  // label-correcting rounds over the arcs in memory, lanes over the states
+      bool changed = false;
+      for (uint32_t s = lane; s < n; s += 64) {
+        const unsigned long long ks = key[s];
+        if (ks == SP1_KEY_INF) continue;
+        const float ds = nb_dec((uint32_t)(ks >> 32));
+        const uint32_t h1 = (uint32_t)ks + 1u;
+        for (uint32_t k = pr.off[s]; k < pr.off[s + 1]; ++k) {
+          const wfst_tr a = pr.arcs[k];
+          const float c = (ds + a.weight) + 0.0f;
+          if (!(c < INF)) continue;
+          const unsigned long long ck = ((unsigned long long)nb_enc(c) << 32) | h1;
+          if (ck < key[a.nextstate]) changed |= atomicMin(&key[a.nextstate], ck) > ck;
+        }
+      }
+      __syncthreads();
+      if (!__any(changed)) break;
+    }
+  }
+  // final state: d[s] (x) rho(s) (shortest_path.rs:214-220), ties to the smaller state
+  unsigned long long best = SP1_KEY_INF;
+  for (uint32_t s = lane; s < n; s += 64) {
+    parent[s] = SP1_PARENT_NONE;
+    const float f = pr.finals[s];
+    const unsigned long long ks = key[s];
+    if (!(f < INF) || ks == SP1_KEY_INF) continue;
+    const float tot = (nb_dec((uint32_t)(ks >> 32)) + f) + 0.0f;
+    if (!(tot < INF)) continue;
+    const unsigned long long c = ((unsigned long long)nb_enc(tot) << 32) | s;
+    best = c < best ? c : best;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long x = __shfl_xor(best, d);
+    best = x < best ? x : best;
+  }
+  if (best == SP1_KEY_INF) {
+    if (lane == 0) outs[blockIdx.x] = o;
+    return;
+  }
+  __syncthreads();
+  // parents: min (class, source, position) over the arcs the rule admits
+  for (uint32_t s = lane; s < n; s += 64) {
+    const unsigned long long ks = key[s];
+    if (ks == SP1_KEY_INF) continue;
+    const float ds = nb_dec((uint32_t)(ks >> 32));
+    const uint32_t h1 = (uint32_t)ks + 1u, b = staged ? l_off[s] : pr.off[s], e = staged ? l_off[s + 1] : pr.off[s + 1];
+    for (uint32_t k = b; k < e; ++k) {
+      uint2 a;
+      if (staged) {
+        a = l_wn[k];
+      } else {
+        const wfst_tr t = pr.arcs[k];
+        a = make_uint2(__float_as_uint(t.weight), t.nextstate);
+      }
+      const float c = (ds + __uint_as_float(a.x)) + 0.0f;
+      if (!(c < INF)) continue;
+      const unsigned long long ck = ((unsigned long long)nb_enc(c) << 32) | h1;
+      const unsigned long long cls = sp1_parent_class(ck, ks, key[a.y]);
+      if (cls != SP1_PARENT_NONE) atomicMin(&parent[a.y], cls | ((unsigned long long)s << 32) | (k - b));
+    }
+  }
+  __syncthreads();
+  const uint32_t fp = (uint32_t)best;
+  o.has_path = 1u;
+  o.final_weight = pr.finals[fp];
+  o.total = nb_dec((uint32_t)(best >> 32));
+  // the walk: one lane follows the parents (LDS) and notes the arc index of every step where the keys were (they are not
+  // needed any more: the start state is where the walk ends); the arcs themselves are then fetched by all lanes at once
+  // and go to pinned memory in the order make_path_fst expects (arc k enters the k-th created state)
+  uint32_t* const steps = (uint32_t*)key;  // [<= n]
+  uint32_t hops = 0, status = 0;
+  if (lane == 0) {
+    uint32_t cur = fp;
+    while (cur != (uint32_t)pr.start) {
+      const unsigned long long p = parent[cur];
+      if (p == SP1_PARENT_NONE || hops >= n) {  // (cannot happen at a fixed point of non-negative weights: reported, not followed)
+        status = 1u;
+        break;
+      }
+      const uint32_t s = (uint32_t)(p >> 32) & 0x7FFFFFFFu, pos = (uint32_t)p;
+      steps[hops] = (staged ? l_off[s] : pr.off[s]) + pos;
+      cur = s;
+      ++hops;
+    }
+  }
+  hops = __shfl(hops, 0);
+  status = __shfl(status, 0);
+  __syncthreads();
+  if (status == 0u)
+    for (uint32_t k = lane; k < hops; k += 64) {
+      wfst_tr tr = pr.arcs[steps[k]];
+      tr.nextstate = k;
+      path[k] = tr;
+    }
+  o.hops = hops;
+  o.status = status;
+  if (lane == 0) outs[blockIdx.x] = o;
+}
+
+}  // namespace
+
+// A lone tiny FST (the two-step route on small lattices: compose, then shortest_path) is one wavefront's work too: ~0.1 ms
+// instead of the ~0.5 ms of launches and synchronisations the relaxation kernels cost whatever the size.  Larger inputs
+// would keep ONE wave busy for longer than the GPU-wide kernels take.  (Not when a test pins a relaxation kernel.)
+bool shortest_path_n1_tiny(wfst_ctx* ctx, const wfst_fst* f, wfst_fst** out) {
+  constexpr uint64_t TINY_ARCS = 2048;
+  if (f->n_states > SP1_MAX_STATES || f->n_arcs > TINY_ARCS || std::getenv("WFST_SSSP_MAILBOX") || std::getenv("WFST_SSSP_DELTA")) return false;
+  *out = nullptr;
+  shortest_path_n1_batch(ctx, &f, 1, out, /*lone=*/true);
+  return *out != nullptr;
+}
+
+void shortest_path_n1_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, wfst_fst** outs, bool lone) {
+  hipStream_t st = ctx->stream;
+  std::vector<size_t> idx;
+  uint32_t max_n = 0;
+  const bool allow = !std::getenv("WFST_SP1_DEVICE") || std::atoi(std::getenv("WFST_SP1_DEVICE")) != 0;
+  for (size_t i = 0; i < n; ++i) {
+    const wfst_fst* f = fsts[i];
+    outs[i] = nullptr;
+    // (the reference tie order is a property of the single-FST path; negative weights keep its convergence guard)
+    if (!allow || ctx->tie_reference || f->n_states > SP1_MAX_STATES || f->n_arcs > 4ull * SP1_MAX_STATES || (n < 2 && !lone)) continue;
+    ensure_device(const_cast<wfst_fst*>(f));
+    if (f->has_negative) continue;
+    idx.push_back(i);
+    max_n = std::max(max_n, f->n_states);
+  }
+  if (!idx.empty()) {
+    const size_t m = idx.size();
+    size_t lds = 0;
+    for (size_t i : idx) lds = std::max(lds, sp1_lds_bytes(fsts[i]->n_states, (uint32_t)fsts[i]->n_arcs));
+    std::vector<NbProb> hp(m);
+    size_t pay = 0;
+    for (size_t j = 0; j < m; ++j) {
+      const wfst_fst* f = fsts[idx[j]];
+      hp[j] = NbProb{f->dev.offsets, f->dev.arcs, f->dev.finals, f->n_states, (uint32_t)f->n_arcs, (int32_t)f->start, 0u, pay};
+      pay += nb_al(16 * (size_t)std::max<uint32_t>(f->n_states, 1));  // a shortest path visits a state once
+    }
+    const size_t pin_bytes = nb_al(m * sizeof(NbProb)) + nb_al(m * sizeof(Sp1Out)) + pay;
+    char* pin = (char*)ctx->pinned_big.get(pin_bytes);
+    NbProb* h_probs = (NbProb*)pin;
+    Sp1Out* h_outs = (Sp1Out*)(pin + nb_al(m * sizeof(NbProb)));
+    uint8_t* h_payload = (uint8_t*)(pin + nb_al(m * sizeof(NbProb)) + nb_al(m * sizeof(Sp1Out)));
+    std::memcpy(h_probs, hp.data(), m * sizeof(NbProb));
+    static std::once_flag lds_once[64];
+    std::call_once(lds_once[(unsigned)ctx->device & 63u], [] {
+      HIP_CHECK(hipFuncSetAttribute((const void*)sp1_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    });
+    // (descriptors read from, results and path arcs written to pinned host memory by the kernel itself)
+    sp1_wave_kernel<<<(uint32_t)m, 64, lds, st>>>(h_probs, h_outs, h_payload);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t j = 0; j < m; ++j) {
+      const Sp1Out& o = h_outs[j];
+      if (o.status != 0u) continue;  // the single-FST path below
+      outs[idx[j]] = make_path_fst(ctx, o.has_path != 0, o.hops, o.final_weight, (const wfst_tr*)(h_payload + o.payload));
+    }
+  }
+  if (lone) return;  // (the caller continues on the relaxation kernels)
+  for (size_t i = 0; i < n; ++i)
+    if (!outs[i]) outs[i] = shortest_path_n1(ctx, fsts[i]);
+}
+
 }  // namespace wfst

@@ -1273,22 +1273,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
 // Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
 // word (add_state / set_final / add_tr / set_start bookkeeping, then shortest_path_properties(.., true)).
 wfst_fst* build_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final_weight, const wfst_tr* path_arcs) {
-  HostCsr h;
-  uint32_t n_states = 0;
-  int64_t start = -1;
-  if (has_path) {
-    n_states = hops + 1;
-    h.finals.assign(n_states, INF);
-    h.finals[0] = final_weight;
-    h.arcs.assign(path_arcs, path_arcs + hops);
-    h.offsets.resize((size_t)n_states + 1);
-    h.offsets[0] = 0;
-    for (uint32_t k = 0; k <= hops; ++k) h.offsets[k + 1] = k;  // state 0 has no arc, state k >= 1 one
-    start = hops;
-  } else {
-    h.offsets.push_back(0);
-  }
-  return make_host_fst(ctx, n_states, start, props::linear_path_props(has_path, hops, final_weight, path_arcs), std::move(h));
+  return make_path_fst(ctx, has_path, hops, final_weight, path_arcs);
 }
 
 // The order in which the reference relaxes the states of an acyclic FST (queues/auto_queue.rs:23-99): state order when the
@@ -1613,6 +1598,10 @@ void shortest_path_n1_abandon(wfst_sp_job* job) {
 
 wfst_ctx* sp_job_ctx(wfst_sp_job* job) { return job->ctx; }
 
-wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) { return shortest_path_n1_end(shortest_path_n1_begin(ctx, f)); }
+wfst_fst* shortest_path_n1(wfst_ctx* ctx, const wfst_fst* f) {
+  wfst_fst* tiny = nullptr;
+  if (shortest_path_n1_tiny(ctx, f, &tiny)) return tiny;
+  return shortest_path_n1_end(shortest_path_n1_begin(ctx, f));
+}
 
 }  // namespace wfst

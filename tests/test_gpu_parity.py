@@ -682,6 +682,34 @@ def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
         assert_flat_identical(got, exp, f"seed {seed} n={n}")
 
 
+@pytest.mark.parametrize("device", ["1", "0"], ids=["wave_kernel", "one_by_one"])
+def test_shortest_path_batch_one_best_vs_oracle(gpu_ctx, oracle, device, monkeypatch):
+    """wfst_shortest_path_batch with nshortest = 1: small inputs are solved by ONE launch, one wavefront each (keys in LDS,
+    the canonical predecessor rule, the walk) — the same FSTs as one shortest_path call each returns and as the oracle's
+    canonical path, bit for bit: cyclic and acyclic inputs, coarse weight grids (ties), epsilons, inputs without a final
+    state or without a start state, a single state; an input with a negative weight takes the single-FST path."""
+    monkeypatch.setenv("WFST_SP1_DEVICE", device)
+    rng = np.random.default_rng(8800)
+    flats = []
+    for k in range(40):
+        flats.append(random_fst_flat(rng, int(rng.integers(1, 300)), int(rng.integers(1, 6)), 5, p_eps_i=0.1 * (k % 2), p_final=0.05 + 0.3 * rng.random(),
+                                     min_fanout=k % 2, acyclic=bool(k % 3 == 0), weight_grid=1 if k % 4 == 0 else 512, max_w=4 if k % 4 == 0 else 2560))
+    flats[3]["finals"][:] = np.inf  # no final state: the empty FST
+    flats[5]["start"] = None
+    flats[7] = synth.linear_acceptor_flat([4])
+    neg = random_fst_flat(rng, 30, 3, 4, p_final=0.3, acyclic=True, min_fanout=1)
+    neg["arcs"]["weight"][0] = np.float32(-1.5)
+    flats.append(neg)
+    ds = [to_device(f) for f in flats]
+    outs = rustfst_amd.shortest_path_batch(ds, ShortestPathConfig(nshortest=1))
+    assert len(outs) == len(flats)
+    for k, (f, d, out) in enumerate(zip(flats, ds, outs)):
+        got = out.to_flat()
+        assert_flat_identical(got, d.shortest_path().to_flat(), f"batch item {k} vs the single call")
+        if k < len(flats) - 1:  # (the canonical oracle is defined for non-negative weights)
+            assert_flat_identical(got, to_oracle(oracle, f).shortest_path_canonical().to_flat(), f"batch item {k} vs the oracle")
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_nshortest_unique_vs_oracle(gpu_ctx, oracle, seed):
     """nshortest > 1 with unique = true (shortest_path.rs:157-165): distances and reverse() on the GPU, determinization of the

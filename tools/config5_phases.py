@@ -25,3 +25,7 @@ rustfst_amd.shortest_path_batch(outs, cfg, ctx=ctx)
 t0 = time.perf_counter(); rustfst_amd.shortest_path_batch(outs, cfg, ctx=ctx); print(f"nbest10 x64: {1e3*(time.perf_counter()-t0):.3f} ms")
 one = la.compose(rel[0]); ctx.synchronize()
 t0 = time.perf_counter(); one = la.compose(rel[0]); ctx.synchronize(); print(f"one look-ahead composition: {1e3*(time.perf_counter()-t0):.3f} ms ({one.num_states} states)")
+cfg1 = ShortestPathConfig(nshortest=1)
+rustfst_amd.shortest_path_batch(outs, cfg1, ctx=ctx)
+t0 = time.perf_counter(); p1 = rustfst_amd.shortest_path_batch(outs, cfg1, ctx=ctx); print(f"1-best x64 (shortest_path_batch, nshortest = 1): {1e3*(time.perf_counter()-t0):.3f} ms")
+t0 = time.perf_counter(); p1 = [o.shortest_path() for o in outs]; print(f"1-best x64 (one call each): {1e3*(time.perf_counter()-t0):.3f} ms")
