@@ -539,7 +539,11 @@ __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__
     // Offsets and arcs in LDS: the states are taken IN ORDER by the whole wave (lanes over the arcs of one state), so a
     // sweep carries an improvement along every forward arc at once — a lattice numbered in BFS order needs one sweep and
     // a second that finds nothing to do (a state is expanded again only if its key changed since it last was).
-    for (;;) {
+    for (uint32_t sweep = 0;; ++sweep) {
+      if (sweep > n + 1u) {  // (more sweeps than states: only a negative cycle does that; the driver excludes negative weights)
+        o.status = 2u;
+        break;
+      }
       bool changed = false;
       for (uint32_t s = 0; s < n; ++s) {
         const unsigned long long ks = key[s];
@@ -560,7 +564,11 @@ __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__
       if (!__any(changed)) break;
     }
   } else {
-    for (;;) {  // label-correcting rounds over the arcs in memory, lanes over the states
+    for (uint32_t round = 0;; ++round) {  // label-correcting rounds over the arcs in memory, lanes over the states
+      if (round > n + 1u) {
+        o.status = 2u;
+        break;
+      }
       bool changed = false;
       for (uint32_t s = lane; s < n; s += 64) {
         const unsigned long long ks = key[s];
@@ -578,6 +586,10 @@ __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__
       __syncthreads();
       if (!__any(changed)) break;
     }
+  }
+  if (o.status != 0u) {  // did not converge: left to the single-FST path (which reports it)
+    if (lane == 0) outs[blockIdx.x] = o;
+    return;
   }
   // final state: d[s] (x) rho(s) (shortest_path.rs:214-220), ties to the smaller state
   unsigned long long best = SP1_KEY_INF;
