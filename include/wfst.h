@@ -283,7 +283,9 @@ wfst_status wfst_vec_fst_from_device(const wfst_fst* fst, wfst_vec_fst** out);
  * (unique = false) small inputs — the composed lattices of a decoding batch: BASELINE configs[4] — are searched by ONE
  * launch, one wavefront per input (distances, reverse, the reference's heap search, connect); with nshortest == 1 small
  * inputs (<= 4096 states) are likewise solved by one launch (keys in LDS, the canonical predecessor rule, the walk); larger
- * ones go through the single-FST paths one after the other.  Same results as n calls of wfst_shortest_path. */
+ * ones go through the single-FST paths one after the other; with unique = true the distances and arrays of all small inputs
+ * come to the host in one launch and the host stages (reversal, determinization, search) run on host threads.  Same
+ * results as n calls of wfst_shortest_path. */
 wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, const wfst_shortest_path_config* cfg,
                                      wfst_fst** outs);
 

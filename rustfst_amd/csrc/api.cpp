@@ -331,6 +331,10 @@ wfst_status wfst_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* fsts,
         shortest_path_n1_batch(ctx, fsts, n, outs);
         return;
       }
+      if (c.nshortest >= 2 && c.unique) {  // small inputs: one launch for distances + arrays, the host stages on threads
+        shortest_path_nbest_unique_batch(ctx, fsts, n, c.nshortest, c.delta, outs);
+        return;
+      }
       for (size_t i = 0; i < n; ++i) {
         if (c.nshortest == 0) {
           HostCsr h;

@@ -306,6 +306,17 @@ wfst_fst* make_path_fst(wfst_ctx* ctx, bool has_path, uint32_t hops, float final
 // nbest_batch.hip: nshortest == 1 for many small FSTs in one launch (one wavefront each); the others one after the other
 void shortest_path_n1_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, wfst_fst** outs, bool lone = false);
 bool shortest_path_n1_tiny(wfst_ctx* ctx, const wfst_fst* f, wfst_fst** out);  // a lone tiny FST: one wavefront (false: not applicable)
+// nbest_batch.hip: distances + CSR of many small device FSTs in one launch (for host-side stages over a batch)
+struct SmallFstExport {
+  bool ok = false;
+  std::vector<float> dist;
+  HostCsr csr;
+};
+constexpr uint32_t SMALL_FST_MAX_STATES = 4096, SMALL_FST_MAX_ARCS = 16384;
+void export_small_with_distances(wfst_ctx* ctx, const wfst_fst* const* fsts, const std::vector<size_t>& idx,
+                                 std::vector<SmallFstExport>& out);
+// nshortest.hip: nshortest > 1 with unique = true for a batch (small inputs: one launch + host threads)
+void shortest_path_nbest_unique_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, uint64_t nshortest, float delta, wfst_fst** outs);
 void compose_shortest_path_batch_abandon(wfst_batch_job* job);
 wfst_ctx* batch_job_ctx(const wfst_batch_job* job);
 // compose_wide.hip

@@ -506,8 +506,14 @@ __host__ __device__ inline size_t sp1_lds_bytes(uint32_t n, uint32_t n_arcs) {
   return nb_al(b);
 }
 
+// mode 1 (export): stop after the relaxation and hand the distances AND the input's CSR to the host — dist[n] f32 |
+// offsets[n + 1] | finals[n] | arcs[n_arcs], each 16-byte aligned, in the problem's payload slice — for host-side stages
+// over many small inputs (the `unique` n-best branch: determinization) that would otherwise download them one by one.
+__host__ __device__ inline size_t sp1_export_bytes(uint32_t n, uint32_t n_arcs) {
+  return nb_al(4 * (size_t)n) + nb_al(4 * ((size_t)n + 1)) + nb_al(4 * (size_t)n) + 16 * (size_t)n_arcs;
+}
 __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__ probs, Sp1Out* __restrict__ outs,
-                                                      uint8_t* __restrict__ payload) {
+                                                      uint8_t* __restrict__ payload, uint32_t mode) {
   extern __shared__ __align__(16) unsigned char nb_lds[];
   const uint32_t lane = threadIdx.x;
   const NbProb pr = probs[blockIdx.x];
@@ -588,6 +594,25 @@ __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__
     }
   }
   if (o.status != 0u) {  // did not converge: left to the single-FST path (which reports it)
+    if (lane == 0) outs[blockIdx.x] = o;
+    return;
+  }
+  if (mode == 1u) {
+    uint8_t* pl = payload + pr.scratch;
+    float* const e_dist = (float*)pl;
+    pl += nb_al(4 * (size_t)n);
+    uint32_t* const e_off = (uint32_t*)pl;
+    pl += nb_al(4 * ((size_t)n + 1));
+    float* const e_fin = (float*)pl;
+    pl += nb_al(4 * (size_t)n);
+    uint4* const e_arcs = (uint4*)pl;
+    for (uint32_t s = lane; s < n; s += 64) {
+      e_dist[s] = key[s] == SP1_KEY_INF ? INF : nb_dec((uint32_t)(key[s] >> 32));
+      e_fin[s] = pr.finals[s];
+    }
+    for (uint32_t s = lane; s <= n; s += 64) e_off[s] = pr.off[s];
+    for (uint32_t k = lane; k < pr.n_arcs; k += 64) e_arcs[k] = reinterpret_cast<const uint4*>(pr.arcs)[k];
+    o.has_path = 1u;
     if (lane == 0) outs[blockIdx.x] = o;
     return;
   }
@@ -673,6 +698,54 @@ __global__ void __launch_bounds__(64) sp1_wave_kernel(const NbProb* __restrict__
 
 }  // namespace
 
+// Forward distances (the exact fixed point) and the CSR of the small inputs idx[..] of fsts, all in ONE launch and one
+// synchronisation; false for an input the kernel handed back.  Inputs must have a start state and at most SP1_MAX_STATES
+// states / 4 * SP1_MAX_STATES arcs, no negative weights, and a device copy.
+void export_small_with_distances(wfst_ctx* ctx, const wfst_fst* const* fsts, const std::vector<size_t>& idx,
+                                 std::vector<SmallFstExport>& out) {
+  const size_t m = idx.size();
+  out.assign(m, SmallFstExport{});
+  if (m == 0) return;
+  hipStream_t st = ctx->stream;
+  std::vector<NbProb> hp(m);
+  size_t pay = 0, lds = 0;
+  for (size_t j = 0; j < m; ++j) {
+    const wfst_fst* f = fsts[idx[j]];
+    hp[j] = NbProb{f->dev.offsets, f->dev.arcs, f->dev.finals, f->n_states, (uint32_t)f->n_arcs, (int32_t)f->start, 0u, pay};
+    pay += nb_al(sp1_export_bytes(f->n_states, (uint32_t)f->n_arcs));
+    lds = std::max(lds, sp1_lds_bytes(f->n_states, (uint32_t)f->n_arcs));
+  }
+  const size_t pin_bytes = nb_al(m * sizeof(NbProb)) + nb_al(m * sizeof(Sp1Out)) + pay;
+  char* pin = (char*)ctx->pinned_big.get(pin_bytes);
+  NbProb* h_probs = (NbProb*)pin;
+  Sp1Out* h_outs = (Sp1Out*)(pin + nb_al(m * sizeof(NbProb)));
+  uint8_t* h_payload = (uint8_t*)(pin + nb_al(m * sizeof(NbProb)) + nb_al(m * sizeof(Sp1Out)));
+  std::memcpy(h_probs, hp.data(), m * sizeof(NbProb));
+  static std::once_flag lds_once[64];
+  std::call_once(lds_once[(unsigned)ctx->device & 63u], [] {
+    HIP_CHECK(hipFuncSetAttribute((const void*)sp1_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  });
+  sp1_wave_kernel<<<(uint32_t)m, 64, lds, st>>>(h_probs, h_outs, h_payload, 1u);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (size_t j = 0; j < m; ++j) {
+    const Sp1Out& o = h_outs[j];
+    if (o.status != 0u || !o.has_path) continue;
+    const wfst_fst* f = fsts[idx[j]];
+    const uint32_t n = f->n_states, na = (uint32_t)f->n_arcs;
+    const uint8_t* pl = h_payload + o.payload;
+    SmallFstExport& e = out[j];
+    e.dist.assign((const float*)pl, (const float*)pl + n);
+    pl += nb_al(4 * (size_t)n);
+    e.csr.offsets.assign((const uint32_t*)pl, (const uint32_t*)pl + n + 1);
+    pl += nb_al(4 * ((size_t)n + 1));
+    e.csr.finals.assign((const float*)pl, (const float*)pl + n);
+    pl += nb_al(4 * (size_t)n);
+    e.csr.arcs.assign((const wfst_tr*)pl, (const wfst_tr*)pl + na);
+    e.ok = true;
+  }
+}
+
 // A lone tiny FST (the two-step route on small lattices: compose, then shortest_path) is one wavefront's work too: ~0.1 ms
 // instead of the ~0.5 ms of launches and synchronisations the relaxation kernels cost whatever the size.  Larger inputs
 // would keep ONE wave busy for longer than the GPU-wide kernels take.  (Not when a test pins a relaxation kernel.)
@@ -721,7 +794,7 @@ void shortest_path_n1_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n
       HIP_CHECK(hipFuncSetAttribute((const void*)sp1_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     });
     // (descriptors read from, results and path arcs written to pinned host memory by the kernel itself)
-    sp1_wave_kernel<<<(uint32_t)m, 64, lds, st>>>(h_probs, h_outs, h_payload);
+    sp1_wave_kernel<<<(uint32_t)m, 64, lds, st>>>(h_probs, h_outs, h_payload, 0u);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(st));
     for (size_t j = 0; j < m; ++j) {

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "fst_props.h"
+#include "host_parallel.h"
 
 namespace wfst {
 
@@ -612,6 +613,68 @@ void determinize_with_distance(const HostCsr& in, int64_t start, uint64_t in_pro
   }
 }
 
+// reverse (reverse.rs:33-87) of a small FST on the host: super-initial state 0 with an epsilon arc (weight = the final
+// weight) to every final state + 1, state s becomes s + 1, arc (s -> t) becomes (t + 1 -> s + 1) in the order the input's
+// arcs are met; the old start state + 1 is final with weight One.  Same arrays as reverse_fst() builds on the GPU.
+void reverse_small_host(const HostCsr& in, uint32_t n, int64_t start, HostCsr& out) {
+  std::vector<uint32_t> deg((size_t)n + 2, 0);
+  for (uint32_t s = 0; s < n; ++s) {
+    if (in.finals[s] != INF) deg[1] += 1;  // (arcs of state 0)
+    for (uint32_t k = in.offsets[s]; k < in.offsets[s + 1]; ++k) deg[(size_t)in.arcs[k].nextstate + 2] += 1;
+  }
+  out.offsets.assign((size_t)n + 2, 0);
+  for (size_t i = 1; i <= (size_t)n + 1; ++i) out.offsets[i] = out.offsets[i - 1] + deg[i];
+  out.arcs.resize(out.offsets[(size_t)n + 1]);
+  std::vector<uint32_t> cur(out.offsets.begin(), out.offsets.end() - 1);
+  for (uint32_t s = 0; s < n; ++s) {
+    if (in.finals[s] != INF) out.arcs[cur[0]++] = wfst_tr{0u, 0u, in.finals[s], s + 1};
+    for (uint32_t k = in.offsets[s]; k < in.offsets[s + 1]; ++k) {
+      const wfst_tr& a = in.arcs[k];
+      out.arcs[cur[(size_t)a.nextstate + 1]++] = wfst_tr{a.ilabel, a.olabel, a.weight, s + 1};
+    }
+  }
+  out.finals.assign((size_t)n + 1, INF);
+  if (start >= 0) out.finals[(size_t)start + 1] = 0.0f;
+}
+
+// The `unique` branch after the distances and the reversal (shortest_path.rs:143-165,170): distance of the super-initial
+// state, determinization of the reversed acceptor, the search on it, connect.
+wfst_fst* nbest_unique_from_reversed(wfst_ctx* ctx, const HostCsr& rh, uint64_t rprops, const std::vector<float>& distance,
+                                     uint64_t nshortest, float delta) {
+  OutFst ofst;
+  auto finish = [&]() {
+    HostCsr h;
+    h.offsets.push_back(0);
+    for (const OutFst::St& st : ofst.states) {
+      h.arcs.insert(h.arcs.end(), st.trs.begin(), st.trs.end());
+      h.offsets.push_back((uint32_t)h.arcs.size());
+      h.finals.push_back(st.has_final ? st.final_w : INF);
+    }
+    return make_host_fst(ctx, (uint32_t)ofst.states.size(), ofst.start, ofst.p, std::move(h));
+  };
+  float d0 = INF;
+  for (uint32_t k = rh.offsets[0]; k < rh.offsets[1]; ++k) {
+    const uint32_t state = rh.arcs[k].nextstate - 1;
+    if (state < distance.size()) d0 = wplus(d0, wtimes(rh.arcs[k].weight, distance[state]));
+  }
+  std::vector<float> distance_2;
+  distance_2.reserve(distance.size() + 1);
+  distance_2.push_back(d0);
+  distance_2.insert(distance_2.end(), distance.begin(), distance.end());
+  HostCsr dh;
+  std::vector<float> distance_3;
+  determinize_with_distance(rh, 0, rprops, distance_2, delta, dh, distance_3);
+  nbest_search([&](uint32_t st, uint32_t* cnt) {
+                 *cnt = dh.offsets[st + 1] - dh.offsets[st];
+                 return dh.arcs.data() + dh.offsets[st];
+               },
+               [&](uint32_t st) { return dh.finals[st]; }, distance_3, nshortest, delta, ofst);
+  if (ofst.states.empty()) return finish();
+  ofst.connect();
+  ofst.p = props::shortest_path(ofst.p, false) & props::ALL;
+  return finish();
+}
+
 wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshortest, float delta, bool unique) {
   OutFst ofst;
   auto finish = [&]() {
@@ -638,28 +701,7 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
     // every string has ONE path; the search then runs on that acceptor.  Acceptors only, as in the reference.
     std::unique_ptr<wfst_fst> rf(reverse_fst(ctx, f));
     ensure_host(rf.get());
-    const HostCsr& rh = rf->host;
-    float d0 = INF;
-    for (uint32_t k = rh.offsets[0]; k < rh.offsets[1]; ++k) {
-      const uint32_t state = rh.arcs[k].nextstate - 1;
-      if (state < distance.size()) d0 = wplus(d0, wtimes(rh.arcs[k].weight, distance[state]));
-    }
-    std::vector<float> distance_2;
-    distance_2.reserve((size_t)n + 1);
-    distance_2.push_back(d0);
-    distance_2.insert(distance_2.end(), distance.begin(), distance.end());
-    HostCsr dh;
-    std::vector<float> distance_3;
-    determinize_with_distance(rh, rf->start, rf->props, distance_2, delta, dh, distance_3);
-    nbest_search([&](uint32_t st, uint32_t* cnt) {
-                   *cnt = dh.offsets[st + 1] - dh.offsets[st];
-                   return dh.arcs.data() + dh.offsets[st];
-                 },
-                 [&](uint32_t st) { return dh.finals[st]; }, distance_3, nshortest, delta, ofst);
-    if (ofst.states.empty()) return finish();
-    ofst.connect();
-    ofst.p = props::shortest_path(ofst.p, false) & props::ALL;
-    return finish();
+    return nbest_unique_from_reversed(ctx, rf->host, rf->props, distance, nshortest, delta);
   }
   // 2. reversed FST (GPU transpose, cached on the handle)
   wfst_fst* mf = const_cast<wfst_fst*>(f);
@@ -696,6 +738,42 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
   ofst.connect();
   ofst.p = props::shortest_path(ofst.p, false) & props::ALL;
   return finish();
+}
+
+// nshortest > 1 with unique = true for a batch: the distances and the arrays of all small inputs come to the host in ONE
+// launch (export_small_with_distances), then reversal, determinization and the search of every input run on host threads
+// (64 lattices one after the other were ~0.8 ms each: a relaxation, a GPU reversal and two read-backs per input).
+void shortest_path_nbest_unique_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n, uint64_t nshortest, float delta,
+                                      wfst_fst** outs) {
+  std::vector<size_t> idx;
+  for (size_t i = 0; i < n; ++i) {
+    const wfst_fst* f = fsts[i];
+    outs[i] = nullptr;
+    if (n < 2 || f->start < 0 || f->n_states == 0 || f->n_states > SMALL_FST_MAX_STATES || f->n_arcs > SMALL_FST_MAX_ARCS) continue;
+    ensure_device(const_cast<wfst_fst*>(f));
+    if (f->has_negative) continue;
+    idx.push_back(i);
+  }
+  std::vector<SmallFstExport> ex;
+  export_small_with_distances(ctx, fsts, idx, ex);
+  const unsigned n_thr = std::getenv("WFST_HOST_THREADS") ? host_threads(idx.size())
+                                                           : (unsigned)std::min<size_t>(std::min(16u, host_threads(1u << 16)), idx.size() / 4);
+  parallel_chunks(n_thr, idx.size(), 1, [&](unsigned, uint64_t b, uint64_t e) {
+    for (uint64_t j = b; j < e; ++j) {
+      if (!ex[j].ok) continue;
+      const wfst_fst* f = fsts[idx[j]];
+      HostCsr rh;
+      reverse_small_host(ex[j].csr, f->n_states, f->start, rh);
+      // the reversed FST's ACCEPTOR bit (reverse.rs:80-86): from the input's word, or from its arcs (every arc added to the
+      // fresh output keeps or clears it, mutable_fst.rs:235-244)
+      bool all_same = true;
+      for (const wfst_tr& a : ex[j].csr.arcs) all_same = all_same && a.ilabel == a.olabel;
+      const uint64_t rprops = ((f->props & props::ACCEPTOR) || all_same) ? props::ACCEPTOR : props::NOT_ACCEPTOR;
+      outs[idx[j]] = nbest_unique_from_reversed(ctx, rh, rprops, ex[j].dist, nshortest, delta);
+    }
+  });
+  for (size_t i = 0; i < n; ++i)
+    if (!outs[i]) outs[i] = shortest_path_nbest(ctx, fsts[i], nshortest, delta, true);
 }
 
 }  // namespace wfst

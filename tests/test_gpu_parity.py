@@ -682,6 +682,32 @@ def test_nshortest_random_vs_oracle(gpu_ctx, oracle, seed, lazy, monkeypatch):
         assert_flat_identical(got, exp, f"seed {seed} n={n}")
 
 
+def test_nshortest_unique_batch_vs_oracle(gpu_ctx, oracle):
+    """unique = true over a batch: distances and arrays of all small inputs in one launch, reversal / determinization /
+    search on host threads — every result bit-identical to the oracle's and to the single call; inputs without a final
+    state or a start state in between; a transducer anywhere in the batch makes the call KO, as the single call would."""
+    rng = np.random.default_rng(4400)
+    flats = []
+    for k in range(24):
+        f = random_fst_flat(rng, int(rng.integers(2, 60)), 4, 2 + k % 3, p_eps_i=0.1 * (k % 2), p_final=0.3, min_fanout=1,
+                            acyclic=True, weight_grid=4 if k % 2 else 512, max_w=12 if k % 2 else 2560, sort="none")
+        f["arcs"]["olabel"] = f["arcs"]["ilabel"]
+        f["props"] = 0x0000_0000_0001_0000
+        flats.append(f)
+    flats[4]["finals"][:] = np.inf
+    flats[9]["start"] = None
+    ds = [to_device(f) for f in flats]
+    cfg = ShortestPathConfig(nshortest=4, unique=True)
+    outs = rustfst_amd.shortest_path_batch(ds, cfg)
+    for k, (f, d, out) in enumerate(zip(flats, ds, outs)):
+        got = out.to_flat()
+        assert_flat_identical(got, to_oracle(oracle, f).shortest_path_n(4, unique=True).to_flat(), f"unique batch item {k} vs the oracle")
+        assert_flat_identical(got, d.shortest_path(cfg).to_flat(), f"unique batch item {k} vs the single call")
+    tr = random_fst_flat(rng, 10, 3, 3, p_final=0.4, acyclic=True, min_fanout=1)  # ilabel != olabel somewhere, no ACCEPTOR bit
+    with pytest.raises(rustfst_amd.WfstError, match="expected acceptor"):
+        rustfst_amd.shortest_path_batch(ds[:3] + [to_device(tr)], cfg)
+
+
 @pytest.mark.parametrize("device", ["1", "0"], ids=["wave_kernel", "one_by_one"])
 def test_shortest_path_batch_one_best_vs_oracle(gpu_ctx, oracle, device, monkeypatch):
     """wfst_shortest_path_batch with nshortest = 1: small inputs are solved by ONE launch, one wavefront each (keys in LDS,

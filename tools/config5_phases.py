@@ -29,3 +29,12 @@ cfg1 = ShortestPathConfig(nshortest=1)
 rustfst_amd.shortest_path_batch(outs, cfg1, ctx=ctx)
 t0 = time.perf_counter(); p1 = rustfst_amd.shortest_path_batch(outs, cfg1, ctx=ctx); print(f"1-best x64 (shortest_path_batch, nshortest = 1): {1e3*(time.perf_counter()-t0):.3f} ms")
 t0 = time.perf_counter(); p1 = [o.shortest_path() for o in outs]; print(f"1-best x64 (one call each): {1e3*(time.perf_counter()-t0):.3f} ms")
+cfgu = ShortestPathConfig(nshortest=10, unique=True)
+accept = []
+for o in outs:  # the composed lattices as acceptors of their output labels (what a decoder ranks)
+    f = o.to_flat(); f["arcs"]["ilabel"] = f["arcs"]["olabel"]; f["props"] = 0x10000
+    accept.append(f)
+da = rustfst_amd.DeviceFst.upload_many(accept, ctx)
+rustfst_amd.shortest_path_batch(da, cfgu, ctx=ctx)
+t0 = time.perf_counter(); u = rustfst_amd.shortest_path_batch(da, cfgu, ctx=ctx); print(f"unique 10-best x64 (batch): {1e3*(time.perf_counter()-t0):.3f} ms")
+t0 = time.perf_counter(); u1 = [d.shortest_path(cfgu) for d in da[:8]]; print(f"unique 10-best, one call each: {1e3*(time.perf_counter()-t0)/8:.3f} ms per lattice")
