@@ -372,6 +372,40 @@ def test_nshortest_unique_gives_the_n_best_distinct_strings(oracle, seed):
         assert len(all_path_weights(many, max_len=64)) > len(all_strings(many))
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_determinize_is_deterministic_and_equivalent(oracle, seed):
+    """determinize_fsa (pinned on K12) on random acyclic acceptors: no state of the result has two arcs with one label, and
+    every string keeps exactly the least weight it had in the input (weights on a coarse grid: the quantization by delta
+    is the identity there)."""
+    rng = np.random.default_rng(4600 + seed)
+    flat = acceptor_flat(rng, int(rng.integers(2, 12)), 4, 2 + seed % 3, p_eps_i=0.15 * (seed % 2), p_final=0.4, acyclic=True,
+                         min_fanout=1, weight_grid=4, max_w=16)
+    det = to_oracle(oracle, flat).determinize_fsa().to_flat()
+    for s_ in range(det["n_states"]):
+        labels = [int(a["ilabel"]) for a in det["arcs"][det["offsets"][s_]:det["offsets"][s_ + 1]]]
+        assert len(labels) == len(set(labels)) and labels == sorted(labels), (s_, labels)  # one arc per label, label order
+
+    def strings_with_eps(fl):  # (epsilon is a label like any other for determinize: keep it in the string)
+        best = {}
+        off, arcs, fin = fl["offsets"], fl["arcs"], fl["finals"]
+
+        def rec(st, labs, acc):
+            if np.isfinite(fin[st]):
+                w = float(np.float32(acc + fin[st]))
+                best[labs] = min(best.get(labs, np.inf), w)
+            for a in arcs[off[st]:off[st + 1]]:
+                rec(int(a["nextstate"]), labs + (int(a["ilabel"]),), np.float32(acc + a["weight"]))
+
+        if fl["start"] is not None:
+            rec(fl["start"], (), np.float32(0.0))
+        return best
+
+    want, got = strings_with_eps(flat), strings_with_eps(det)
+    assert set(want) == set(got)
+    for k in want:
+        assert abs(want[k] - got[k]) < 1e-3, (k, want[k], got[k])
+
+
 def test_nshortest_unique_needs_an_acceptor(oracle):
     rng = np.random.default_rng(5)
     flat = random_fst_flat(rng, 6, 3, 3, p_final=0.5, acyclic=True, min_fanout=1)  # a transducer: no ACCEPTOR bit
