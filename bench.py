@@ -444,7 +444,7 @@ def main():
         ms_sp_t = alone(lambda: dt.shortest_path())
         ms_batch = alone(lambda: rustfst_amd.compose_shortest_path_batch(daccs, dt2, ctx=ctx2))
         sweeps = ctx.stats()["sweeps"]
-        relax_kernel = ("sssp_relax_kernel", "sssp_mbox_kernel")[int(ctx.stats()["relax_kernel"])]
+        relax_kernel = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel")[int(ctx.stats()["relax_kernel"])]
 
         # ------------------------------------------------------------------ configs[1]: ONE 1000-arc string against a
         # 100k-state T (the case a lone dependent chain makes the GPU lose to one CPU core; reported, not timed above)

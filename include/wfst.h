@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 3 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed */
+#define WFST_ABI_VERSION 4 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
+                             * 4: wfst_stats gained resident_aborts, relax_kernel may be 2 */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
 
@@ -362,9 +363,12 @@ typedef struct {
   uint64_t string_problems; /* problems of the last fused batch that took the string o T kernel (fst1 a linear,
                                epsilon-free acceptor, fst2 without input epsilons) */
   uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
-                               (owner-computes mailbox launches: WIDE / COLLECT / NARROW) */
+                               (owner-computes mailbox launches: WIDE / COLLECT / NARROW, one level per launch), 2 the
+                               same with the WIDE levels inside one sssp_mbox_resident_kernel launch */
   uint64_t nbest_device_problems; /* inputs of the last wfst_shortest_path_batch (nshortest > 1) searched by the wave kernel
                                      (the others went through the host search) */
+  uint64_t resident_aborts; /* resident relaxation launches that gave up waiting for their own workgroups (the solve was
+                               then repeated with one launch per level, and the context stays in that mode), cumulative */
 } wfst_stats;
 /* on = 1: every relaxation launch is bracketed by HIP events and followed by a synchronisation (per-launch trace below;
  * never on in timed runs).  on = 2: no per-launch events; the sweeps of a repeated shortest_path query (one pre-queued

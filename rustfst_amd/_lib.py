@@ -27,7 +27,8 @@ class Stats(C.Structure):
     _fields_ = [("relax_launches", C.c_uint64), ("relax_ms", C.c_double), ("relax_arcs", C.c_uint64),
                 ("relax_states", C.c_uint64), ("sweeps", C.c_uint64), ("compose_states", C.c_uint64),
                 ("compose_arcs", C.c_uint64), ("compose_retries", C.c_uint64), ("compose_ms", C.c_double),
-                ("string_problems", C.c_uint64), ("relax_kernel", C.c_uint64), ("nbest_device_problems", C.c_uint64)]
+                ("string_problems", C.c_uint64), ("relax_kernel", C.c_uint64), ("nbest_device_problems", C.c_uint64),
+                ("resident_aborts", C.c_uint64)]
 
 
 # every symbol include/wfst.h declares: (name, restype, argtypes)

@@ -114,6 +114,7 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
   bool tie_reference = false;  // wfst_ctx_set_tie_order: the reference's predecessor choice on acyclic inputs
+  bool resident_off = false;   // a resident relaxation launch gave up waiting on this context: one launch per level from now on
   // wfst_ctx_set_profiling(ctx, 2): no per-launch events; the sweeps of a repeated (predicted) shortest_path query are timed
   // as ONE chain between two events on the stream, without any synchronisation between launches
   bool chain_timing = false;
@@ -181,6 +182,10 @@ struct MboxPlan {
   uint32_t nb = 0;         // blocks of 4096 states
   DBuf<uint32_t> roff;     // [nb*nb + 1] destination-major
   DBuf<uint32_t> roff_t;   // [nb*nb]     source-major copy
+  // regions of the resident kernel (sssp_resident.h): 16-byte header + one slot per arc, 64-byte aligned, in 8-byte units
+  DBuf<uint32_t> roffh;    // [nb*nb + 1] destination-major
+  DBuf<uint32_t> roffh_t;  // [nb*nb]     source-major copy
+  uint64_t res_units = 0;  // units of one parity buffer
 };
 }  // namespace wfst
 

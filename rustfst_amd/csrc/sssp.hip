@@ -120,6 +120,7 @@ __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float
 }
 
 #include "sssp_mailbox.h"
+#include "sssp_resident.h"
 
 // Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
 // +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
@@ -810,6 +811,28 @@ __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __re
   if (hops) hops[s] = k == KEY_INF ? 0xFFFFFFFFu : (uint32_t)k;
 }
 
+// One resident solve per device at a time: a grid that waits for its own workgroups must be resident as a whole, and two
+// such grids started together could each hold half of the CUs.  (Another process is not covered: the wait limit is.)
+struct ResidentLease {
+  std::atomic<int>* slot = nullptr;
+  ResidentLease() = default;
+  ResidentLease(const ResidentLease&) = delete;
+  ResidentLease& operator=(const ResidentLease&) = delete;
+  bool acquire(int device) {
+    static std::atomic<int> busy[64];
+    std::atomic<int>* s = &busy[(unsigned)device & 63u];
+    int expect = 0;
+    if (!s->compare_exchange_strong(expect, 1)) return false;
+    slot = s;
+    return true;
+  }
+  void release() {
+    if (slot) slot->store(0);
+    slot = nullptr;
+  }
+  ~ResidentLease() { release(); }
+};
+
 struct Solve {
   DBuf<uint64_t> key;
   DBuf<uint32_t> shadow;  // enc(d) half of the keys, for the pre-check gathers
@@ -836,6 +859,14 @@ struct Solve {
   uint64_t hint_mask = ~0ull;  // mailbox: bit k = launch k of this FST's last solve was not a busy WIDE sweep (gated launch)
   size_t mb_dyn = 0;         // dynamic LDS bytes of a mailbox launch
   bool force_big = false;    // tests: the many-blocks variant of the kernel on a small FST (WFST_SSSP_BIG=1)
+  // resident launches (sssp_resident.h): the WIDE levels of the solve inside ONE launch, every workgroup on a CU of its own
+  bool resident = false;
+  DBuf<uint2> rs_msgs;       // two parity buffers of plan->res_units entries
+  DBuf<uint32_t> rs_abort;   // one word
+  DBuf<unsigned long long> rs_trace;  // WFST_SSSP_RES_TRACE=<file>: per-level stamps
+  ResView rv{};
+  uint32_t res_max_levels = RS_LEVEL_CAP;
+  ResidentLease lease;       // at most one resident solve per device at a time (two half-resident grids would wait for each other)
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -869,6 +900,19 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
   mbox_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roff.p, nb, p->roff_t.p);
+  uint32_t h_units = 0;
+  if (nb <= MB_NBMAX) {  // the resident kernel's regions: header + one slot per arc, 64-byte aligned
+    p->roffh = DBuf<uint32_t>(owner_pool, cells + 1);
+    p->roffh_t = DBuf<uint32_t>(owner_pool, cells);
+    DBuf<uint32_t> sizes(*ctx->pool, cells + 1);
+    res_size_kernel<<<(uint32_t)((cells + 1 + 255) / 256), 256, 0, st>>>(hist.p, (uint32_t)cells, sizes.p);
+    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, sizes.p, p->roffh.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+    mbox_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roffh.p, nb, p->roffh_t.p);
+    HIP_CHECK(hipMemcpyAsync(&h_units, p->roffh.p + cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));  // sizes is released here
+    p->res_units = h_units;
+  }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(st));  // hist / temp are released here
   f->mbox = p;
@@ -891,7 +935,14 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
     // hint = the launch is probably NOT a busy WIDE sweep (what the last solve of this FST did in that slot, or unknown):
     // it then finds out its mode and whether it sleeps BEFORE it asks for its 48 KB of keys and offsets
     const uint32_t hint = profile || abs_sweep >= 64 ? 1u : (uint32_t)((sv.hint_mask >> abs_sweep) & 1ull);
-    if (sv.mv.nb > MB_NBMAX || sv.force_big)
+    // resident launches take the odd slots: slot 0 is the head of the search (NARROW), a resident launch runs every WIDE
+    // level that follows and the hand-over, the next slot is the NARROW launch that drains the search; whichever kernel
+    // finds another mode in its slot does that mode's work (the two kernels leave the same state behind)
+    if (sv.resident && !profile && (abs_sweep & 1u) && abs_sweep < RS_MAX_SWEEP)
+      sssp_mbox_resident_kernel<<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
+                                                                         sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
+                                                                         sv.narrow_t, sv.res_max_levels);
+    else if (sv.mv.nb > MB_NBMAX || sv.force_big)
       sssp_mbox_kernel<true><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
                                                                       sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
                                                                       profile, hint, sv.narrow_t);
@@ -1007,15 +1058,61 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       HIP_CHECK(hipMemsetAsync(sv.mb_dbg.p, 0, (size_t)MB_DBG_SWEEPS * nb * 16 * 8, st));
       mv.dbg = sv.mb_dbg.p;
     }
+    // Resident launches: every block needs a CU of its own for the whole launch (1024 threads x 128 registers and ~150 KB of
+    // LDS fill one), so the grid must fit the device, and only one such solve runs per device at a time.  Not under the
+    // per-sweep profiler (it times launches), not after a launch of this context gave up waiting.
+    sv.resident = false;
+    sv.rv = ResView{};
+    {
+      int want = 1;
+      if (const char* e = std::getenv("WFST_SSSP_RESIDENT")) want = std::atoi(e);
+      const uint64_t bytes = sv.plan->res_units * sizeof(uint2);
+      if (want && !ctx->profiling && !ctx->resident_off && !sv.force_big && nb <= MB_NBMAX && nb <= (uint32_t)ctx->n_cus &&
+          sv.plan->res_units != 0 && bytes < 0x7FFFFFF0ull && sv.lease.acquire(ctx->device)) {
+        try {
+          sv.rs_msgs = DBuf<uint2>(pool, 2 * (size_t)sv.plan->res_units);
+          sv.rs_abort = DBuf<uint32_t>(pool, 16);
+          sv.resident = true;
+        } catch (const Error&) {
+          sv.rs_msgs.reset();
+          sv.rs_abort.reset();
+          sv.lease.release();
+        }
+      }
+      if (sv.resident) {
+        ResView& rv = sv.rv;
+        rv.msgs[0] = sv.rs_msgs.p;
+        rv.msgs[1] = sv.rs_msgs.p + sv.plan->res_units;
+        rv.roffh = sv.plan->roffh.p;
+        rv.roffh_t = sv.plan->roffh_t.p;
+        rv.abort = sv.rs_abort.p;
+        rv.bytes = (uint32_t)bytes;
+        rv.tlim_ticks = 2000000u;  // 20 ms of wall_clock64
+        if (const char* e = std::getenv("WFST_SSSP_RES_TLIM_US")) rv.tlim_ticks = (uint32_t)std::min<long long>(4000000000ll, std::atoll(e) * 100ll);
+        sv.res_max_levels = RS_LEVEL_CAP;
+        if (const char* e = std::getenv("WFST_SSSP_RES_LEVELS")) sv.res_max_levels = std::max<uint32_t>(2u, std::min<uint32_t>(RS_LEVEL_CAP, (uint32_t)std::atol(e)));
+        rv.trace = nullptr;
+        if (std::getenv("WFST_SSSP_RES_TRACE")) {
+          sv.rs_trace = DBuf<unsigned long long>(pool, (size_t)RS_TRACE_LEVELS * nb * 4);
+          HIP_CHECK(hipMemsetAsync(sv.rs_trace.p, 0, (size_t)RS_TRACE_LEVELS * nb * 4 * 8, st));
+          rv.trace = sv.rs_trace.p;
+        }
+        static std::once_flag res_once[64];
+        std::call_once(res_once[(unsigned)ctx->device & 63u], [] {
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MB_DYN_BUDGET));
+        });
+      }
+    }
     sssp_mbox_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, f->dev.offsets, n, (uint32_t)f->start,
-                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t);
+                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t, sv.rv.msgs[0],
+                                                      sv.rv.msgs[1], sv.rv.roffh, sv.rv.abort);
   } else {
     sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
                                                  sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
                                                  delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
   }
   HIP_CHECK(hipGetLastError());
-  ctx->stats.relax_kernel = sv.mbox ? 1u : 0u;
+  ctx->stats.relax_kernel = sv.mbox ? (sv.resident ? 2u : 1u) : 0u;
   sv.sweep_cap = 4ull * n + 64;
   if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
   if (const char* e = std::getenv("WFST_SSSP_CHASE_ROUNDS")) sv.chase_rounds = (uint32_t)std::atol(e);
@@ -1154,6 +1251,7 @@ struct SweepDriver {
   }
   uint32_t* host_flags(const SweepBatch& b) const { return h_imp + b.which * IMP_RING; }
 
+  bool aborted = false;    // a resident launch raised FLAG_RES_ABORT
   uint64_t seen_busy = 0;  // bit k: launch k was a busy WIDE sweep (flag value 1 + MODE_WIDE)
   bool scan_flags(const SweepBatch& b) {  // true when a sweep of the batch changed nothing
     const uint32_t* hf = h_imp + b.which * IMP_RING;
@@ -1161,6 +1259,10 @@ struct SweepDriver {
       sweeps_done = b.first + k + 1;
       const uint32_t v = hf[(b.first + k) % IMP_RING];
       if (!v) return true;
+      if (v == FLAG_RES_ABORT) {  // a resident launch gave up waiting for its own workgroups: the caller solves again without
+        aborted = true;
+        return true;
+      }
       if (v == FLAG_NARROW_CLEAN) return true;  // a NARROW launch that left nothing anywhere: the fixed point, certified
       // (WIDE and COLLECT launches have every block awake and loading its keys: no gate next time)
       if ((v == 1u + MODE_WIDE || v == 1u + MODE_COLLECT) && b.first + k < 64) seen_busy |= 1ull << (b.first + k);
@@ -1205,6 +1307,21 @@ void mbox_dump_trace(wfst_ctx* ctx, Solve& sv) {
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (FILE* fp = std::fopen(path, "wb")) {
     const uint32_t hdr[2] = {MB_DBG_SWEEPS, sv.mv.nb};
+    std::fwrite(hdr, 4, 2, fp);
+    std::fwrite(h.data(), 8, h.size(), fp);
+    std::fclose(fp);
+  }
+}
+
+// tuning aid: the level stamps of the resident launches go to the file named by WFST_SSSP_RES_TRACE (u64 [64][nb][4])
+void res_dump_trace(wfst_ctx* ctx, Solve& sv) {
+  const char* path = std::getenv("WFST_SSSP_RES_TRACE");
+  if (!sv.resident || !sv.rs_trace.p || !path) return;
+  std::vector<unsigned long long> h((size_t)RS_TRACE_LEVELS * sv.mv.nb * 4);
+  HIP_CHECK(hipMemcpyAsync(h.data(), sv.rs_trace.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (FILE* fp = std::fopen(path, "wb")) {
+    const uint32_t hdr[2] = {RS_TRACE_LEVELS, sv.mv.nb};
     std::fwrite(hdr, 4, 2, fp);
     std::fwrite(h.data(), 8, h.size(), fp);
     std::fclose(fp);
@@ -1261,13 +1378,23 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     drv.init(ctx, f, &sv);
     drv.start();
     drv.finish();
+    if (drv.aborted) {  // a resident launch gave up waiting (its grid was not resident as a whole): one launch per level
+      HIP_CHECK(hipStreamSynchronize(st));
+      ctx->resident_off = true;
+      ctx->stats.resident_aborts += 1;
+      sv.lease.release();
+      run_relaxation(ctx, f, sv);
+      return;
+    }
     sweeps_done = drv.sweeps_done;
     f->last_hint_mask.store(drv.hint_mask(), std::memory_order_relaxed);
   }
+  sv.lease.release();
   sv.sweeps = sweeps_done;
   ctx->stats.sweeps = sweeps_done;
   note_sweeps(f, sweeps_done);
   mbox_dump_trace(ctx, sv);
+  res_dump_trace(ctx, sv);
 }
 
 // Builds the linear output FST exactly as single_shortest_path_backtrace does, including the property
@@ -1530,11 +1657,20 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   Solve& sv = j->sv;
   if (!ctx->profiling) {
     j->drv.finish();
+    if (j->drv.aborted) {  // a resident launch gave up waiting: the whole query again, one launch per level
+      HIP_CHECK(hipStreamSynchronize(st));
+      ctx->resident_off = true;
+      ctx->stats.resident_aborts += 1;
+      j.reset();  // (its buffers go back to the pool, the lease with them)
+      return shortest_path_n1_end(shortest_path_n1_begin(ctx, f));
+    }
+    sv.lease.release();
     sv.sweeps = j->drv.sweeps_done;
     ctx->stats.sweeps = sv.sweeps;
     note_sweeps(f, sv.sweeps);
     f->last_hint_mask.store(j->drv.hint_mask(), std::memory_order_relaxed);
     mbox_dump_trace(ctx, sv);
+    res_dump_trace(ctx, sv);
   }
   if (j->tail_queued && j->drv.extended) {  // the speculative tail ran on unfinished distances: once more
     HIP_CHECK(hipMemsetAsync(&sv.ctl.p->best, 0xFF, sizeof(unsigned long long), st));

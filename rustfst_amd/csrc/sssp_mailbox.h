@@ -105,9 +105,19 @@ __global__ void mbox_transpose_kernel(const uint32_t* __restrict__ roff, uint32_
 // work-list segment (sweep 0 is NARROW); without, it waits in the pending mask (sweep 0 is WIDE).
 __global__ void __launch_bounds__(256) sssp_mbox_setup_kernel(uint64_t* __restrict__ key, MboxView mb, uint32_t* __restrict__ improved,
                                                               Ctl* __restrict__ ctl, const uint32_t* __restrict__ offsets, uint32_t n,
-                                                              uint32_t start, float tau0, uint32_t narrow_on) {
+                                                              uint32_t start, float tau0, uint32_t narrow_on, uint2* rs_msgs0,
+                                                              uint2* rs_msgs1, const uint32_t* __restrict__ rs_roffh,
+                                                              uint32_t* __restrict__ rs_abort) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   const uint32_t nb = mb.nb;
+  if (rs_msgs0) {  // resident launches (sssp_resident.h): no region header carries a tag of this solve yet
+    for (uint32_t i = tid; i < nb * nb; i += nt) {
+      const uint32_t h = rs_roffh[i];
+      rs_msgs0[h].x = 0;
+      rs_msgs1[h].x = 0;
+    }
+    if (tid == 0) rs_abort[0] = 0;
+  }
   for (uint32_t i = tid; i < n; i += nt) {
     const bool is_start = i == start;
     key[i] = is_start ? (uint64_t)enc_f32(0.0f) << 32 : KEY_INF;

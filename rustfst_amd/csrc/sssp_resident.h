@@ -1,0 +1,485 @@
+// sssp_resident.h — the WIDE phase of a mailbox solve as ONE launch (included by sssp.hip after sssp_mailbox.h).
+//
+// Same owner-computes scheme, same recurrence (single_shortest_path, rustfst/src/algorithms/shortest_path.rs:173-239),
+// same near-far schedule and therefore the same sequence of levels as sssp_mbox_kernel launched once per level — but
+// the workgroups do not leave between two levels:
+//   * workgroup j keeps the keys and arc offsets of its block in LDS for ALL the levels it runs (loaded once, written
+//     back once), and the set of states to look at as a bit mask in LDS: a candidate that lowers a key (the LDS atomicMin
+//     returns the old one) sets the state's bit, the scan lists the near ones and leaves the far ones set — no per-thread
+//     copies of keys between levels, nothing of a level's bookkeeping goes through memory;
+//   * a level's hand-over between workgroups is the data itself.  Region (i -> j) starts with a 16-byte HEADER
+//     {tag of the level, message count, sender's near | far counts, sender's waiting count | sent flag} in the same
+//     64-byte sector as its first six messages; the sender writes messages with write-through (`sc1`) stores, every
+//     storing wave drains (`s_waitcnt vmcnt(0)`), then the headers go out — cdna_hip_programming.md Guideline 16, form R1,
+//     with the header as a data-tagged granule.  The receiver polls the first sector of each of its regions (4 lanes per
+//     region, one `sc1` 16-byte load each: ONE trip brings the tag, the count and the first six candidates) and applies
+//     a region as soon as its tag is the level's; thin levels never need a second trip for the inbox;
+//   * the numbers the schedule needs (near activations and far-waiting states of the previous level, whether anybody
+//     sent or still waits) travel in the headers: every workgroup sums the same nb headers and takes the same decision
+//     (threshold, WIDE / COLLECT, fixed point) without a counter in memory.
+// The launch ends with the COLLECT level (hand-over to a NARROW launch of sssp_mbox_kernel), at the fixed point, or
+// after `max_levels`; what it leaves in memory (keys, waiting masks, work-list segments, the schedule ring) is exactly
+// what a sssp_mbox_kernel launch in the same mode would have left, so the two kernels can follow each other in any
+// order.  Level 0 of a launch reads the inbox the previous launch left in the one-level kernel's format.
+//
+// Needs every workgroup resident (nb <= CUs, one 1024-thread workgroup per CU): the host checks it; every wait is
+// bounded by a wall-clock limit — a workgroup that gives up raises `abort`, everybody leaves, the host runs the solve
+// again with one launch per level.
+
+constexpr uint32_t RS_HDR = 2;      // 8-byte units of a region header
+constexpr uint32_t RS_FIRST = 6;    // messages sharing the header's 64-byte sector
+constexpr uint32_t RS_ALIGN = 8;    // regions start on 64-byte boundaries (units)
+constexpr uint32_t RS_MU = 4;       // 16-byte message loads a lane keeps in flight while it reads the rest of a region
+constexpr uint32_t FLAG_RES_ABORT = 0xAB0u;  // activity flag of a launch that gave up waiting
+constexpr uint32_t RS_MAX_SWEEP = 60000;     // tag = (sweep + 1) << 16 | level
+constexpr uint32_t RS_LEVEL_CAP = 65000;
+
+typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));
+
+struct ResView {
+  uint2* msgs[2];           // regions of odd / even levels (level l reads msgs[l & 1], written by level l - 1)
+  const uint32_t* roffh;    // [nb*nb] destination-major: header of region (i -> j) at unit roffh[j*nb + i]
+  const uint32_t* roffh_t;  // [nb*nb] sender-major copy
+  uint32_t* abort;          // one word, zeroed per solve
+  unsigned long long* trace;  // tuning (WFST_SSSP_RES_TRACE): [level][block][4] wall-clock stamps, or null
+  uint32_t bytes;           // of one parity buffer
+  uint32_t tlim_ticks;      // wall_clock64 ticks (100 MHz) a workgroup waits for a header before it gives up
+};
+constexpr uint32_t RS_TRACE_LEVELS = 64;
+
+__global__ void res_size_kernel(const uint32_t* __restrict__ hist, uint32_t cells, uint32_t* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < cells) out[k] = (RS_HDR + hist[k] + RS_ALIGN - 1u) & ~(RS_ALIGN - 1u);
+  else if (k == cells) out[k] = 0;
+}
+
+// sum over the 64 lanes of a wave, result in lane 63 (DPP row shifts / broadcasts: no LDS trips)
+__device__ __forceinline__ uint32_t wave_sum_to_last(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ uint32_t quad_first(uint32_t v) {  // lane 4k's value in lanes 4k .. 4k+3
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
+}
+
+__global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
+                                                                        uint64_t* __restrict__ key, MboxView mb, ResView rv, uint32_t par_in,
+                                                                        uint32_t n, uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
+                                                                        uint32_t sweep, float delta, uint32_t near_low, uint32_t narrow_t,
+                                                                        uint32_t max_levels) {
+  extern __shared__ __align__(16) unsigned char mb_dyn[];
+  __shared__ unsigned long long lkey[MB_B];
+  __shared__ uint32_t l_off[MB_B + 1];
+  __shared__ uint16_t a_state[MB_B];
+  __shared__ unsigned long long s_tot[2][2];  // per level parity: near | far << 32, waiting | senders << 32 (sums over the headers)
+  __shared__ uint32_t s_lv[2][6];             // per level parity: an, sent, npend, nfar, spare, spare
+  __shared__ uint32_t l_pend[MB_B / 32];      // states whose key was lowered since they were last expanded, or that wait beyond the threshold
+  __shared__ uint32_t s_nw[4];
+  __shared__ uint32_t s_abort;
+  constexpr uint32_t R = MB_B / MB_THREADS;
+  constexpr uint32_t PW = MB_B / 32;
+  constexpr uint32_t WPR = MB_THREADS / 32;
+  asm volatile("" ::"s"(offsets), "s"(mb.cnt[1]), "s"(ctl), "s"(rv.roffh), "s"(max_levels));
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t j = blockIdx.x, nb = mb.nb, stg = mb.stg;
+  uint2* const l_stage = (uint2*)mb_dyn;                         // [nb * stg]
+  uint32_t* const l_roff_out = (uint32_t*)(l_stage + nb * stg);  // [nb] first message slot of region (j -> d)
+  uint32_t* const l_cur = l_roff_out + nb;                       // [nb]
+  uint32_t* const l_base = l_cur + nb;                           // [nb]
+  const uint32_t s0 = j << MB_LOG;
+  uint32_t* improved = improved_ring + (sweep % IMP_RING);
+  const uint32_t reg = tid / MB_LPR, q = tid % MB_LPR;
+  static_assert(MB_LPR == 4, "the header sector is read by four lanes");
+
+  // ---- prologue: as sssp_mbox_kernel's first trip (everything issued before anything is consumed)
+  uint32_t c_in = 0, rb_in = 0, hdr_in = 0;
+  if (reg < nb) {
+    c_in = mb.cnt[par_in][j * nb + reg];
+    rb_in = mb.roff[j * nb + reg];
+    hdr_in = rv.roffh[j * nb + reg];
+  }
+  uint32_t ro_out = 0;
+  if (tid < nb) ro_out = rv.roffh_t[(size_t)j * nb + tid];
+  uint32_t pw[R];
+  for (uint32_t r = 0; r < R; ++r) pw[r] = mb.pend[j * PW + (tid >> 5) + WPR * r];
+  const uint32_t bmind = mb.blk_mind[j], bfar = mb.blk_far[j];
+  const bool wrote_out = mb.wrote[par_in ^ 1u][j] != 0u;
+  const uint32_t wl_n = min(mb.wl_cnt[j], NW_SEG);
+  unsigned long long kreg[R];
+  uint32_t oreg[R], o_last = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t s = s0 + tid + MB_THREADS * r;
+    kreg[r] = KEY_INF;
+    oreg[r] = 0;
+    if (s < n) {
+      kreg[r] = key[s];
+      oreg[r] = offsets[s];
+    } else if (s == n) {
+      oreg[r] = offsets[n];
+    }
+  }
+  if (tid == MB_THREADS - 1 && s0 + MB_B <= n) {
+    uint32_t t = tid;
+    asm volatile("" : "+v"(t));
+    o_last = offsets[s0 + t + MB_THREADS * (R - 1) + 1];
+  }
+  const SchedRaw raw = mbox_sched_load(ctl, sweep);
+  if (tid < nb) {
+    l_roff_out[tid] = ro_out + RS_HDR;
+    l_cur[tid] = 0;
+    l_base[tid] = 0;
+  }
+  for (uint32_t r = 0; r < R; ++r) {
+    l_off[tid + MB_THREADS * r] = oreg[r];
+    lkey[tid + MB_THREADS * r] = kreg[r];
+    if ((tid & 31u) == 0) l_pend[(tid >> 5) + WPR * r] = pw[r];
+  }
+  if (tid == MB_THREADS - 1) l_off[MB_B] = o_last;
+  const Sched sc = mbox_sched_eval(ctl, raw, sweep, delta, near_low, narrow_t);
+  if (tid < 24) {
+    if (tid < 4) ((unsigned long long*)s_tot)[tid] = 0;
+    if (tid >= 8 && tid < 20) ((uint32_t*)s_lv)[tid - 8] = 0u;
+    if (tid == 20) s_abort = 0;
+  }
+  if (j == 0 && tid < NEAR_SHARDS) ctl->nf[(sweep + 1) % NEAR_RING][tid * NF_STRIDE] = 0;  // recycle
+  __syncthreads();
+
+  unsigned long long* const nf = &ctl->nf[sweep % NEAR_RING][(j % NEAR_SHARDS) * NF_STRIDE];
+  if (wrote_out) {  // counts this workgroup published two sweeps ago in the one-level format: nothing is published there now
+    for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_in ^ 1u][(size_t)d * nb + j] = 0;
+    if (tid == 0) mb.wrote[par_in ^ 1u][j] = 0;
+  }
+  if (sc.mode == MODE_NARROW) {  // launched where a NARROW launch was due: do what sssp_mbox_kernel would have done
+    if (j == 0 && tid == 0) {
+      ctl->tau[sweep % RING] = __float_as_uint(sc.tau);
+      ctl->streak[sweep % RING] = sc.streak;
+      ctl->mode[sweep % RING] = sc.mode;
+    }
+    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, sc.tau_use, sc.far_total, near_low, 0u, wl_n, bmind != 0xFFFFFFFFu, bfar,
+                (uint4*)lkey, s_nw, par_in ^ 1u, l_roff_out, l_cur, l_base);
+    return;
+  }
+
+  // ---- state that lives across the levels
+  float tau_rec = sc.tau, tau = sc.tau_use;
+  uint32_t mode = sc.mode, streak = sc.streak;
+  uint32_t cnt_prev = sc.prev_near;  // near activations of the level before the current one
+  const uint32_t tag_base = (sweep + 1u) << 16;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)rv.msgs[0], 0, (int)rv.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)rv.msgs[1], 0, (int)rv.bytes, 0x00020000);
+  uint32_t last_an = 0, last_nfar = 0;
+  bool clean = false;
+#define RS_STAMP(p) do { if (rv.trace && tid == 0 && lvl < RS_TRACE_LEVELS) rv.trace[((size_t)lvl * nb + j) * 4 + (p)] = wall_clock64(); } while (0)
+  // a candidate for local state `tl`: the minimum is taken in LDS; a key that went down marks its state
+#define RS_APPLY(tl_, cand_) do { const uint32_t tl__ = (tl_); const unsigned long long c__ = (cand_);                 \
+    if (c__ < atomicMin(&lkey[tl__], c__)) atomicOr(&l_pend[tl__ >> 5], 1u << (tl__ & 31u)); } while (0)
+
+  for (uint32_t lvl = 0;; ++lvl) {
+    const uint32_t ps = lvl & 1u;
+    // ---------------- inbox
+    if (lvl == 0) {
+      const uint2* __restrict__ msgs_in = mb.msgs[par_in];
+      constexpr uint32_t MU = 8;
+      for (uint32_t k0 = q; k0 < c_in; k0 += MB_LPR * MU) {
+        uint2 m[MU];
+        for (uint32_t u = 0; u < MU; ++u) {
+          m[u] = make_uint2(0u, 0u);
+          if (k0 + MB_LPR * u < c_in) m[u] = msgs_in[rb_in + k0 + MB_LPR * u];
+        }
+        for (uint32_t u = 0; u < MU; ++u)
+          if (k0 + MB_LPR * u < c_in) RS_APPLY(m[u].x & (MB_B - 1u), ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
+      }
+    } else {
+      const uint32_t want = tag_base | lvl;
+      const __amdgpu_buffer_rsrc_t rs = ps ? rs1 : rs0;
+      const uint32_t hdr_b = hdr_in * 8u;  // the header sector of region (reg -> j); this lane reads bytes 16 q .. 16 q + 15 of it
+      bool pend = reg < nb;
+      uint32_t t_nf = 0, t_ps = 0;
+      uint32_t spins = 0;
+      unsigned long long t0 = 0;
+      for (;;) {
+        rs_u32x4 v = {0u, 0u, 0u, 0u};
+        if (pend) v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(hdr_b + q * 16u), 0, 16);
+        const uint32_t tag = quad_first(v.x), cnt = quad_first(v.y);
+        if (pend && tag == want) {
+          if (q == 0) {
+            t_nf = v.z;
+            t_ps = v.w;
+          } else {
+            const uint32_t i0 = 2u * (q - 1u);
+            if (i0 < cnt) RS_APPLY(v.x & (MB_B - 1u), ((unsigned long long)v.y << 32) | (v.x >> MB_LOG));
+            if (i0 + 1u < cnt) RS_APPLY(v.z & (MB_B - 1u), ((unsigned long long)v.w << 32) | (v.z >> MB_LOG));
+          }
+          // the rest of the region: pairs of messages, pair p = messages RS_FIRST + 2p, + 1 at byte 64 + 16 p
+          for (uint32_t p0 = q; RS_FIRST + 2u * p0 < cnt; p0 += MB_LPR * RS_MU) {
+            rs_u32x4 m[RS_MU];
+            for (uint32_t u = 0; u < RS_MU; ++u) {
+              const uint32_t p = p0 + MB_LPR * u;
+              m[u] = rs_u32x4{0u, 0u, 0u, 0u};
+              if (RS_FIRST + 2u * p < cnt) m[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(hdr_b + 64u + p * 16u), 0, 16);
+            }
+            for (uint32_t u = 0; u < RS_MU; ++u) {
+              const uint32_t i0 = RS_FIRST + 2u * (p0 + MB_LPR * u);
+              if (i0 < cnt) RS_APPLY(m[u].x & (MB_B - 1u), ((unsigned long long)m[u].y << 32) | (m[u].x >> MB_LOG));
+              if (i0 + 1u < cnt) RS_APPLY(m[u].z & (MB_B - 1u), ((unsigned long long)m[u].w << 32) | (m[u].z >> MB_LOG));
+            }
+          }
+          pend = false;
+        }
+        if (!__any(pend)) break;
+        // somebody's header is not there yet: poll again (bounded by the wall clock; everybody leaves once anybody gave up)
+        if ((++spins & 31u) == 0u || rv.tlim_ticks == 0u) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          const uint32_t ab = __hip_atomic_load(rv.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ab != 0u || now - t0 > (unsigned long long)rv.tlim_ticks || rv.tlim_ticks == 0u) {  // (limit 0: tests of the fallback)
+            if (lane == 0) {
+              s_abort = 1u;
+              __hip_atomic_store(rv.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // the senders' figures: one header per 4 lanes (the other lanes hold zeros)
+      const uint32_t a_near = wave_sum_to_last(t_nf & 0xFFFFu), a_far = wave_sum_to_last(t_nf >> 16);
+      const uint32_t a_pend = wave_sum_to_last(t_ps & 0xFFFFu), a_sent = wave_sum_to_last(t_ps >> 16);
+      if (lane == 63) {
+        atomicAdd(&s_tot[ps][0], ((unsigned long long)a_far << 32) | a_near);
+        atomicAdd(&s_tot[ps][1], ((unsigned long long)a_sent << 32) | a_pend);
+      }
+    }
+    __syncthreads();  // B1: the inbox is applied
+    RS_STAMP(0);
+    if (lvl > 0) {
+      if (s_abort) {
+        if (tid == 0) *improved = FLAG_RES_ABORT;
+        return;
+      }
+      const unsigned long long ta = s_tot[ps][0], tb = s_tot[ps][1];
+      const uint32_t cnt = (uint32_t)ta, far_total = (uint32_t)(ta >> 32), pend_total = (uint32_t)tb, senders = (uint32_t)(tb >> 32);
+      if (senders == 0u && pend_total == 0u) {  // the level before this one changed nothing anywhere: the fixed point
+        clean = true;
+        break;
+      }
+      // the schedule of this level: mbox_sched_eval's rules on the same figures
+      const float prev = tau_rec;
+      uint32_t m = MODE_WIDE;
+      if (narrow_t && cnt != 0u && cnt + far_total <= narrow_t && (cnt < cnt_prev || cnt + far_total <= min(narrow_t, NW_SMALL)))
+        m = MODE_COLLECT;
+      if (lvl + 1u >= max_levels) m = MODE_COLLECT;  // (the launch is over: hand whatever is active to the next one)
+      uint32_t st_new = 0;
+      if (cnt >= near_low) {
+        tau_rec = prev;
+      } else if (cnt) {
+        tau_rec = cnt < cnt_prev ? prev + delta : prev;
+      } else {
+        st_new = min(streak + 1u, 30u);
+        tau_rec = prev + delta * (float)(1u << (st_new - 1u));
+      }
+      streak = st_new;
+      mode = m;
+      tau = m == MODE_COLLECT ? INF : tau_rec;
+      cnt_prev = cnt;
+    }
+    if (tid < 8) {  // the other parity's level scalars: everybody has read them (B1 is behind their last readers)
+      if (tid < 2) s_tot[ps ^ 1u][tid] = 0;
+      else s_lv[ps ^ 1u][tid - 2] = 0u;
+    }
+    const bool collect = mode == MODE_COLLECT;
+
+    // ---------------- the marked states: near ones listed (and unmarked), far ones keep waiting
+    {
+      bool near_[R];
+      uint32_t n_near = 0, n_far = 0;
+      for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t tl = tid + MB_THREADS * r;
+        const uint32_t w = l_pend[tl >> 5];
+        const bool act = ((w >> (tl & 31u)) & 1u) != 0;
+        const uint32_t ed = (uint32_t)(lkey[tl] >> 32);
+        near_[r] = act && dec_f32(ed) <= tau;
+        const bool far = act && !near_[r];
+        const unsigned long long fm = __ballot(far), nm = __ballot(near_[r]);
+        if (w != 0u && (lane & 31u) == 0) {  // (the 32 lanes of a half read the word before its first lane rewrites it)
+          const uint32_t fw = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+          l_pend[tl >> 5] = fw;
+          n_far += (uint32_t)__popc(fw);
+        }
+        n_near += (uint32_t)__popcll(nm);
+      }
+      uint32_t base = 0;
+      if (n_near) {
+        if (lane == 0) base = atomicAdd(&s_lv[ps][0], n_near);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      }
+      for (uint32_t r = 0; r < R; ++r) {
+        const unsigned long long nm = __ballot(near_[r]);
+        if (near_[r]) a_state[base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (uint16_t)(tid + MB_THREADS * r);
+        base += (uint32_t)__popcll(nm);
+      }
+      if (__ballot(n_far != 0u)) {
+        n_far += __shfl_xor(n_far, 32);
+        if (lane == 0 && n_far) atomicAdd(&s_lv[ps][3], n_far);
+      }
+    }
+    __syncthreads();  // B2
+    RS_STAMP(1);
+    const uint32_t an = s_lv[ps][0];
+    last_an = an;
+    if (collect) {
+      // ---- hand-over: the states this level would have expanded become the block's segment of the work list
+      for (uint32_t e = tid; e < an; e += MB_THREADS) {
+        const uint32_t tl = a_state[e];
+        const unsigned long long k = lkey[tl];
+        const uint32_t b = l_off[tl], c = l_off[tl + 1] - b;
+        mb.wl[(size_t)j * NW_SEG + e] = make_uint4(s0 + tl, b, (uint32_t)(k >> 32), ((uint32_t)k << MB_LOG) | min(c, NW_DEG_SAT));
+        if ((uint32_t)k >> MB_HOP_BITS) ctl->pad = 1u;
+      }
+      // (tau = +inf: nobody is far, nothing was expanded: nothing waits)
+      last_nfar = 0;
+      break;
+    }
+
+    // ---------------- expansion: as sssp_mbox_kernel's, messages into the regions of level lvl + 1 (write-through stores)
+    uint32_t sent = 0;
+    {
+      const uint32_t sub = tid & 15u, grp = tid >> 4;
+      unsigned long long* __restrict__ msgs_out = (unsigned long long*)rv.msgs[ps ^ 1u];
+      constexpr uint32_t ROUND = (MB_THREADS / 16) * MB_UNROLL;
+      for (uint32_t r0 = 0; r0 < an; r0 += ROUND) {
+        uint32_t tl_[MB_UNROLL];
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          const uint32_t e = r0 + grp + (MB_THREADS / 16) * u;
+          tl_[u] = e < an ? (uint32_t)a_state[e] : 0xFFFFFFFFu;
+        }
+        uint32_t i_[MB_UNROLL], end_[MB_UNROLL], h1_[MB_UNROLL];
+        float d_[MB_UNROLL];
+        bool more = false;
+        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+          i_[u] = end_[u] = h1_[u] = 0;
+          d_[u] = 0.0f;
+          if (tl_[u] != 0xFFFFFFFFu) {
+            const unsigned long long k = lkey[tl_[u]];
+            const uint32_t b = l_off[tl_[u]];
+            end_[u] = l_off[tl_[u] + 1];
+            d_[u] = dec_f32((uint32_t)(k >> 32));
+            h1_[u] = (uint32_t)k + 1u;
+            i_[u] = b + sub;
+          }
+          more |= i_[u] < end_[u];
+        }
+        more = __any(more);
+        while (more) {
+          uint2 a[MB_UNROLL];
+          bool v[MB_UNROLL];
+          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+            v[u] = i_[u] < end_[u];
+            a[u] = make_uint2(0x7F800000u, 0u);
+            if (v[u]) a[u] = wn[i_[u]];
+          }
+          uint32_t enc[MB_UNROLL], slot[MB_UNROLL];
+          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+            const float c = (d_[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+            v[u] = v[u] && c < INF;                                    // +inf never improves (shortest_path.rs:226)
+            enc[u] = enc_f32(c);
+            if (v[u] && (a[u].y >> MB_LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
+              RS_APPLY(a[u].y & (MB_B - 1u), ((unsigned long long)enc[u] << 32) | h1_[u]);
+              v[u] = false;
+            }
+          }
+          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+            slot[u] = 0;
+            if (v[u]) slot[u] = atomicAdd(&l_cur[a[u].y >> MB_LOG], 1u);
+          }
+          more = false;
+          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
+            if (v[u]) {
+              const uint2 msg = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
+              const uint32_t db = a[u].y >> MB_LOG, rel = slot[u] - l_base[db];
+              if (rel < stg) l_stage[db * stg + rel] = msg;
+              else __hip_atomic_store(&msgs_out[l_roff_out[db] + slot[u]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+              if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;
+            }
+            sent += (uint32_t)__popcll(__ballot(v[u]));
+            i_[u] += 16;
+            more |= i_[u] < end_[u];
+          }
+          more = __any(more);
+        }
+        __syncthreads();
+        // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
+        for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / MB_LPR) {
+          const uint32_t b0 = l_base[rg], cn = min(l_cur[rg] - b0, stg), ro = l_roff_out[rg] + b0;
+          for (uint32_t k = q; k < cn; k += MB_LPR) {
+            const uint2 msg = l_stage[rg * stg + k];
+            __hip_atomic_store(&msgs_out[ro + k], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (r0 + ROUND < an) {
+          __syncthreads();
+          for (uint32_t d = tid; d < nb; d += MB_THREADS) l_base[d] = l_cur[d];
+          __syncthreads();
+        }
+      }
+    }
+    RS_STAMP(2);
+    if (lane == 0 && sent) atomicAdd(&s_lv[ps][1], sent);
+    // ---------------- what waits now: the far states of the scan and the states lowered from inside the block (every
+    //                  expansion's LDS atomics are behind the last round's barrier; no round at all: the scan's are behind B2)
+    if (tid < MB_B / 32) {
+      uint32_t c = (uint32_t)__popc(l_pend[tid]);
+      c = wave_sum_to_last(c);
+      if (lane == 63 && c) atomicAdd(&s_lv[ps][2], c);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its messages have left (Guideline 16 R1)
+    __syncthreads();  // B3
+    // ---------------- publish: the headers of level lvl + 1
+    {
+      const uint32_t total_sent = s_lv[ps][1], npend = s_lv[ps][2], nfar = s_lv[ps][3];
+      last_nfar = nfar;
+      if (tid < nb) {
+        const uint32_t c = l_cur[tid];
+        const rs_u32x4 h = {tag_base | (lvl + 1u), c, (an & 0xFFFFu) | (nfar << 16), (npend & 0xFFFFu) | ((total_sent != 0u ? 1u : 0u) << 16)};
+        __builtin_amdgcn_raw_buffer_store_b128(h, ps ? rs0 : rs1, (int)((l_roff_out[tid] - RS_HDR) * 8u), 0, 16);
+        l_cur[tid] = 0;
+        l_base[tid] = 0;
+      }
+    }
+    RS_STAMP(3);
+  }
+#undef RS_APPLY
+
+  // ---------------- the launch is over: keys, waiting masks, schedule ring as a one-level launch would leave them
+  __syncthreads();
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t tl = tid + MB_THREADS * r, s = s0 + tl;
+    if (s < n) key[s] = lkey[tl];
+    if ((tid & 31u) == 0) mb.pend[j * PW + (tid >> 5) + WPR * r] = 0;
+  }
+  const bool collect_exit = !clean;
+  if (tid == 0) {
+    mb.blk_pend[j] = 0;
+    mb.blk_mind[j] = 0xFFFFFFFFu;
+    mb.blk_far[j] = 0;
+    mb.wl_cnt[j] = collect_exit ? last_an : 0u;
+    if (collect_exit) {
+      if (last_an && *improved == 0u) *improved = 1u + MODE_COLLECT;
+      if (last_an | last_nfar) atomicAdd(nf, ((unsigned long long)last_nfar << 32) | last_an);
+    } else if (j == 0) {
+      atomicMax(improved, FLAG_NARROW_CLEAN);
+    }
+    if (j == 0) {
+      ctl->tau[sweep % RING] = __float_as_uint(tau_rec);
+      ctl->streak[sweep % RING] = streak;
+      ctl->mode[sweep % RING] = collect_exit ? MODE_COLLECT : MODE_WIDE;
+    }
+  }
+#undef RS_STAMP
+}

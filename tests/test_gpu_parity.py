@@ -388,7 +388,7 @@ def test_config3_properties_1m_states(gpu_ctx, oracle):
             assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")
 
 
-@pytest.mark.parametrize("kernel", ["mailbox", "mailbox_no_narrow", "atomic"])
+@pytest.mark.parametrize("kernel", ["mailbox", "mailbox_no_narrow", "mailbox_one_level", "atomic"])
 def test_config3_benched_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
     """The solve bench.py times — shortest_path(T), T = 1M states / 10M arcs, seed 3 — against the canonical oracle at full
     size: every distance, every hop count and the path itself bit-identical, for the mailbox launches (with and without
@@ -396,16 +396,19 @@ def test_config3_benched_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
     monkeypatch.setenv("WFST_SSSP_MAILBOX", "0" if kernel == "atomic" else "1")
     if kernel == "mailbox_no_narrow":
         monkeypatch.setenv("WFST_SSSP_NARROW", "0")
+    if kernel == "mailbox_one_level":
+        monkeypatch.setenv("WFST_SSSP_RESIDENT", "0")
     ctx = rustfst_amd.Context(0)
     t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
     d = to_device(t, ctx)
     can = to_oracle(oracle, t).shortest_path_canonical()
     for q in range(3):
         dist, hops = d.shortest_distance(want_hops=True)
-        assert ctx.stats()["relax_kernel"] == (0 if kernel == "atomic" else 1)
+        assert ctx.stats()["relax_kernel"] == {"atomic": 0, "mailbox_one_level": 1}.get(kernel, 2)
         np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
         np.testing.assert_array_equal(hops, can.hops)
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"benched solve, {kernel}, query {q}")
+    assert ctx.stats()["resident_aborts"] == 0
 
 
 def test_config3_512_acceptors_and_one_long_string_against_1m_states(gpu_ctx, oracle):
@@ -499,18 +502,24 @@ def test_chasing_does_not_change_results(oracle, monkeypatch, cap, budget, low, 
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"chase small {k}")
 
 
-@pytest.mark.parametrize("mailbox", ["1", "1:narrow=0", "1:narrow=1000000000", "1:narrow=64", "1:hint=0", "1:hint=1", "0"])
+@pytest.mark.parametrize("mailbox", ["1", "1:narrow=0", "1:narrow=1000000000", "1:narrow=64", "1:hint=0", "1:hint=1", "0",
+                                     "1:res=0", "1:reslevels=2", "1:reslevels=3", "1:restlim=0"])
 @pytest.mark.parametrize("delta", [None, "0", "0.7", "1000"])
 def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delta):
     """The owner-computes (mailbox) sweeps and the atomic sweeps reach the same fixed point: distances, hop counts and
     the path are bit-identical to the canonical oracle on graphs of less than one block, a partial last block, many
     blocks, a sparse deep graph, epsilons, ties everywhere, and whatever the near-far band width is — with the hand-over
     to NARROW launches off (narrow=0), at its default, forced whenever a sweep was busy (narrow=1e9: WIDE / COLLECT /
-    NARROW in turn, segments that overflow), and with every launch / no launch gated (hint)."""
+    NARROW in turn, segments that overflow), and with every launch / no launch gated (hint).  The WIDE levels run inside
+    resident launches by default (sssp_mbox_resident_kernel): also without them (res=0), with launches cut after two / three
+    levels (every level a first or a last one, hand-overs between the two kernels in both directions), and with a wait
+    limit of zero (the first header that is not there yet makes the launch give up: the solve is repeated with one launch
+    per level and the context stays in that mode)."""
     monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox.split(":")[0])
     if ":" in mailbox:
         k, v = mailbox.split(":")[1].split("=")
-        monkeypatch.setenv({"narrow": "WFST_SSSP_NARROW", "hint": "WFST_SSSP_HINT"}[k], v)
+        monkeypatch.setenv({"narrow": "WFST_SSSP_NARROW", "hint": "WFST_SSSP_HINT", "res": "WFST_SSSP_RESIDENT",
+                            "reslevels": "WFST_SSSP_RES_LEVELS", "restlim": "WFST_SSSP_RES_TLIM_US"}[k], v)
     if delta is not None:
         monkeypatch.setenv("WFST_SSSP_DELTA", delta)
     ctx = rustfst_amd.Context(0)
@@ -544,7 +553,7 @@ def test_mailbox_sweeps_beyond_2_20_states(oracle, monkeypatch, narrow):
     can = to_oracle(oracle, t).shortest_path_canonical()
     for q in range(2):
         dist, hops = d.shortest_distance(want_hops=True)
-        assert ctx.stats()["relax_kernel"] == 1
+        assert ctx.stats()["relax_kernel"] == 1  # (more than 256 blocks: one launch per level)
         np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
         np.testing.assert_array_equal(hops, can.hops)
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"2.1M states q={q}")
