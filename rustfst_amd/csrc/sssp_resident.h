@@ -414,12 +414,25 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
           more = __any(more);
         }
         __syncthreads();
-        // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination)
+        // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination), two messages per
+        // 16-byte write-through store (an 8-byte `sc1` store is a fabric write of its own: half the transactions to drain);
+        // message k sits at unit ro + k, and ro is even: pairs start at even k
         for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / MB_LPR) {
-          const uint32_t b0 = l_base[rg], cn = min(l_cur[rg] - b0, stg), ro = l_roff_out[rg] + b0;
-          for (uint32_t k = q; k < cn; k += MB_LPR) {
-            const uint2 msg = l_stage[rg * stg + k];
-            __hip_atomic_store(&msgs_out[ro + k], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t first = l_base[rg], last = first + min(l_cur[rg] - first, stg), ro = l_roff_out[rg];
+          const uint2* __restrict__ stv = l_stage + rg * stg - first;  // staged message k at stv[k]
+          const uint32_t p_lo = (first + 1u) & ~1u;
+          if (q == 0 && (first & 1u) && last > first) {
+            const uint2 msg = stv[first];
+            __hip_atomic_store(&msgs_out[ro + first], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          for (uint32_t k = p_lo + 2u * q; k + 1u < last; k += 2u * MB_LPR) {
+            const uint2 m0 = stv[k], m1 = stv[k + 1u];
+            const rs_u32x4 pr = {m0.x, m0.y, m1.x, m1.y};
+            __builtin_amdgcn_raw_buffer_store_b128(pr, ps ? rs0 : rs1, (int)((ro + k) * 8u), 0, 16);
+          }
+          if (q == 1 && last > p_lo && ((last - p_lo) & 1u)) {
+            const uint2 msg = stv[last - 1u];
+            __hip_atomic_store(&msgs_out[ro + last - 1u], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         if (r0 + ROUND < an) {
