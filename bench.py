@@ -217,7 +217,7 @@ def main():
     if args.overlap and args.batch_cus > 0:
         # Two contexts on DISJOINT compute units: the batch kernel is 64 lone waves chasing dependent loads, and a
         # load issued from a CU that also hosts streaming relaxation waves waits 2-4x longer in that CU's memory
-        # queue (tools/cu_mask_test.py: 1.08 -> 0.90 ms per step).  CU i = bit i%32 of word i//32.
+        # queue (tools/cu_mask_probe.py: 1.08 -> 0.90 ms per step).  CU i = bit i%32 of word i//32.
         n_cus = torch.cuda.get_device_properties(device).multi_processor_count
         k = min(args.batch_cus, n_cus - 1)
         small = np.zeros((n_cus + 31) // 32, dtype=np.uint32)

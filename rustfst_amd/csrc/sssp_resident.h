@@ -33,6 +33,7 @@ constexpr uint32_t RS_MU = 4;       // 16-byte message loads a lane keeps in fli
 constexpr uint32_t FLAG_RES_ABORT = 0xAB0u;  // activity flag of a launch that gave up waiting
 constexpr uint32_t RS_MAX_SWEEP = 60000;     // tag = (sweep + 1) << 16 | level
 constexpr uint32_t RS_LEVEL_CAP = 65000;
+constexpr uint32_t RS_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-destination tables) next to ~57 KB static
 
 typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));
 
