@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <exception>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -30,18 +31,29 @@ void parallel_chunks(unsigned n_thr, uint64_t n_items, uint64_t chunk, F&& body)
   std::atomic<uint64_t> next{0};
   std::vector<std::exception_ptr> errs(n_thr);
   std::vector<std::thread> pool;
-  for (unsigned t = 0; t < n_thr; ++t)
-    pool.emplace_back([&, t] {
-      try {
-        for (;;) {
-          const uint64_t b = next.fetch_add(chunk, std::memory_order_relaxed);
-          if (b >= n_items) break;
-          body(t, b, std::min(n_items, b + chunk));
-        }
-      } catch (...) {
-        errs[t] = std::current_exception();
+  auto worker = [&](unsigned t) {
+    try {
+      for (;;) {
+        const uint64_t b = next.fetch_add(chunk, std::memory_order_relaxed);
+        if (b >= n_items) break;
+        body(t, b, std::min(n_items, b + chunk));
       }
-    });
+    } catch (...) {
+      errs[t] = std::current_exception();
+    }
+  };
+  pool.reserve(n_thr);
+  unsigned started = 0;
+  for (; started + 1 < n_thr; ++started) {
+    // a thread that cannot be created (EAGAIN under a process limit) must not leave joinable threads behind: the caller's
+    // thread takes the chunks nobody else will (it always works as the last "thread" anyway)
+    try {
+      pool.emplace_back(worker, started);
+    } catch (const std::system_error&) {
+      break;
+    }
+  }
+  worker(n_thr - 1);
   for (auto& th : pool) th.join();
   for (auto& e : errs)
     if (e) std::rethrow_exception(e);

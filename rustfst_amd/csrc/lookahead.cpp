@@ -494,7 +494,11 @@ bool compute_acyclic_parallel(uint32_t ins, const uint32_t* offsets, const wfst_
     });
   }
   std::vector<std::vector<uint32_t>> finished(n_thr);
-  while (!todo.empty()) {
+  // every round rescans the whole list: depth x |todo| steps.  A long epsilon chain (a million states in a line) would make
+  // that quadratic where the sequential visit is linear: past a few dozen rounds with most of the list still waiting, the
+  // sequential path takes over.
+  for (uint32_t round = 0; !todo.empty(); ++round) {
+    if (round >= 64 && todo.size() > 4096) return false;
     parallel_chunks(n_thr, todo.size(), 1u << 10, [&](unsigned t, uint64_t b, uint64_t e) {
       for (uint64_t i = b; i < e; ++i) {
         const uint32_t s = todo[i];

@@ -127,7 +127,11 @@ __global__ void __launch_bounds__(64) nbest_wave_kernel(const NbProb* __restrict
   // ---- 1. forward distances: the exact (min,+) fixed point (f32 + is monotone: unique whatever the order)
   for (uint32_t s = lane; s < n; s += 64) l_dist[s] = s == (uint32_t)pr.start ? nb_enc(0.0f) : nb_enc(INF);
   __syncthreads();
-  for (;;) {
+  for (uint32_t round = 0;; ++round) {
+    if (round > n + 1u) {  // more rounds than states: only a negative cycle does that (the driver excludes negative weights,
+      if (lane == 0) *out = NbOut{NB_TREE_FULL, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0ull};  // but a wave must never spin): host search
+      return;
+    }
     bool changed = false;
     for (uint32_t s = lane; s < n; s += 64) {
       const float ds = nb_dec(l_dist[s]);
@@ -391,8 +395,9 @@ void shortest_path_nbest_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_
     for (size_t i = 0; i < n; ++i) {
       const wfst_fst* f = fsts[i];
       if (f->n_states == 0 || f->start < 0) continue;  // (trivial: the host path returns the empty FST at once)
-      if (f->n_states > NB_MAX_STATES || f->n_arcs > NB_MAX_ARCS || f->has_negative) continue;
-      ensure_device(const_cast<wfst_fst*>(f));
+      if (f->n_states > NB_MAX_STATES || f->n_arcs > NB_MAX_ARCS) continue;
+      ensure_device(const_cast<wfst_fst*>(f));  // (has_negative is worked out by the upload: a host-only handle reads false before it)
+      if (f->has_negative) continue;
       dev_idx.push_back(i);
       max_n = std::max(max_n, f->n_states);
       max_arcs = std::max<uint32_t>(max_arcs, (uint32_t)f->n_arcs);
@@ -761,7 +766,8 @@ void shortest_path_n1_batch(wfst_ctx* ctx, const wfst_fst* const* fsts, size_t n
   hipStream_t st = ctx->stream;
   std::vector<size_t> idx;
   uint32_t max_n = 0;
-  const bool allow = !std::getenv("WFST_SP1_DEVICE") || std::atoi(std::getenv("WFST_SP1_DEVICE")) != 0;
+  // (a fused batch in flight on this context owns its pinned staging: every input takes the general path then)
+  const bool allow = (!std::getenv("WFST_SP1_DEVICE") || std::atoi(std::getenv("WFST_SP1_DEVICE")) != 0) && !ctx->batch_in_flight;
   for (size_t i = 0; i < n; ++i) {
     const wfst_fst* f = fsts[i];
     outs[i] = nullptr;

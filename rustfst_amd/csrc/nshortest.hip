@@ -688,7 +688,13 @@ wfst_fst* shortest_path_nbest(wfst_ctx* ctx, const wfst_fst* f, uint64_t nshorte
     return make_host_fst(ctx, (uint32_t)ofst.states.size(), ofst.start, ofst.p, std::move(h));
   };
   const uint32_t n = f->n_states;
-  if (f->start < 0 || n == 0) return finish();  // shortest_distance -> [] ; istart check fails -> FO::new()
+  if (f->start < 0 || n == 0) {  // shortest_distance -> [] ; istart check fails -> FO::new()
+    if (unique) {  // the reference determinizes reverse(ifst) whatever its start state is: "expected acceptor" comes first
+      std::unique_ptr<wfst_fst> rf(reverse_fst(ctx, f));
+      if (!(rf->props & props::ACCEPTOR)) throw Error("DeterminizeFsaImpl : expected acceptor as argument");  // determinize_fsa_op.rs:138-140
+    }
+    return finish();
+  }
   // 1. forward distances (GPU relaxation; exact fixed point == the reference's on grid weights)
   const bool timing = std::getenv("WFST_HOST_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -749,7 +755,9 @@ void shortest_path_nbest_unique_batch(wfst_ctx* ctx, const wfst_fst* const* fsts
   for (size_t i = 0; i < n; ++i) {
     const wfst_fst* f = fsts[i];
     outs[i] = nullptr;
-    if (n < 2 || f->start < 0 || f->n_states == 0 || f->n_states > SMALL_FST_MAX_STATES || f->n_arcs > SMALL_FST_MAX_ARCS) continue;
+    if (n < 2 || ctx->batch_in_flight || f->start < 0 || f->n_states == 0 || f->n_states > SMALL_FST_MAX_STATES ||
+        f->n_arcs > SMALL_FST_MAX_ARCS)
+      continue;  // (a fused batch in flight owns the context's pinned staging: one by one then)
     ensure_device(const_cast<wfst_fst*>(f));
     if (f->has_negative) continue;
     idx.push_back(i);
