@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define WFST_ABI_VERSION 4 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
-                             * 4: wfst_stats gained resident_aborts, relax_kernel may be 2 */
+                             * 4: wfst_stats gained resident_aborts, relax_kernel may be 2; wfst_comm_create_host, wfst_gather_records_begin */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
 
@@ -315,6 +315,11 @@ typedef struct wfst_comm wfst_comm;
 wfst_status wfst_comm_unique_id(uint8_t* id /* [WFST_COMM_ID_BYTES] */);
 /* every rank, collectively (ncclCommInitRank): a communicator bound to ctx's GPU with a stream and pinned staging of its own */
 wfst_status wfst_comm_create(wfst_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t world, wfst_comm** out);
+/* The same communicator over a HOST transport: `fn` all-gathers `bytes` bytes per rank between host buffers (recv holds
+ * world * bytes, rank-major) and returns 0 — an MPI_Allgather, a gloo group, a test harness.  No RCCL, no device staging,
+ * the exchange completes inside _begin; staging sets, record layout and the ragged gather are the code of the RCCL path. */
+typedef int (*wfst_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+wfst_status wfst_comm_create_host(uint32_t rank, uint32_t world, wfst_allgather_fn fn, void* user, wfst_comm** out);
 wfst_status wfst_comm_info(const wfst_comm* comm, uint32_t* rank, uint32_t* world);
 wfst_status wfst_comm_destroy(wfst_comm* comm);
 /* All-gather of n linear path FSTs per rank as fixed-size records (layout of wfst_fst_pack_paths).  _begin packs into
@@ -323,6 +328,8 @@ wfst_status wfst_comm_destroy(wfst_comm* comm);
  * One exchange in flight per communicator. */
 wfst_status wfst_gather_paths_begin(wfst_comm* comm, const wfst_fst* const* paths, size_t n, uint32_t max_arcs);
 wfst_status wfst_gather_paths_end(wfst_comm* comm, uint32_t* out /* [world * n * (4 + 4 * max_arcs)] */);
+/* _begin for records that exist already (the table wfst_compose_shortest_path_batch_packed filled): no handles, no packing */
+wfst_status wfst_gather_records_begin(wfst_comm* comm, const uint32_t* records, size_t n, uint32_t max_arcs);
 /* Orders the communicator's stream behind everything queued on ctx's stream so far: the next exchange then runs AFTER
  * that work (a step's relaxation sweeps need every compute unit; the all-gather kernel is better off beside the start of
  * the next step than in the middle of this one).  Optional; without it an exchange starts as soon as it is queued. */

@@ -84,6 +84,8 @@ SYMBOLS = [
      [_vp, _P(_vp), _sz, _vp, _P(ComposeConfig), _P(ShortestPathConfig), _u32, _vp, _P(_u64)]),
     ("wfst_comm_unique_id", C.c_int, [_vp]),
     ("wfst_comm_create", C.c_int, [_vp, _vp, _u32, _u32, _P(_vp)]),
+    ("wfst_comm_create_host", C.c_int, [_u32, _u32, _vp, _vp, _P(_vp)]),
+    ("wfst_gather_records_begin", C.c_int, [_vp, _vp, _sz, _u32]),
     ("wfst_comm_info", C.c_int, [_vp, _P(_u32), _P(_u32)]),
     ("wfst_comm_destroy", C.c_int, [_vp]),
     ("wfst_comm_order_after", C.c_int, [_vp, _vp]),

@@ -82,6 +82,11 @@ struct wfst_comm {
     bool in_flight = false;
   } sets[2];
   hipEvent_t order_ev = nullptr;  // wfst_comm_order_after
+  // host transport (wfst_comm_create_host): the exchange is the caller's all-gather of host buffers (MPI, gloo, a test
+  // harness) — no RCCL, no device, no stream; everything above the transport (staging sets, record layout, ragged
+  // gathers) is the same code
+  wfst_allgather_fn host_fn = nullptr;
+  void* host_user = nullptr;
   int next = 0, pending = -1;
   uint32_t paths_n = 0, paths_max_arcs = 0;  // shape of a wfst_gather_paths_begin in flight
 };
@@ -91,6 +96,17 @@ namespace {
 void set_reserve(wfst_comm* c, wfst_comm::Set& s, size_t bytes) {
   if (bytes <= s.cap) return;
   const size_t cap = std::max<size_t>(bytes, std::max<size_t>(2 * s.cap, 4096));
+  if (c->host_fn) {
+    std::free(s.h_in);
+    std::free(s.h_out);
+    s.h_in = s.h_out = nullptr;
+    s.cap = 0;
+    s.h_in = std::malloc(cap);
+    s.h_out = std::malloc(cap * c->world);
+    if (!s.h_in || !s.h_out) throw Error("out of memory");
+    s.cap = cap;
+    return;
+  }
   if (s.h_in) (void)hipHostFree(s.h_in);
   if (s.h_out) (void)hipHostFree(s.h_out);
   if (s.d_in) (void)hipFree(s.d_in);
@@ -106,6 +122,12 @@ void set_reserve(wfst_comm* c, wfst_comm::Set& s, size_t bytes) {
 
 // queues H2D -> all-gather -> D2H of `bytes` bytes per rank (already in s.h_in) on the communicator's stream
 void queue_exchange(wfst_comm* c, wfst_comm::Set& s, size_t bytes) {
+  if (c->host_fn) {  // (synchronous: the transport returns with every rank's block in place)
+    if (c->host_fn(c->host_user, s.h_in, s.h_out, bytes) != 0) throw Error("wfst_comm: the host transport's all-gather failed");
+    s.bytes = bytes;
+    s.in_flight = true;
+    return;
+  }
   Rccl& r = rccl();
   HIP_CHECK(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, c->stream));
   rccl_check(r.AllGather(s.d_in, s.d_out, bytes, /*ncclInt8*/ 0, c->comm, c->stream), "ncclAllGather");
@@ -125,7 +147,7 @@ wfst_comm::Set& begin_set(wfst_comm* c, size_t bytes) {
 const void* end_set(wfst_comm* c, size_t* bytes) {
   if (c->pending < 0) throw Error("wfst_comm: no exchange in flight");
   wfst_comm::Set& s = c->sets[c->pending];
-  HIP_CHECK(hipEventSynchronize(s.done));
+  if (!c->host_fn) HIP_CHECK(hipEventSynchronize(s.done));
   s.in_flight = false;
   c->pending = -1;
   *bytes = s.bytes;
@@ -165,6 +187,19 @@ wfst_status wfst_comm_create(wfst_ctx* ctx, const uint8_t* id, uint32_t rank, ui
   });
 }
 
+wfst_status wfst_comm_create_host(uint32_t rank, uint32_t world, wfst_allgather_fn fn, void* user, wfst_comm** out) {
+  return wrap([&] {
+    if (!fn || !out) throw Error("null pointer");
+    if (world == 0 || rank >= world) throw Error("wfst_comm_create_host: rank out of range");
+    auto c = std::make_unique<wfst_comm>();
+    c->rank = rank;
+    c->world = world;
+    c->host_fn = fn;
+    c->host_user = user;
+    *out = c.release();
+  });
+}
+
 wfst_status wfst_comm_info(const wfst_comm* comm, uint32_t* rank, uint32_t* world) {
   return wrap([&] {
     if (!comm) throw Error("null comm");
@@ -176,6 +211,14 @@ wfst_status wfst_comm_info(const wfst_comm* comm, uint32_t* rank, uint32_t* worl
 wfst_status wfst_comm_destroy(wfst_comm* c) {
   return wrap([&] {
     if (!c) return;
+    if (c->host_fn) {
+      for (auto& s : c->sets) {
+        std::free(s.h_in);
+        std::free(s.h_out);
+      }
+      delete c;
+      return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
@@ -195,6 +238,7 @@ wfst_status wfst_comm_destroy(wfst_comm* c) {
 wfst_status wfst_comm_order_after(wfst_comm* c, wfst_ctx* ctx) {
   return wrap([&] {
     if (!c || !ctx) throw Error("null pointer");
+    if (c->host_fn) return;  // (a host transport queues nothing on a stream)
     if (ctx->device != c->device) throw Error("wfst_comm_order_after: the context lives on another GPU");
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->order_ev) HIP_CHECK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
@@ -206,7 +250,7 @@ wfst_status wfst_comm_order_after(wfst_comm* c, wfst_ctx* ctx) {
 wfst_status wfst_comm_allgather_begin(wfst_comm* c, const void* send, size_t bytes) {
   return wrap([&] {
     if (!c || (bytes && !send)) throw Error("null pointer");
-    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->host_fn) HIP_CHECK(hipSetDevice(c->device));
     wfst_comm::Set& s = begin_set(c, std::max<size_t>(bytes, 1));
     if (bytes) std::memcpy(s.h_in, send, bytes);
     queue_exchange(c, s, bytes);
@@ -228,7 +272,7 @@ wfst_status wfst_comm_allgather_end(wfst_comm* c, void* recv) {
 wfst_status wfst_gather_paths_begin(wfst_comm* c, const wfst_fst* const* paths, size_t n, uint32_t max_arcs) {
   return wrap([&] {
     if (!c || (n && !paths)) throw Error("null pointer");
-    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->host_fn) HIP_CHECK(hipSetDevice(c->device));
     const size_t bytes = n * (4 + 4 * (size_t)max_arcs) * sizeof(uint32_t);
     wfst_comm::Set& s = begin_set(c, std::max<size_t>(bytes, 1));
     // the records are packed straight into the pinned send buffer (same layout as wfst_fst_pack_paths)
@@ -239,6 +283,21 @@ wfst_status wfst_gather_paths_begin(wfst_comm* c, const wfst_fst* const* paths, 
       if (msg) (void)wfst_string_destroy(msg);
       throw Error(m);
     }
+    queue_exchange(c, s, bytes);
+    c->pending = c->next;
+    c->next ^= 1;
+    c->paths_n = (uint32_t)n;
+    c->paths_max_arcs = max_arcs;
+  });
+}
+
+wfst_status wfst_gather_records_begin(wfst_comm* c, const uint32_t* records, size_t n, uint32_t max_arcs) {
+  return wrap([&] {
+    if (!c || (n && !records)) throw Error("null pointer");
+    if (!c->host_fn) HIP_CHECK(hipSetDevice(c->device));
+    const size_t bytes = n * (4 + 4 * (size_t)max_arcs) * sizeof(uint32_t);
+    wfst_comm::Set& s = begin_set(c, std::max<size_t>(bytes, 1));
+    if (bytes) std::memcpy(s.h_in, records, bytes);
     queue_exchange(c, s, bytes);
     c->pending = c->next;
     c->next ^= 1;
@@ -262,7 +321,7 @@ wfst_status wfst_gather_paths_end(wfst_comm* c, uint32_t* out) {
 wfst_status wfst_comm_allgatherv(wfst_comm* c, const void* send, size_t bytes, uint64_t* sizes, void** recv, size_t* total) {
   return wrap([&] {
     if (!c || (bytes && !send) || !sizes || !recv || !total) throw Error("null pointer");
-    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->host_fn) HIP_CHECK(hipSetDevice(c->device));
     uint64_t mine = bytes;
     {
       wfst_comm::Set& s = begin_set(c, sizeof(uint64_t));

@@ -174,6 +174,60 @@ class Comm:
                 pass
             self._h = None
 
+    @classmethod
+    def from_host_transport(cls, rank: int, world: int, allgather) -> "Comm":
+        """The library's communicator over a HOST all-gather (wfst_comm_create_host): `allgather(send, recv)` gets two
+        uint8 numpy views (bytes of this rank / world * bytes, rank-major) and fills `recv`.  No GPU, no RCCL: MPI or gloo
+        deployments, and the CPU tests of the exchange code (staging sets, record layout, ragged gathers)."""
+        import ctypes as C
+
+        from . import _lib
+
+        def _cb(_user, send, recv, nbytes):
+            try:
+                s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[:int(nbytes)]
+                r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(max(int(nbytes) * world, 1),))[:int(nbytes) * world]
+                allgather(s, r)
+                return 0
+            except Exception:  # (an exception must not cross the C frame)
+                return 1
+
+        self = cls.__new__(cls)
+        self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)(_cb)  # kept alive with the object
+        h = C.c_void_p()
+        _lib.check(_lib.lib().wfst_comm_create_host(rank, world, C.cast(self._cb, C.c_void_p), None, C.byref(h)), "wfst_comm_create_host")
+        self._h, self.ctx, self.rank, self.world = h, None, rank, world
+        self._shape = None
+        return self
+
+    @classmethod
+    def from_torch_group_host(cls) -> "Comm":
+        """Host transport over torch.distributed's default group (gloo): the CPU counterpart of from_torch_group."""
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def allgather(send, recv):
+            t = torch.from_numpy(np.ascontiguousarray(send))
+            out = torch.empty(world * max(t.numel(), 1), dtype=torch.uint8)[:world * t.numel()]
+            if t.numel():
+                dist.all_gather_into_tensor(out, t)
+                recv[...] = out.numpy()
+
+        return cls.from_host_transport(rank, world, allgather)
+
+    def gather_records_begin(self, records: np.ndarray, max_arcs: int):
+        """gather_paths_begin for records that exist already ([n, 4 + 4 * max_arcs] uint32: pack_paths, or the table of
+        compose_shortest_path_batch_packed): no handles, no packing."""
+        from . import _lib
+        r = np.ascontiguousarray(records, dtype=np.uint32)
+        n = r.shape[0]
+        if r.ndim != 2 or r.shape[1] != 4 + 4 * max_arcs:
+            raise ValueError("records must be [n, 4 + 4 * max_arcs] uint32")
+        _lib.check(_lib.lib().wfst_gather_records_begin(self._h, r.ctypes.data, n, max_arcs), "wfst_gather_records_begin")
+        self._shape = (n, 4 + 4 * max_arcs)
+
     @staticmethod
     def unique_id() -> bytes:
         import ctypes as C

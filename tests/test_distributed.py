@@ -193,6 +193,89 @@ def test_broadcast_workload_gloo_world2():
     assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, "ok"), (1, "ok")]
 
 
+def _worker_cabi(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from oracle import oracle_py
+    from rustfst_amd import dist as wdist
+    from rustfst_amd import synth
+    from rustfst_amd._lib import WfstError
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = wdist.Comm.from_torch_group_host()  # wfst_comm_create_host: the library's exchange code over gloo
+        ok = (comm.rank, comm.world) == (rank, world)
+        t = synth.make_transducer(400, 6, 16, 0.05, seed=17)
+        accs = synth.make_acceptors(t, n_total, 10, seed0=300)
+        ot = oracle_py.OracleFst.from_flat(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"])
+
+        def solve(i):
+            a = accs[i]
+            oa = oracle_py.OracleFst.from_flat(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"])
+            return oa.compose(ot).shortest_path_canonical().to_flat()
+
+        mine = wdist.shard_indices(n_total, rank, world)
+        n_local = (n_total + world - 1) // world
+        max_arcs = 10 + 8
+        packed = wdist.pack_paths([solve(i) for i in mine], max_arcs)
+        if packed.shape[0] < n_local:
+            packed = np.concatenate([packed, np.zeros((n_local - packed.shape[0], packed.shape[1]), np.uint32)])
+        # 1. records -> wfst_gather_records_begin / wfst_gather_paths_end: rank-major layout, interleave restores global order
+        comm.gather_records_begin(packed, max_arcs)
+        try:  # one exchange in flight per communicator
+            comm.gather_records_begin(packed, max_arcs)
+            ok = False
+        except WfstError:
+            pass
+        g = comm.gather_paths_end()
+        ok &= g.shape == (world,) + packed.shape and np.array_equal(g[rank], packed)
+        allp = wdist.unpack_paths(wdist.interleave(g, n_total))
+        for i in range(n_total):
+            exp = solve(i)
+            ok &= allp[i]["n_states"] == exp["n_states"] and np.array_equal(allp[i]["arcs"], exp["arcs"])
+            ok &= np.array_equal(allp[i]["finals"], exp["finals"])
+        # 2. the two staging sets alternate and grow: exchanges of different sizes back to back, each rank's block in its slot
+        for rep, words in enumerate((3, 5000, 7, 20000, 1)):
+            blk = (np.arange(words, dtype=np.uint32) * (rank + 1) + rep).reshape(1, words)
+            got = comm.allgather(blk)
+            ok &= got.shape == (world, 1, words)
+            for r in range(world):
+                ok &= np.array_equal(got[r, 0], np.arange(words, dtype=np.uint32) * (r + 1) + rep)
+        # 3. ragged: wfst_comm_allgatherv (sizes, then payloads padded to the largest rank), empty contributions
+        blobs = [bytes([rank + 1]) * (100 * (k + 1) + 37 * rank) for k in range(2 + 3 * rank)]
+        got = comm.gather_fsts(blobs)
+        ok &= len(got) == world and got[rank] == blobs
+        for r in range(world):
+            ok &= got[r] == [bytes([r + 1]) * (100 * (k + 1) + 37 * r) for k in range(2 + 3 * r)]
+        ok &= comm.gather_fsts([] if rank == 0 else [b"x" * 9]) == [[]] + [[b"x" * 9] for _ in range(world - 1)]
+        ok &= comm.gather_fsts([]) == [[] for _ in range(world)]
+        comm.order_after(None) if False else None  # (a host transport has no stream: nothing to order)
+        q.put((rank, "ok" if ok else "mismatch"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_c_abi_exchange_over_gloo_world2(n_total):
+    """The exchange code behind the C-ABI (csrc/gather.cpp: staging sets, rank-major records, `one exchange in flight`,
+    the two-step ragged gather) at world = 2 without RCCL: wfst_comm_create_host runs it over a host all-gather (gloo
+    here).  Records of sharded oracle results come back in global order and equal the one-process answers; exchanges of
+    growing and shrinking sizes alternate between the two sets; ragged and empty contributions keep their rank slots."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cabi, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
 @pytest.mark.gpu
 def test_rccl_single_rank_gather_of_hip_results():
     """The N > 1 plumbing on the hardware that exists here: a 1-rank nccl (= RCCL) process group carries the results of the
