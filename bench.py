@@ -13,7 +13,9 @@ S1 and S2 are independent requests: S2 is enqueued first, asynchronously, on a s
 (its single long kernel uses one wave per acceptor), S1 then runs on the first stream and overlaps with it,
 and S2's results are collected last (--serial runs them back to back on one stream instead).
 Acceptor i of the global batch (B x N acceptors) lives on rank i mod N (weak scaling: per-GPU work is
-fixed); T is replicated; no collective during compute.
+fixed); T is replicated; no collective during compute.  At N > 1 the S1 query of rank r is the single-source solve from
+rank r's own start state of T (distinct queries on the replicated T, never N copies of one solve); `batch_only` in the
+line carries the sharded batch's own rate (acceptors/s, us per compose->shortest_path), the figure that scales.
 value = arcs/s over the whole job, arcs per rank-step = E(T) [each arc of T relaxed at least once]
         + E_composed (arcs emitted by compose before trim) + E_relaxed on the composed FSTs (== E_composed).
 
@@ -256,9 +258,17 @@ def main():
         if not args.no_extras:  # the acceptors of the batch_sweep extra: generated BEFORE T is uploaded (make_acceptors
             # marks the walks' end states final in T: the device copy and the CPU baseline must see the same T)
             sweep_accs = synth.make_acceptors(t, SWEEP_MAX, args.acc_len, seed0=50_000)
-    dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+    # Several GPUs: every rank holds T.  The unit that scales is the (acceptor, T) problem; the direct shortest_path(T) of a
+    # step is a DIFFERENT query on every rank — the single-source solve from rank r's own start state (T is strongly
+    # connected: every start reaches everything) — so the arcs summed over the ranks are arcs of distinct work, never N
+    # copies of one solve.  Rank 0's query is the 1-GPU one.
+    s1_start = int(t["start"]) if world == 1 else int((int(t["start"]) + rank * 104729) % int(t["n_states"]))
+    dt = rustfst_amd.DeviceFst.from_arrays(t["n_states"], s1_start, t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
     daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([accs_all[i] for i in mine], ctx2))
-    dt2 = dt  # T is read-only for both pipelines: one HBM copy serves both contexts
+    # T is read-only for both pipelines: one HBM copy serves both contexts — except where this rank's S1 query starts
+    # elsewhere (the acceptors are walks from T's own start state: the compositions need T as it is)
+    dt2 = dt if s1_start == int(t["start"]) else rustfst_amd.DeviceFst.from_arrays(
+        t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
     e_t = int(t["offsets"][-1])
     gen_s = time.time() - t0
 
@@ -324,6 +334,7 @@ def main():
         os.remove(f_out)
 
     last = {}
+    batch_arcs = [0]  # composed + relaxed arcs of the batch legs only (what scales with the number of GPUs)
     phases = [0.0, 0.0, 0.0, 0.0, 0]  # host seconds in: first begin, second begin, batch finish, shortest_path finish; steps
 
     # the result exchange runs inside libwfst_amd (wfst_comm_* / wfst_gather_paths_*: its own RCCL communicator, stream and
@@ -374,6 +385,7 @@ def main():
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
         if (world > 1 or force_dist) and not args.overlap:
             exchange(outs)
+        batch_arcs[0] += 2 * n_arcs
         return e_t + 2 * n_arcs
 
     def drain():
@@ -405,6 +417,7 @@ def main():
         barrier()
         t_start = time.perf_counter()
         arcs = 0
+        batch_arcs[0] = 0
         step_s = np.empty(args.steps, dtype=np.float64)  # host clock per step (a step ends with both results on the host)
         prev = t_start
         for k in range(args.steps):
@@ -426,9 +439,9 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-            ta = torch.tensor([arcs], dtype=torch.int64, device=device)
+            ta = torch.tensor([arcs, batch_arcs[0]], dtype=torch.int64, device=device)
             dist.all_reduce(ta, op=dist.ReduceOp.SUM)
-            arcs = int(ta.item())
+            arcs, batch_arcs[0] = int(ta[0].item()), int(ta[1].item())
 
         # ------------------------------------------------------------------ per-part times (untimed extra pass)
         # each request ALONE on its own context, host clock around the synchronous call (3 repetitions, best)
@@ -663,6 +676,16 @@ def main():
         if world > 1 or force_dist:
             import torch.distributed as dist
             rccl_world = dist.get_world_size()
+            assert rccl_world == world and comm.world == world, "the RCCL communicator does not span --gpus ranks"
+        # the figure that scales with the number of GPUs: the sharded batch alone (acceptor i on rank i mod N)
+        batch_only = {
+            "acceptors_per_s": round(n_total * args.steps / elapsed, 1),
+            "us_per_compose_shortest_path": round(1e6 * elapsed / max(1, n_total * args.steps), 4),
+            "batch_arcs_per_s": round(batch_arcs[0] / elapsed, 1),
+            "note": "global batch (acceptors on all ranks) per timed second of the overlapped step; the direct shortest_path(T) "
+                    "of a step is one single-source query per rank (rank r: start state (start + 104729 r) mod N): distinct work, "
+                    "counted in `value`, not in these",
+        }
         ms = 1e3 * step_s
         out = {
             "metric": "arcs relaxed/sec (compose -> shortest_path, 1M-state / 10M-arc FST)",
@@ -672,7 +695,8 @@ def main():
                                   "p50": round(float(np.percentile(ms, 50)), 4), "p99": round(float(np.percentile(ms, 99)), 4),
                                   "timed_seconds": round(elapsed, 3), "clock": "host perf_counter per step on rank 0"},
             "step_host_phases_us": step_phases_us,
-            "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist),
+            "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist), "batch_only": batch_only,
+            "s1_start_states": "T's own" if world == 1 else f"rank r: ({int(t['start'])} + 104729 r) mod {int(t['n_states'])}",
             "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
