@@ -73,3 +73,44 @@ def assert_flat_identical(a, b, what="", check_props=True):
                                   err_msg=f"{what}: final weights (bit pattern)")
     if check_props:
         assert a["props"] == b["props"], f"{what}: props {a['props']:#x} != {b['props']:#x}"
+
+
+def enumerate_paths(flat, max_paths=200_000):
+    """Every complete path (start -> a final state) of an ACYCLIC flat FST by exhaustive depth-first enumeration:
+    [(total weight as float64 of left-folded f32 sums, (ilabels...), (olabels...))].  Independent of the oracle and of
+    the library: the brute force the n-best results are checked against."""
+    if flat["start"] is None or flat["n_states"] == 0:
+        return []
+    off, arcs, fin = flat["offsets"], flat["arcs"], flat["finals"]
+    out = []
+
+    def rec(s, w, il, ol):
+        if len(out) > max_paths:
+            raise RuntimeError("too many paths for the brute force")
+        if np.isfinite(fin[s]):
+            out.append((float(np.float32(w) + np.float32(fin[s])), tuple(il), tuple(ol)))
+        for a in arcs[off[s]:off[s + 1]]:
+            rec(int(a["nextstate"]), np.float32(np.float32(w) + np.float32(a["weight"])), il + [int(a["ilabel"])], ol + [int(a["olabel"])])
+
+    rec(int(flat["start"]), np.float32(0.0), [], [])
+    return out
+
+
+def check_nbest_against_brute_force(result_flat, input_flat, n, what=""):
+    """`result_flat` = shortest_path(nshortest = n) of the ACYCLIC `input_flat`: it must hold exactly min(n, #paths)
+    complete paths, each a real path of the input (same label strings once epsilons are removed, same weight), and their
+    weights must be the n smallest path weights of the input (as a multiset: ties may pick either path)."""
+    def strip(t):
+        return tuple(x for x in t if x != 0)
+    brute = enumerate_paths(input_flat)
+    got = enumerate_paths(result_flat)
+    assert len(got) == min(n, len(brute)), f"{what}: {len(got)} paths in the result, {len(brute)} in the input, n = {n}"
+    want_w = sorted(w for w, _, _ in brute)[:len(got)]
+    np.testing.assert_allclose(sorted(w for w, _, _ in got), want_w, rtol=0, atol=1e-4, err_msg=f"{what}: the n smallest weights")
+    have = {}
+    for w, il, ol in brute:
+        have.setdefault((strip(il), strip(ol)), []).append(w)
+    for w, il, ol in got:
+        ws = have.get((strip(il), strip(ol)))
+        assert ws is not None, f"{what}: the result holds a string the input does not accept: {il} / {ol}"
+        assert min(abs(w - x) for x in ws) <= 1e-4, f"{what}: path {il} has weight {w}, the input gives {ws}"

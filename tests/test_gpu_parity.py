@@ -806,6 +806,49 @@ def test_nshortest_batch_wave_kernel_vs_oracle(gpu_ctx, oracle, device, monkeypa
         assert_flat_identical(g.to_flat(), to_oracle(oracle, f).shortest_path_canonical().to_flat(), "batch n=1")
 
 
+def test_k13_nshortest_hand_traced_known_answers(gpu_ctx):
+    """n = 2, 3 on the K2 graph against the answers traced by hand through the reference's source
+    (tests/golden/K13_DERIVATION.md, shortest_path.rs:409-518): the tie between 0-2-3 and 0-1-1-3 resolved as the
+    reference's heap resolves it — through the single call (host search) and through the batch call (wave kernel)."""
+    g = golden("k13_nshortest_k2.json")
+    d = vbuild(g["fst"]).to_device()
+    from test_oracle import flat_matches_spec
+    for n, key in ((2, "n2"), (3, "n3")):
+        flat_matches_spec(d.shortest_path(ShortestPathConfig(nshortest=n)).to_flat(), g[key])
+        both = rustfst_amd.shortest_path_batch([d, d], ShortestPathConfig(nshortest=n))
+        assert int(rustfst_amd.default_context().stats()["nbest_device_problems"]) == 2
+        for o in both:
+            flat_matches_spec(o.to_flat(), g[key])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nshortest_host_search_vs_wave_kernel_vs_brute_force(gpu_ctx, seed, monkeypatch):
+    """Evidence for the n-best code that does not pass through the oracle: the host heap search (nshortest.hip, what large
+    inputs take) and the wave kernel (nbest_batch.hip: an independent implementation of shortest_path.rs:409-518 on the
+    device) return bit-identical FSTs on the same inputs — acyclic and cyclic, with ties —, and on the acyclic ones both
+    hold exactly the n lightest paths of an exhaustive enumeration written in Python (tests/helpers.py)."""
+    from helpers import check_nbest_against_brute_force
+    rng = np.random.default_rng(5200 + seed)
+    flats = []
+    for k in range(10):
+        flats.append(random_fst_flat(rng, int(rng.integers(3, 13 if k < 6 else 50)), 3, 4, p_eps_i=0.15, p_final=0.35, min_fanout=1,
+                                     acyclic=k < 6, weight_grid=4 if k % 2 else 512, max_w=12 if k % 2 else 2560))
+    devs = [to_device(f) for f in flats]
+    ctx = rustfst_amd.default_context()
+    for n in (2, 5):
+        cfg = ShortestPathConfig(nshortest=n)
+        monkeypatch.setenv("WFST_NBEST_DEVICE", "1")
+        wave = [o.to_flat() for o in rustfst_amd.shortest_path_batch(devs, cfg)]
+        assert int(ctx.stats()["nbest_device_problems"]) == len(flats)
+        monkeypatch.setenv("WFST_NBEST_DEVICE", "0")
+        host = [o.to_flat() for o in rustfst_amd.shortest_path_batch(devs, cfg)]
+        assert int(ctx.stats()["nbest_device_problems"]) == 0
+        for k, (f, w, h) in enumerate(zip(flats, wave, host)):
+            assert_flat_identical(w, h, f"seed {seed} input {k} n={n}: wave kernel vs host search")
+            if k < 6:
+                check_nbest_against_brute_force(w, f, n, f"seed {seed} input {k} n={n}")
+
+
 @pytest.mark.parametrize("lazy", ["0", "1"], ids=["reverse_on_host", "reverse_in_hbm"])
 def test_nshortest_on_transducer_and_lattice(gpu_ctx, oracle, lazy, monkeypatch):
     monkeypatch.setenv("WFST_NBEST_LAZY", lazy)

@@ -77,6 +77,29 @@ def test_k2_shortest_path_known_answer(oracle):
     assert spc.n_tied_choices == 0
 
 
+# ---------------------------------------------------------------- K13: hand-traced n_shortest_path (shortest_path.rs:409-518)
+def test_k13_nshortest_known_answers(oracle):
+    """n = 2 and n = 3 on the K2 graph, traced by hand through the reference's source (tests/golden/K13_DERIVATION.md):
+    the second-best path TIES (0-2-3 and 0-1-1-3 both weigh 11) and the reference's heap returns the loop path first —
+    state numbering, arc order, weights and which tied path comes first are all pinned."""
+    g = load_golden("k13_nshortest_k2.json")
+    f = build(oracle, g["fst"])
+    flat_matches_spec(f.shortest_path_n(2).to_flat(), g["n2"])
+    flat_matches_spec(f.shortest_path_n(3).to_flat(), g["n3"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nshortest_against_independent_brute_force(oracle, seed):
+    """The oracle's n-best results against an exhaustive enumeration written independently of it (tests/helpers.py): the
+    right number of paths, every one a path of the input, their weights the n smallest."""
+    from helpers import check_nbest_against_brute_force
+    rng = np.random.default_rng(9100 + seed)
+    flat = random_fst_flat(rng, int(rng.integers(3, 13)), 3, 4, p_eps_i=0.15, p_final=0.35, min_fanout=1, acyclic=True,
+                           weight_grid=4 if seed % 2 else 512, max_w=12 if seed % 2 else 2560)
+    for n in (1, 2, 4, 9):
+        check_nbest_against_brute_force(to_oracle(oracle, flat).shortest_path_n(n).to_flat(), flat, n, f"seed {seed} n={n}")
+
+
 # ---------------------------------------------------------------- K12: determinize_static.rs:210-270
 def test_k12_determinize_known_answers(oracle):
     """The reference's two known answers for `determinize` of a tropical acceptor (DeterminizeFsa, default common divisor,
