@@ -179,7 +179,8 @@ struct RevCsr {
 // Message-region plan of the mailbox relaxation sweeps (sssp_mailbox.h): offsets of the region reserved for every
 // (source block, destination block) pair, sized by the number of arcs between the two blocks.
 struct MboxPlan {
-  uint32_t nb = 0;         // blocks of 4096 states
+  uint32_t nb = 0;         // blocks of 1 << log states
+  uint32_t log = 12;
   DBuf<uint32_t> roff;     // [nb*nb + 1] destination-major
   DBuf<uint32_t> roff_t;   // [nb*nb]     source-major copy
   // regions of the resident kernel (sssp_resident.h): 16-byte header + one slot per arc, 64-byte aligned, in 8-byte units
@@ -225,6 +226,7 @@ struct wfst_fst {
   mutable std::shared_ptr<wfst::RevCsr> rev_dev;
   // region plan of the mailbox relaxation sweeps; depends on (source, target) pairs only, built on first use
   mutable std::shared_ptr<wfst::MboxPlan> mbox;
+  mutable std::shared_ptr<wfst::MboxPlan> mbox13;  // the same with blocks of 8192 states (resident launches of 1M .. 2M-state FSTs)
   // a linear, epsilon-free, single-final acceptor ("string": utils::acceptor, labels_to_fst.rs:111-132), detected at
   // upload from the host arrays; such an fst1 takes the specialised string o T kernel of the fused batch
   bool is_string = false;

@@ -861,6 +861,8 @@ struct Solve {
   bool force_big = false;    // tests: the many-blocks variant of the kernel on a small FST (WFST_SSSP_BIG=1)
   // resident launches (sssp_resident.h): the WIDE levels of the solve inside ONE launch, every workgroup on a CU of its own
   bool resident = false;
+  uint32_t log = 12;         // log2 of the block size (13: every launch of the solve is a resident one)
+  size_t res_dyn = 0;        // dynamic LDS bytes of a resident launch
   DBuf<uint2> rs_msgs;       // two parity buffers of plan->res_units entries
   DBuf<uint32_t> rs_abort;   // one word
   DBuf<unsigned long long> rs_trace;  // WFST_SSSP_RES_TRACE=<file>: per-level stamps
@@ -881,19 +883,22 @@ bool mbox_eligible(const wfst_fst* f) {
 
 // Region plan of the mailbox sweeps: arcs between every pair of blocks, scanned into region offsets.  Depends only on
 // the (source, target) pairs of the arcs, so tr_sort leaves it valid; cached on the handle (owner's pool).
-std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
+std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f, uint32_t log) {
   std::lock_guard<std::mutex> lk(f->cache_mu);
-  if (f->mbox) return f->mbox;
-  const uint32_t n = f->n_states, nb = (n + MB_B - 1) >> MB_LOG;
+  std::shared_ptr<MboxPlan>& slot = log == 13 ? f->mbox13 : f->mbox;
+  if (slot) return slot;
+  const uint32_t n = f->n_states, nb = (uint32_t)(((uint64_t)n + (1u << log) - 1) >> log);
   hipStream_t st = ctx->stream;
   DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;
   auto p = std::make_shared<MboxPlan>();
   p->nb = nb;
+  p->log = log;
   const size_t cells = (size_t)nb * nb;
   p->roff = DBuf<uint32_t>(owner_pool, cells + 1);
   p->roff_t = DBuf<uint32_t>(owner_pool, cells);
   DBuf<uint32_t> hist(*ctx->pool, cells + 1);
-  mbox_hist_kernel<<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
+  if (log == 13) mbox_hist_kernel<13><<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
+  else mbox_hist_kernel<12><<<nb, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, nb, hist.p);
   HIP_CHECK(hipMemsetAsync(hist.p + cells, 0, sizeof(uint32_t), st));
   size_t temp_bytes = 0;
   HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
@@ -915,7 +920,7 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f) {
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(st));  // hist / temp are released here
-  f->mbox = p;
+  slot = p;
   return p;
 }
 
@@ -938,10 +943,15 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
     // resident launches take the odd slots: slot 0 is the head of the search (NARROW), a resident launch runs every WIDE
     // level that follows and the hand-over, the next slot is the NARROW launch that drains the search; whichever kernel
     // finds another mode in its slot does that mode's work (the two kernels leave the same state behind)
-    if (sv.resident && !profile && (abs_sweep & 1u) && abs_sweep < RS_MAX_SWEEP)
-      sssp_mbox_resident_kernel<<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
-                                                                         sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
-                                                                         sv.narrow_t, sv.res_max_levels);
+    if (sv.log == 13) {  // (blocks of 8192 states exist in the resident kernel only: it also runs the NARROW launches of such a solve)
+      if (abs_sweep >= RS_MAX_SWEEP) throw Error("shortest_path: relaxation did not converge");
+      sssp_mbox_resident_kernel<13><<<sv.mv.nb, MB_THREADS, sv.res_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
+                                                                             sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
+                                                                             sv.narrow_t, sv.res_max_levels);
+    } else if (sv.resident && !profile && (abs_sweep & 1u) && abs_sweep < RS_MAX_SWEEP)
+      sssp_mbox_resident_kernel<12><<<sv.mv.nb, MB_THREADS, sv.res_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
+                                                                             sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
+                                                                             sv.narrow_t, sv.res_max_levels);
     else if (sv.mv.nb > MB_NBMAX || sv.force_big)
       sssp_mbox_kernel<true><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
                                                                       sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
@@ -991,18 +1001,47 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   bool want_mbox = delta < INF && mbox_eligible(f) && ((n + MB_B - 1) >> MB_LOG) <= MB_NB_DEFAULT;
   int mbox_mode = want_mbox ? 1 : 0;
   if (const char* e = std::getenv("WFST_SSSP_MAILBOX")) mbox_mode = mbox_eligible(f) ? std::atoi(e) : 0;
+  // Resident launches (sssp_resident.h) need every block on a CU of its own for the whole launch, and only one such solve
+  // runs per device at a time: the lease is taken first, because it decides the block size — 4096 states, or 8192 for the
+  // FSTs of 1M .. 2M states that then still fit one block per CU (every launch of such a solve is a resident one).
+  bool want_res = false;
+  sv.log = 12;
+  sv.lease.release();
+  if (mbox_mode >= 1) {
+    int want = 1;
+    if (const char* e = std::getenv("WFST_SSSP_RESIDENT")) want = std::atoi(e);
+    const bool big_env = std::getenv("WFST_SSSP_BIG") && std::atoi(std::getenv("WFST_SSSP_BIG")) != 0;
+    const uint32_t cus = (uint32_t)std::min<int>(ctx->n_cus, (int)MB_NBMAX);
+    const uint32_t nb12 = (n + 4095u) >> 12, nb13 = (uint32_t)(((uint64_t)n + 8191u) >> 13);
+    uint32_t log = 0;
+    if (nb12 <= cus) log = 12;
+    else if (nb13 <= cus && !std::getenv("WFST_SSSP_LOG12")) log = 13;
+    if (want && log && !ctx->profiling && !ctx->resident_off && !big_env && sv.lease.acquire(ctx->device)) {
+      want_res = true;
+      sv.log = log;
+    }
+  }
   if (mbox_mode >= 1) {
     // Two message buffers of one slot per arc, the nb^2 region tables and counts come from the pool: on a tight pool (or a
     // dense graph) the atomic sweeps, which need none of it, run instead.
     try {
-      sv.plan = mbox_plan(ctx, f);
+      sv.plan = mbox_plan(ctx, f, sv.log);
       const uint32_t nb = sv.plan->nb;
       sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
-      const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
+      const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * ((1u << sv.log) / 32);
       sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 4 * nb);
-      sv.mb_wl = DBuf<uint4>(pool, (size_t)nb * NW_SEG);
+      sv.mb_wl = DBuf<uint4>(pool, (size_t)nb << sv.log);
+      if (want_res) {
+        sv.rs_msgs = DBuf<uint2>(pool, 2 * (size_t)sv.plan->res_units);
+        sv.rs_abort = DBuf<uint32_t>(pool, 16);
+      }
       sv.mbox = true;
     } catch (const Error&) {
+      if (sv.log == 13) throw;  // (a pool too tight for the 8192-state plan: the caller's next solve takes the default path)
+      want_res = false;
+      sv.rs_msgs.reset();
+      sv.rs_abort.reset();
+      sv.lease.release();
       sv.plan.reset();
       sv.mb_msgs.reset();
       sv.mb_words.reset();
@@ -1012,7 +1051,7 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   }
   if (sv.mbox) {
     const uint32_t nb = sv.plan->nb;
-    const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * (MB_B / 32);
+    const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * ((1u << sv.log) / 32);
     MboxView& mv = sv.mv;
     mv.roff = sv.plan->roff.p;
     mv.roff_t = sv.plan->roff_t.p;
@@ -1063,21 +1102,22 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     // per-sweep profiler (it times launches), not after a launch of this context gave up waiting.
     sv.resident = false;
     sv.rv = ResView{};
+    sv.res_dyn = 0;
     {
-      int want = 1;
-      if (const char* e = std::getenv("WFST_SSSP_RESIDENT")) want = std::atoi(e);
       const uint64_t bytes = sv.plan->res_units * sizeof(uint2);
-      if (want && !ctx->profiling && !ctx->resident_off && !sv.force_big && nb <= MB_NBMAX && nb <= (uint32_t)ctx->n_cus &&
-          sv.plan->res_units != 0 && bytes < 0x7FFFFFF0ull && sv.mb_dyn <= RS_DYN_BUDGET && sv.lease.acquire(ctx->device)) {
-        try {
-          sv.rs_msgs = DBuf<uint2>(pool, 2 * (size_t)sv.plan->res_units);
-          sv.rs_abort = DBuf<uint32_t>(pool, 16);
-          sv.resident = true;
-        } catch (const Error&) {
-          sv.rs_msgs.reset();
-          sv.rs_abort.reset();
-          sv.lease.release();
-        }
+      constexpr size_t LDS_BYTES = 160u * 1024u;
+      const size_t fixed = res_lds_bytes(sv.log, nb, 0);
+      const uint32_t stg_res = fixed + 8u * nb <= LDS_BYTES ? (uint32_t)std::min<size_t>(MB_STG_MAX, (LDS_BYTES - fixed) / (8u * nb)) : 0u;
+      if (want_res && !sv.force_big && sv.plan->res_units != 0 && bytes < 0x7FFFFFF0ull && stg_res >= 4 && sv.rs_msgs.p) {
+        sv.resident = true;
+        mv.stg = std::min(mv.stg, stg_res);
+        sv.mb_dyn = (size_t)nb * mv.stg * sizeof(uint2) + 3u * (size_t)nb * sizeof(uint32_t);
+        sv.res_dyn = res_lds_bytes(sv.log, nb, mv.stg);
+      } else {
+        if (sv.log == 13) throw Error("shortest_path: internal error (the 8192-state plan without a resident launch)");
+        sv.rs_msgs.reset();
+        sv.rs_abort.reset();
+        sv.lease.release();
       }
       if (sv.resident) {
         ResView& rv = sv.rv;
@@ -1103,13 +1143,19 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
         if (!std::getenv("WFST_SSSP_NARROW")) sv.narrow_t = 16384;
         static std::once_flag res_once[64];
         std::call_once(res_once[(unsigned)ctx->device & 63u], [] {
-          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_DYN_BUDGET));
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_resident_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_resident_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         });
       }
     }
-    sssp_mbox_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, f->dev.offsets, n, (uint32_t)f->start,
-                                                      delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t, sv.rv.msgs[0],
-                                                      sv.rv.msgs[1], sv.rv.roffh, sv.rv.abort);
+    if (sv.log == 13)
+      sssp_mbox_setup_kernel<13><<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, f->dev.offsets, n, (uint32_t)f->start,
+                                                            delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t, sv.rv.msgs[0],
+                                                            sv.rv.msgs[1], sv.rv.roffh, sv.rv.abort);
+    else
+      sssp_mbox_setup_kernel<12><<<sv.blocks, 256, 0, st>>>(sv.key.p, mv, sv.improved.p, sv.ctl.p, f->dev.offsets, n, (uint32_t)f->start,
+                                                            delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t, sv.rv.msgs[0],
+                                                            sv.rv.msgs[1], sv.rv.roffh, sv.rv.abort);
   } else {
     sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
                                                  sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,

@@ -82,8 +82,11 @@ constexpr uint32_t MB_DBG_SWEEPS = 64;
 #define MB_STAMP(p) do { if (mb.dbg && tid == 0 && sweep < MB_DBG_SWEEPS) mb.dbg[((size_t)sweep * nb + j) * 16 + (p)] = wall_clock64(); } while (0)
 
 // ---- plan (cached on the FST handle): region offsets from the number of arcs between every pair of blocks
+// (LOG = log2 of the block size: 12 everywhere except the resident launches of graphs of 1M .. 2M states, which own 8192 states)
+template <uint32_t LOG>
 __global__ void __launch_bounds__(1024) mbox_hist_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                          uint32_t n, uint32_t nb, uint32_t* __restrict__ hist) {
+  constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG;
   __shared__ uint32_t l_h[MB_NBMAX_BIG];
   const uint32_t j = blockIdx.x;
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) l_h[d] = 0;
@@ -103,11 +106,13 @@ __global__ void mbox_transpose_kernel(const uint32_t* __restrict__ roff, uint32_
 
 // Initial state of a mailbox solve in one launch.  With NARROW launches the start state is the one entry of its block's
 // work-list segment (sweep 0 is NARROW); without, it waits in the pending mask (sweep 0 is WIDE).
+template <uint32_t LOG>
 __global__ void __launch_bounds__(256) sssp_mbox_setup_kernel(uint64_t* __restrict__ key, MboxView mb, uint32_t* __restrict__ improved,
                                                               Ctl* __restrict__ ctl, const uint32_t* __restrict__ offsets, uint32_t n,
                                                               uint32_t start, float tau0, uint32_t narrow_on, uint2* rs_msgs0,
                                                               uint2* rs_msgs1, const uint32_t* __restrict__ rs_roffh,
                                                               uint32_t* __restrict__ rs_abort) {
+  constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG, NW_SEG = MB_B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   const uint32_t nb = mb.nb;
   if (rs_msgs0) {  // resident launches (sssp_resident.h): no region header carries a tag of this solve yet
@@ -248,8 +253,9 @@ __device__ __forceinline__ Sched mbox_sched_eval(const Ctl* ctl, const SchedRaw&
 // Nothing is read back (a returned atomic would be a third dependent trip per level): the block's far count may count a
 // state twice — it only steers the schedule, and the owner recomputes it the next time it runs — and "somebody waits" is
 // blk_mind != +inf (the owner keeps blk_pend exact for itself).
+template <uint32_t LOG>
 __device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, uint32_t enc_d, bool is_far) {
-  const uint32_t b = t >> MB_LOG;
+  const uint32_t b = t >> LOG;
   atomicOr(&mb.pend[t >> 5], 1u << (t & 31u));
   atomicMin(&mb.blk_mind[b], enc_d);
   if (is_far) atomicAdd(&mb.blk_far[b], 1u);
@@ -258,12 +264,14 @@ __device__ __forceinline__ void mbox_make_wait(const MboxView& mb, uint32_t t, u
 // One NARROW launch of workgroup j: follows the entries of its segment, and what they improve, until nothing near is
 // left, the frontier has grown beyond what one workgroup should carry, or (while states wait beyond the threshold) it
 // has started to shrink — the rule by which sweep_tau widens the band.  `wl` = 2 x NW_CAP entries of LDS.
+template <uint32_t LOG>
 __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                             uint64_t* __restrict__ key, const MboxView& mb, Ctl* __restrict__ ctl,
                                             uint32_t* __restrict__ improved, uint32_t sweep, float tau, uint32_t far_total,
                                             uint32_t near_low, uint32_t profile, uint32_t wl_n, bool waits, uint32_t bfar,
                                             uint4* wl, uint32_t* s_n /*[4]: list sizes [0..1], found beyond the threshold [2]*/,
                                             uint32_t par_out, const uint32_t* l_roff_out, uint32_t* l_cur, uint32_t* l_cap) {
+  constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG, MB_HOP_BITS = 32 - LOG, NW_SEG = MB_B;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x, nb = mb.nb;
   const uint32_t sub = tid & 15u, grp = tid >> 4;
   // The head of the search (sweep 0, ONE workgroup at work): a candidate beyond the threshold is not this launch's
@@ -279,7 +287,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
   for (uint32_t e = tid; e < wl_n; e += MB_THREADS) {  // (a segment longer than the list: the rest keeps waiting)
     const uint4 en = mb.wl[(size_t)j * NW_SEG + e];
     if (e < NW_CAP) wl[e] = en;
-    else mbox_make_wait(mb, en.x, en.z, false);
+    else mbox_make_wait<LOG>(mb, en.x, en.z, false);
   }
   if (tid == 0) {
     s_n[0] = min(wl_n, NW_CAP);
@@ -389,11 +397,11 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
                 listed = true;
               }
               if (!listed) {
-                mbox_make_wait(mb, a[u].y, enc[u], false);
+                mbox_make_wait<LOG>(mb, a[u].y, enc[u], false);
                 left_any = true;
               }
             } else {
-              mbox_make_wait(mb, a[u].y, enc[u], true);
+              mbox_make_wait<LOG>(mb, a[u].y, enc[u], true);
               far_new += 1u;
               left_any = true;
             }
@@ -422,7 +430,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
   {
     const uint32_t left = min(s_n[cur], NW_CAP);
     const uint4* __restrict__ in = wl + cur * NW_CAP;
-    for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait(mb, in[e].x, in[e].z, false);
+    for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait<LOG>(mb, in[e].x, in[e].z, false);
     if (__any(left_any || left != 0u) && lane == 0) s_n[3] = 1u;
     __syncthreads();
     if (tid == 0) atomicMax(improved, s_n[3] ? FLAG_NARROW_LEFT : FLAG_NARROW_CLEAN);
@@ -620,7 +628,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
       for (uint32_t d = tid; d < nb; d += MB_THREADS) mb.cnt[par_out][(size_t)d * nb + j] = 0;
       if (tid == 0) mb.wrote[par_out][j] = 0;
     }
-    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bmind != 0xFFFFFFFFu, bfar,
+    mbox_narrow<MB_LOG>(offsets, wn, key, mb, ctl, improved, sweep, tau, sc.far_total, near_low, profile, wl_n, bmind != 0xFFFFFFFFu, bfar,
                 (uint4*)lkey, s_nw, par_out, l_roff_out, l_cur, l_base);
     MB_STAMP(15);
     return;

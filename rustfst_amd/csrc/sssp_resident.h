@@ -68,27 +68,46 @@ __device__ __forceinline__ uint32_t quad_first(uint32_t v) {  // lane 4k's value
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, false);  // quad_perm:[0,0,0,0]
 }
 
+// LDS of a resident workgroup, all of it dynamic (a block of 8192 states needs more than the 64 KB a kernel may declare
+// statically): scalars, keys, arc offsets, the expansion list, the waiting mask, then the staging slots and the three
+// per-destination tables.
+struct ResScalars {
+  unsigned long long tot[2][2];  // per level parity: near | far << 32, waiting | senders << 32 (sums over the headers)
+  uint32_t lv[2][6];             // per level parity: an, sent, npend, nfar, spare, spare
+  uint32_t nw[4];
+  uint32_t abort_;
+  uint32_t pad_[7];
+};
+static_assert(sizeof(ResScalars) % 16 == 0, "the arrays behind the scalars stay 16-byte aligned");
+constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
+  return sizeof(ResScalars) + ((size_t)8 << log) + ((size_t)4 << log) + 16 + ((size_t)2 << log) + ((size_t)4 << log) / 32 +
+         (size_t)nb * stg * 8 + 3 * (size_t)nb * 4;
+}
+
+template <uint32_t LOG>
 __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                                         uint64_t* __restrict__ key, MboxView mb, ResView rv, uint32_t par_in,
                                                                         uint32_t n, uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
                                                                         uint32_t sweep, float delta, uint32_t near_low, uint32_t narrow_t,
                                                                         uint32_t max_levels) {
+  constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG, MB_HOP_BITS = 32 - LOG, NW_SEG = MB_B;
   extern __shared__ __align__(16) unsigned char mb_dyn[];
-  __shared__ unsigned long long lkey[MB_B];
-  __shared__ uint32_t l_off[MB_B + 1];
-  __shared__ uint16_t a_state[MB_B];
-  __shared__ unsigned long long s_tot[2][2];  // per level parity: near | far << 32, waiting | senders << 32 (sums over the headers)
-  __shared__ uint32_t s_lv[2][6];             // per level parity: an, sent, npend, nfar, spare, spare
-  __shared__ uint32_t l_pend[MB_B / 32];      // states whose key was lowered since they were last expanded, or that wait beyond the threshold
-  __shared__ uint32_t s_nw[4];
-  __shared__ uint32_t s_abort;
+  ResScalars& sc_ = *(ResScalars*)mb_dyn;
+  unsigned long long (&s_tot)[2][2] = sc_.tot;
+  uint32_t (&s_lv)[2][6] = sc_.lv;
+  uint32_t* const s_nw = sc_.nw;
+  uint32_t& s_abort = sc_.abort_;
+  unsigned long long* const lkey = (unsigned long long*)(mb_dyn + sizeof(ResScalars));  // [MB_B]
+  uint32_t* const l_off = (uint32_t*)(lkey + MB_B);                                     // [MB_B + 1] (+ 3 words of padding)
+  uint16_t* const a_state = (uint16_t*)(l_off + MB_B + 4);                              // [MB_B] the states this level expands
+  uint32_t* const l_pend = (uint32_t*)(a_state + MB_B);  // [MB_B / 32] states whose key was lowered since they were last expanded, or that wait
   constexpr uint32_t R = MB_B / MB_THREADS;
   constexpr uint32_t PW = MB_B / 32;
   constexpr uint32_t WPR = MB_THREADS / 32;
   asm volatile("" ::"s"(offsets), "s"(mb.cnt[1]), "s"(ctl), "s"(rv.roffh), "s"(max_levels));
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t j = blockIdx.x, nb = mb.nb, stg = mb.stg;
-  uint2* const l_stage = (uint2*)mb_dyn;                         // [nb * stg]
+  uint2* const l_stage = (uint2*)(l_pend + PW);                  // [nb * stg]
   uint32_t* const l_roff_out = (uint32_t*)(l_stage + nb * stg);  // [nb] first message slot of region (j -> d)
   uint32_t* const l_cur = l_roff_out + nb;                       // [nb]
   uint32_t* const l_base = l_cur + nb;                           // [nb]
@@ -161,8 +180,12 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       ctl->streak[sweep % RING] = sc.streak;
       ctl->mode[sweep % RING] = sc.mode;
     }
-    mbox_narrow(offsets, wn, key, mb, ctl, improved, sweep, sc.tau_use, sc.far_total, near_low, 0u, wl_n, bmind != 0xFFFFFFFFu, bfar,
-                (uint4*)lkey, s_nw, par_in ^ 1u, l_roff_out, l_cur, l_base);
+    if (sweep == 0) {  // the head of the search sends its far candidates in the one-level format (region offsets of that plan)
+      if (tid < nb) l_roff_out[tid] = mb.roff_t[(size_t)j * nb + tid];
+      __syncthreads();
+    }
+    mbox_narrow<LOG>(offsets, wn, key, mb, ctl, improved, sweep, sc.tau_use, sc.far_total, near_low, 0u, wl_n, bmind != 0xFFFFFFFFu, bfar,
+                     (uint4*)lkey, s_nw, par_in ^ 1u, l_roff_out, l_cur, l_base);
     return;
   }
 

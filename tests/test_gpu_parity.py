@@ -559,6 +559,32 @@ def test_mailbox_sweeps_beyond_2_20_states(oracle, monkeypatch, narrow):
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"2.1M states q={q}")
 
 
+@pytest.mark.parametrize("variant", [None, "reslevels=3", "restlim=0", "narrow=0"])
+def test_resident_launches_with_8192_state_blocks(oracle, monkeypatch, variant):
+    """Between 2^20 and 2^21 states a block of 4096 states per compute unit no longer covers the FST: the resident kernel
+    then owns blocks of 8192 states (64 KB of keys in LDS) and runs EVERY launch of the solve, the NARROW ones included.
+    1.3M states / 6.5M arcs: distances, hop counts and the path bit-identical to the canonical oracle; with launches cut
+    after three levels (hand-overs inside the one kernel), without the NARROW hand-over, and with a wait limit of zero
+    (the launch gives up, the solve is repeated with 4096-state blocks and one launch per level)."""
+    if variant:
+        k, v = variant.split("=")
+        monkeypatch.setenv({"reslevels": "WFST_SSSP_RES_LEVELS", "restlim": "WFST_SSSP_RES_TLIM_US", "narrow": "WFST_SSSP_NARROW"}[k], v)
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(1_300_000, 5, 64, 0.0, seed=12)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    for q in range(3):
+        dist, hops = d.shortest_distance(want_hops=True)
+        st = ctx.stats()
+        if variant == "restlim=0":
+            assert st["resident_aborts"] == 1 and st["relax_kernel"] == 1
+        else:
+            assert st["resident_aborts"] == 0 and st["relax_kernel"] == 2
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"1.3M states ({variant}) q={q}")
+
+
 def test_reference_tie_order_on_acyclic_inputs(oracle):
     """wfst_ctx_set_tie_order(ctx, 1): on acyclic inputs shortest_path returns the path RUSTFST returns when optima tie —
     first strict improver in the topological order of its depth-first visit (auto_queue.rs:23-99, top_order_queue.rs:12-94,
