@@ -67,6 +67,7 @@ struct FstView {
   const uint2* anext;  // per arc {arc begin, arc count} of its destination state (string o T kernel only), or null
   uint32_t n_states;
   int32_t start;  // -1 = None
+  uint64_t n_arcs;
 };
 
 struct ProblemDesc {
@@ -1028,7 +1029,8 @@ constexpr uint32_t STR_NONE = 0xFFFFFFFFu;
 __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDesc* __restrict__ descs, FstView f2,
                                                                 Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
                                                                 uint32_t path_cap, uint32_t* __restrict__ path_cursor,
-                                                                uint32_t n_problems, uint32_t maxs) {
+                                                                uint32_t n_problems, uint32_t maxs, uint64_t f2_n_arcs,
+                                                                uint32_t scalar_rows) {
   extern __shared__ uint32_t s_dyn[];
   const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n_problems) return;
@@ -1063,16 +1065,109 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
   }
   uint32_t lo = 0, hi = 1, F = 1, n_arcs = 0, level = 0;  // level = position of the current frontier in the string
   if (lane == 0) s_par[0] = STR_NONE;
-  uint4 a_cur = make_uint4(0, 0, 0, 0);
-  if (L) a_cur = ld_global16(f1.arcs);  // the same address in every lane: one broadcast load
+  // the string's arcs, 64 at a time, one per lane (a linear acceptor: arc i leaves state i), the next 64 already on their
+  // way: a label is a v_readlane away.  (One broadcast load per level, asked for one level ahead, made every level wait
+  // for a vector load — ~0.6 us for a lone wave — however fast the arc block of fst2 came in.)
+  uint4 ch_cur = make_uint4(0, 0, 0, 0), ch_nxt = make_uint4(0, 0, 0, 0);
+  if (lane < L) ch_cur = ld_global16(f1.arcs + lane);
+  if (64u + lane < L) ch_nxt = ld_global16(f1.arcs + 64u + lane);
   bool ok = true;
   for (uint32_t pos = 0; pos < L && F && ok; ++pos) {
-    const uint32_t label = a_cur.x;
-    const float w1 = __uint_as_float(a_cur.z);
-    if (pos + 1 < L) a_cur = ld_global16(f1.arcs + pos + 1);  // next label: off the critical chain
+    const uint32_t pl = pos & 63u;
+    if (pos && pl == 0u) {
+      ch_cur = ch_nxt;
+      ch_nxt = make_uint4(0, 0, 0, 0);
+      if (pos + 64u + lane < L) ch_nxt = ld_global16(f1.arcs + pos + 64u + lane);
+    }
+    const uint32_t label = rl(ch_cur.x, pl);
+    const float w1 = __uint_as_float(rl(ch_cur.z, pl));
     uint32_t nq = 0, nnb = 0, nnc = 0, n_new = 0;  // new states of the next level: lane k holds state hi + k
     float nd = INF;
-    for (uint32_t f = 0; f < F && ok; ++f) {
+    // one matched arc (f -> qd, output label ol, weight w2, the destination's arc block [xb, xb + xc)): the destination
+    // becomes a state of the next level unless the level has it already, and keeps the better way in
+    auto on_match = [&](uint32_t f, float fd, uint32_t qd, uint32_t ol, uint32_t xb, uint32_t xc, float w2) -> bool {
+      const float wsum = wtimes(w1, w2);  // add_tr, compose_fst_op.rs:267-285
+      float c = INF;
+      if (fd < INF) c = (fd + wsum) + 0.0f;  // candidate distance; +inf never relaxes (shortest_path.rs:226)
+      const uint64_t ex = __ballot(lane < n_new && nq == qd);  // StateTable::find_id inside the level
+      uint32_t idx;
+      if (ex == 0) {
+        idx = n_new;
+        if (idx >= 64u || hi + idx >= maxs) return false;
+        if (lane == idx) {
+          nq = qd;
+          nnb = xb;
+          nnc = xc;
+          nd = INF;
+        }
+        if (lane == 0) s_par[hi + idx] = STR_NONE;
+        n_new += 1;
+      } else {
+        idx = (uint32_t)__ffsll((unsigned long long)ex) - 1u;
+      }
+      const float cur = __uint_as_float(rl(__float_as_uint(nd), idx));
+      if (c < cur) {  // strict: on ties the earlier (source id, arc position) stays
+        if (lane == idx) nd = c;
+        if (lane == 0) {
+          s_par[hi + idx] = lo + f;
+          s_ol[hi + idx] = ol;
+          s_w[hi + idx] = wsum;
+        }
+      }
+      return true;
+    };
+    // The common level: ONE frontier state with a short arc block.  A lone wave's vector load takes ~0.6 us from issue to
+    // use on this chip, a scalar load of the same (immutable) rows ~0.1 us (tools/ubench_chase.hip): the labels of a block
+    // of up to 12 arcs come through the scalar cache (the loads also bring every line of the block and of its
+    // destination ranges in), they are compared on the scalar unit, the matched arc is a scalar-cache hit, and the next
+    // level's block address never leaves SGPRs.
+    bool took_scalar = false;
+    if (scalar_rows && F == 1u) {
+      const uint32_t fb = rl(nb, 0), fc = rl(nc, 0);
+      if (fc <= 12u && (uint64_t)fb + 12u <= f2_n_arcs) {
+        took_scalar = true;
+        const float fd = __uint_as_float(rl(__float_as_uint(d), 0));
+        // step 1: the twelve labels (one dword per arc: every 64-byte line of the block is touched) and one word of every line
+        // of the destination-range block, all issued together: one miss latency
+        uint32_t l0, l1, l2, l3, l4, l5, l6, l7, l8, l9, l10, l11, t0, t1, t2;
+        const wfst_tr* ap = f2.arcs + fb;
+        const uint2* np = f2.anext + fb;
+        asm volatile(
+            "s_load_dword %0, %15, 0x0\n\ts_load_dword %1, %15, 0x10\n\ts_load_dword %2, %15, 0x20\n\ts_load_dword %3, %15, 0x30\n\t"
+            "s_load_dword %4, %15, 0x40\n\ts_load_dword %5, %15, 0x50\n\ts_load_dword %6, %15, 0x60\n\ts_load_dword %7, %15, 0x70\n\t"
+            "s_load_dword %8, %15, 0x80\n\ts_load_dword %9, %15, 0x90\n\ts_load_dword %10, %15, 0xa0\n\ts_load_dword %11, %15, 0xb0\n\t"
+            "s_load_dword %12, %16, 0x0\n\ts_load_dword %13, %16, 0x2c\n\ts_load_dword %14, %16, 0x58\n\ts_waitcnt lgkmcnt(0)"
+            : "=&s"(l0), "=&s"(l1), "=&s"(l2), "=&s"(l3), "=&s"(l4), "=&s"(l5), "=&s"(l6), "=&s"(l7), "=&s"(l8), "=&s"(l9), "=&s"(l10),
+              "=&s"(l11), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+            : "s"(ap), "s"(np)
+            : "memory");
+        uint32_t m = 0;  // arcs of the block that carry the label, in arc order
+        m |= (l0 == label ? 1u : 0u) | (l1 == label ? 2u : 0u) | (l2 == label ? 4u : 0u) | (l3 == label ? 8u : 0u);
+        m |= (l4 == label ? 16u : 0u) | (l5 == label ? 32u : 0u) | (l6 == label ? 64u : 0u) | (l7 == label ? 128u : 0u);
+        m |= (l8 == label ? 256u : 0u) | (l9 == label ? 512u : 0u) | (l10 == label ? 1024u : 0u) | (l11 == label ? 2048u : 0u);
+        m &= (1u << fc) - 1u;
+        n_arcs += (uint32_t)__popc(m);
+        while (m) {
+          const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+          m &= m - 1u;
+          // step 2: the matched arc and its destination's range: both lines are in the scalar cache now
+          typedef uint32_t sv4 __attribute__((ext_vector_type(4)));
+          typedef uint32_t sv2 __attribute__((ext_vector_type(2)));
+          sv4 a;
+          sv2 nx;
+          const uint32_t o16 = k * 16u, o8 = k * 8u;
+          asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx2 %1, %3, %5\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(a), "=&s"(nx)
+                       : "s"(ap), "s"(np), "s"(o16), "s"(o8)
+                       : "memory");
+          if (!on_match(0u, fd, a[3], a[1], nx[0], nx[1], __uint_as_float(a[2]))) {
+            ok = false;
+            break;
+          }
+        }
+      }
+    }
+    for (uint32_t f = 0; f < F && ok && !took_scalar; ++f) {
       const uint32_t fb = rl(nb, f), fc = rl(nc, f);
       const float fd = __uint_as_float(rl(__float_as_uint(d), f));
       for (uint32_t base = 0; base < fc && ok; base += 64) {
@@ -1088,38 +1183,9 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
         while (m) {
           const uint32_t l = (uint32_t)__ffsll((unsigned long long)m) - 1u;
           m &= m - 1;
-          const uint32_t qd = rl(a.w, l), ol = rl(a.y, l), xb = rl(nx.x, l), xc = rl(nx.y, l);
-          const float w2 = __uint_as_float(rl(a.z, l));
-          const float wsum = wtimes(w1, w2);  // add_tr, compose_fst_op.rs:267-285
-          float c = INF;
-          if (fd < INF) c = (fd + wsum) + 0.0f;  // candidate distance; +inf never relaxes (shortest_path.rs:226)
-          const uint64_t ex = __ballot(lane < n_new && nq == qd);  // StateTable::find_id inside the level
-          uint32_t idx;
-          if (ex == 0) {
-            idx = n_new;
-            if (idx >= 64u || hi + idx >= maxs) {
-              ok = false;
-              break;
-            }
-            if (lane == idx) {
-              nq = qd;
-              nnb = xb;
-              nnc = xc;
-              nd = INF;
-            }
-            if (lane == 0) s_par[hi + idx] = STR_NONE;
-            n_new += 1;
-          } else {
-            idx = (uint32_t)__ffsll((unsigned long long)ex) - 1u;
-          }
-          const float cur = __uint_as_float(rl(__float_as_uint(nd), idx));
-          if (c < cur) {  // strict: on ties the earlier (source id, arc position) stays
-            if (lane == idx) nd = c;
-            if (lane == 0) {
-              s_par[hi + idx] = lo + f;
-              s_ol[hi + idx] = ol;
-              s_w[hi + idx] = wsum;
-            }
+          if (!on_match(f, fd, rl(a.w, l), rl(a.y, l), rl(nx.x, l), rl(nx.y, l), __uint_as_float(rl(a.z, l)))) {
+            ok = false;
+            break;
           }
         }
       }
@@ -1215,6 +1281,7 @@ FstView view_of(const wfst_fst* f) {
   v.anext = nullptr;
   v.n_states = f->n_states;
   v.start = (int32_t)f->start;
+  v.n_arcs = f->n_arcs;
   return v;
 }
 
@@ -1320,7 +1387,10 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
       wpb = (64u << 10) / (16u * maxs);
     }
     string_compose_sp_kernel<<<(uint32_t)((n + wpb - 1) / wpb), 64 * wpb, (size_t)wpb * 16u * maxs, st>>>(
-        k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p, (uint32_t)n, maxs);
+        k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p, (uint32_t)n, maxs, f2.n_arcs,
+        // scalar arc-block loads where a wave is alone on its SIMD (a handful of strings): -7 % per level; with eight waves
+        // per compute unit the other waves hide the vector latency anyway and the extra scalar instructions cost 3 %
+        std::getenv("WFST_STRING_SCALAR") ? (uint32_t)std::atoi(std::getenv("WFST_STRING_SCALAR")) : (n <= 8 ? 1u : 0u));
   } else
     compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, caps, run.arena.p, run.stride, k_res, k_paths, path_cap,
                                                             run.d_cursor.p);
