@@ -38,7 +38,7 @@ def kernel_sources_sha256():
     state of the kernel is flagged stale in the bench line"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sssp.hip", "sssp_mailbox.h"):
+    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_resident.h"):
         with open(os.path.join(ROOT, "rustfst_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--config5-states", type=int, default=5_000_000,
                     help="states of the HCLG-shaped operand of the configs[4] extra (0 = skip it)")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--roofline-sizes", default="1000000,2000000,5000000,16000000",
+                    help="states of the extra `roofline_vs_size` solves (same generator; empty = off)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra legs (first-query times, the single-string case of configs[1], the "
                          "all-cores CPU batch leg)")
@@ -172,24 +174,107 @@ def config5_extra(n_states, ctx, device):
         ok = ok and weights(nb[i]) == weights(plain.shortest_path(cfg10)) and len(weights(nb[i])) >= 1
     res["nbest_weights_match_plain_composition"] = bool(ok)
     del la, d1, outs, nb
-    # the CPU restatement (1 core) on an operand it finishes in a few seconds: precompute, one composition, its n = 10
+    # the CPU restatement (1 core) on the SAME operand (full size): precompute, one composition, its n = 10
     from oracle import oracle_py
-    n_cpu = min(n_states, 500_000)
-    t1c, accs_c = build(n_cpu, 4, 9)
-    o1 = oracle_py.OracleFst.from_flat(t1c["n_states"], t1c["start"], t1c["offsets"], t1c["arcs"], t1c["finals"], t1c["props"])
-    oa = [oracle_py.OracleFst.from_flat(a["n_states"], a["start"], a["offsets"], a["arcs"], a["finals"], a["props"]) for a in accs_c]
+    o1 = oracle_py.OracleFst.from_flat(t1["n_states"], t1["start"], t1["offsets"], t1["arcs"], t1["finals"], t1["props"])
+    a0 = accs[0]
+    oa0 = oracle_py.OracleFst.from_flat(a0["n_states"], a0["start"], a0["offsets"], a0["arcs"], a0["finals"], a0["props"])
     c0 = time.perf_counter()
-    oc = o1.compose_lookahead(oa[0])
+    oc = o1.compose_lookahead(oa0)
     t_first = time.perf_counter() - c0
     c0 = time.perf_counter()
     onb = oc.shortest_path_n(10)
     t_nb = time.perf_counter() - c0
-    res["cpu"] = {"states": n_cpu, "cores": 1, "kind": "port",
+    res["cpu"] = {"states": int(t1["n_states"]), "cores": 1, "kind": "port",
                   "lookahead_precompute_plus_one_composition_s": round(t_first, 3), "nbest10_ms": round(1e3 * t_nb, 3),
-                  "note": "oracle restatement: MatcherFst::new (label reachability + relabelling) is redone per composition, "
-                          "as in rustfst-cli; one acceptor"}
-    del onb
+                  "note": "oracle restatement on the same operand: MatcherFst::new (label reachability + relabelling) is redone per "
+                          "composition, as in rustfst-cli; one acceptor"}
+    del onb, oc, o1, t1
+
+    # ---- the wide look-ahead driver at scale (with |Sigma| = 256 a composed lattice has ~250 states: the figures above are
+    # latencies of tiny problems).  |Sigma| = 8: every acceptor label matches ~1.25 arcs per state, the lattice fills the
+    # operand within a few levels — tens of millions of composed states from ONE acceptor of 40 labels.
+    import math
+    W_SIGMA, W_LEN = 8, 40
+    c0 = time.perf_counter()
+    tw = synth.make_transducer(n_states, 10, W_SIGMA, 0.05, seed=9)
+    aw = synth.make_acceptors(tw, 1, W_LEN, seed0=77)[0]
+    tw["arcs"]["ilabel"], tw["arcs"]["olabel"] = tw["arcs"]["olabel"].copy(), tw["arcs"]["ilabel"].copy()
+    tw["props"] = synth.O_LABEL_SORTED
+    gen_w = time.perf_counter() - c0
+    dw = rustfst_amd.DeviceFst.from_arrays(tw["n_states"], tw["start"], tw["offsets"], tw["arcs"], tw["finals"], tw["props"], ctx)
+    del tw
+    c0 = time.perf_counter()
+    law = rustfst_amd.LookAhead(dw)
+    create_w = time.perf_counter() - c0
+    daw = rustfst_amd.DeviceFst.from_arrays(aw["n_states"], aw["start"], aw["offsets"], aw["arcs"], aw["finals"], aw["props"], ctx)
+    relw = law.relabel(daw)
+    best = float("inf")
+    for _ in range(2):
+        ctx.synchronize()
+        c0 = time.perf_counter()
+        ow = law.compose(relw)
+        ctx.synchronize()
+        best = min(best, time.perf_counter() - c0)
+    stw = ctx.stats()
+    cs, ca = int(stw["compose_states"]), int(stw["compose_arcs"])
+    m = ca / max(1, cs)
+    per_state = 24 + 16 * 1.0 + 4 * 1.0 * math.ceil(math.log2(10 + 1)) + 48 * m  # B_comp per expanded state
+    res["wide_lookahead"] = {
+        "workload": f"look-ahead composition of ONE acceptor of {W_LEN} labels with the same generator at |Sigma| = {W_SIGMA} "
+                    f"({n_states} states): the wide look-ahead driver", "generate_s": round(gen_w, 2), "lookahead_create_s": round(create_w, 3),
+        "composed_states": cs, "composed_arcs": ca, "result_states": int(ow.num_states), "ms": round(1e3 * best, 2),
+        "states_per_s": round(cs / best, 1), "arcs_per_s": round(ca / best, 1),
+        "roofline_compose": {"bound": "hbm", "accounting": "SURVEY 8(d): B_comp = sum over expanded states of 24 + 16 f1 + 4 f1 ceil(log2(f2 + 1)) + 48 m "
+                             "(f1 = 1, f2 = 10, m = arcs / states) / host clock around the synchronous call (an upper bound of the kernel time)",
+                             "algorithmic_bytes": int(per_state * cs), "achieved": round(per_state * cs / best / 1e9, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(per_state * cs / best / 1e9 / HBM_PEAK_GBS, 5)}}
+    del ow, law, dw
     return res
+
+
+def roofline_vs_size(ctx, sizes, fanout, sigma):
+    """The relaxation's fraction of the HBM roofline (SURVEY 8(d) accounting: (20 E + 12 N) bytes per solve / summed kernel
+    time / 8 TB/s) on the SAME generator at several sizes: where the per-level floor of a 1M-state solve is amortised,
+    and which kernel the library picks there."""
+    import numpy as np
+    import rustfst_amd
+    from rustfst_amd import synth
+    names = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel")
+    rows = []
+    for n in sizes:
+        c0 = time.perf_counter()
+        t = synth.make_transducer(n, fanout, sigma, 0.0, seed=3)
+        gen_s = time.perf_counter() - c0
+        e = int(t["offsets"][-1])
+        d = rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+        del t
+        for _ in range(5):  # plan, transpose, prediction settle
+            d.shortest_path()
+        ctx.set_profiling(2)
+        chain, host = [], []
+        for _ in range(9):
+            c0 = time.perf_counter()
+            d.shortest_path()
+            host.append(1e3 * (time.perf_counter() - c0))
+            cs = ctx.stats()
+            if cs["relax_launches"]:
+                chain.append((cs["relax_ms"], int(cs["relax_launches"])))
+        ctx.set_profiling(0)
+        st = ctx.stats()
+        row = {"states": n, "arcs": e, "kernel": names[int(st["relax_kernel"])], "ms_shortest_path": round(min(host), 4),
+               "generate_s": round(gen_s, 1)}
+        if chain:
+            chain.sort()
+            ms, launches = chain[len(chain) // 2]
+            by = 20.0 * e + 12.0 * n
+            row.update({"launches": launches, "relax_kernel_ms": round(ms, 4), "algorithmic_bytes": int(by),
+                        "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+        rows.append(row)
+        del d
+    return {"accounting": "SURVEY 8(d): (20 E + 12 N) bytes per solve / summed relaxation-kernel time of a repeated query (HIP events "
+                          "around the pre-queued launch chain, median of 9) / 8 TB/s", "generator": f"T(N, fan-out {fanout}, |Sigma| = {sigma}, seed 3)",
+            "points": rows}
 
 
 def main():
@@ -513,6 +598,11 @@ def main():
         if rank == 0 and not args.no_extras and args.config5_states > 0:
             config5 = config5_extra(args.config5_states, ctx, device)
 
+        # ------------------------------------------------------------------ the same roofline figure at other sizes
+        rvs = None
+        if rank == 0 and not args.no_extras and args.roofline_sizes:
+            rvs = roofline_vs_size(ctx, [int(x) for x in args.roofline_sizes.split(",") if x], args.fanout, args.sigma)
+
         # ------------------------------------------------------------------ roofline of the relaxation kernel
         # HIP events bracket every sssp_relax_kernel launch on ctx's stream (wfst_ctx_set_profiling);
         # achieved = algorithmic bytes (20 B per arc relaxed + 12 B per frontier state) / kernel time.
@@ -720,7 +810,7 @@ def main():
             "config5": config5, "batch_sweep": batch_sweep,
             "config2_single_string": config2,
             "reference_harness_split": harness,
-            "roofline": roofline, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "roofline_vs_size": rvs, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }
         out_line = json.dumps(out)
     # RCCL prints a version banner through C stdio when its communicator comes up; piped, that buffer only drains at exit

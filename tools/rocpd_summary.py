@@ -30,7 +30,7 @@ def trace(path, alg_bytes=212e6):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | "
               f"{a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
-    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel"):
+    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel"):
         rel = [(e - s) for name, s, e in rows if kname + "(" in name or kname + "<" in name]
         if not rel:
             continue
