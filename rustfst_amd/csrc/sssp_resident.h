@@ -116,6 +116,12 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
   const uint32_t reg = tid / MB_LPR, q = tid % MB_LPR;
   static_assert(MB_LPR == 4, "the header sector is read by four lanes");
 
+  // A launch queued behind the solve's last one (the host sizes a batch from the previous solve, plus a margin): the launch
+  // before it certified the fixed point, or changed nothing, or gave up — nothing to load, nobody to wait for.
+  if (sweep > 0) {
+    const uint32_t pf = improved_ring[(sweep - 1u) % IMP_RING];
+    if (pf == 0u || pf == FLAG_NARROW_CLEAN || pf == FLAG_RES_ABORT) return;
+  }
   // ---- prologue: as sssp_mbox_kernel's first trip (everything issued before anything is consumed)
   uint32_t c_in = 0, rb_in = 0, hdr_in = 0;
   if (reg < nb) {
