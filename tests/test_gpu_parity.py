@@ -1566,6 +1566,27 @@ def _lookahead_pair(rng, n1, n2, acyclic=False, sigma=3, p_oeps=0.45, p_ieps=0.3
 
 
 @pytest.mark.parametrize("path", ["wave", "wide"])
+def test_k13_lookahead_hand_traced_known_answers(gpu_ctx, monkeypatch, path):
+    """Look-ahead composition against the three answers traced by hand through the reference's source
+    (tests/golden/K13_DERIVATION.md section 2, tests/golden/k13_lookahead.json): the relabelled second operand, the pruned
+    dead end, pushed weights and labels, state numbering and arc order — on the single-wave kernel and on the wide driver,
+    and through the batch entry point."""
+    from test_oracle import flat_matches_spec
+    monkeypatch.setenv("WFST_LOOKAHEAD_PATH", path)
+    g = golden("k13_lookahead.json")
+    for case in g["cases"]:
+        la = rustfst_amd.LookAhead(vbuild(case["fst1"]).to_device())  # (relabels and re-sorts its operand, as MatcherFst::new does)
+        rel = la.relabel(vbuild(case["fst2"]).to_device())
+        if "relabeled_fst1" in case:
+            flat_matches_spec(la.fst1.to_flat(), case["relabeled_fst1"])
+        if "relabeled_fst2" in case:
+            flat_matches_spec(rel.to_flat(), case["relabeled_fst2"])
+        flat_matches_spec(la.compose(rel).to_flat(), case["expected"])
+        for o in la.compose_batch([rel, rel]):
+            flat_matches_spec(o.to_flat(), case["expected"])
+
+
+@pytest.mark.parametrize("path", ["wave", "wide"])
 @pytest.mark.parametrize("seed", range(24))
 def test_lookahead_compose_both_drivers(gpu_ctx, oracle, monkeypatch, seed, path):
     """The single-wave kernel and the level-per-launch wide path (one wave per composed state, tuples interned through

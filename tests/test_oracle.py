@@ -88,6 +88,20 @@ def test_k13_nshortest_known_answers(oracle):
     flat_matches_spec(f.shortest_path_n(3).to_flat(), g["n3"])
 
 
+def test_k13_lookahead_known_answers(oracle):
+    """Look-ahead composition (rustfst-cli compose --compose-type lookahead) on three pairs traced by hand through the
+    reference's source (tests/golden/K13_DERIVATION.md section 2): label reachability and relabelling, pruning of a dead end,
+    weight pushing (and its division at the following arcs), label pushing through a multi-epsilon, an unseen label."""
+    g = load_golden("k13_lookahead.json")
+    for case in g["cases"]:
+        out, r1, r2 = build(oracle, case["fst1"]).compose_lookahead(build(oracle, case["fst2"]), want_relabeled=True)
+        flat_matches_spec(out.to_flat(), case["expected"])
+        if "relabeled_fst1" in case:
+            flat_matches_spec(r1.to_flat(), case["relabeled_fst1"])
+        if "relabeled_fst2" in case:
+            flat_matches_spec(r2.to_flat(), case["relabeled_fst2"])
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_nshortest_against_independent_brute_force(oracle, seed):
     """The oracle's n-best results against an exhaustive enumeration written independently of it (tests/helpers.py): the
