@@ -43,7 +43,10 @@ constexpr uint32_t MB_THREADS = WFST_MB_THREADS;
 constexpr uint32_t MB_LPR = MB_THREADS / 256;  // lanes that share an inbox region / a destination's staged run
 constexpr uint32_t MB_HOP_BITS = 32 - MB_LOG;
 constexpr uint32_t MB_UNROLL = 8 * (1024 / MB_THREADS);  // active states a 16-lane group relaxes at once (independent load chains per lane)
-constexpr uint32_t MB_STG_MAX = 24;  // messages per destination staged in LDS between two flushes (the rest is stored directly)
+#ifndef WFST_MB_STG_MAX
+#define WFST_MB_STG_MAX 24
+#endif
+constexpr uint32_t MB_STG_MAX = WFST_MB_STG_MAX;  // messages per destination staged in LDS between two flushes (the rest is stored directly)
 constexpr uint32_t MB_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-destination cursors) next to 57 KB static
 
 // modes of a launch (also what the activity flag of a sweep holds, + 1)

@@ -21,6 +21,26 @@ __global__ void __launch_bounds__(1024) gather(const uint2* __restrict__ wn, con
   }
   if (acc == 0x123456789ull) sink[0] = acc;
 }
+// the same rows with 16 bytes per lane: 8 lanes per row (5 of them carry the 10 arcs), 8 rows per 64-lane instruction
+__global__ void __launch_bounds__(1024) gather16(const uint2* __restrict__ wn, const uint32_t* __restrict__ starts, uint32_t n_rows, uint32_t deg, unsigned long long* sink) {
+  const uint32_t sub = threadIdx.x & 7u;
+  const uint32_t groups = gridDim.x * (blockDim.x / 8);
+  unsigned long long acc = 0;
+  for (uint32_t r = blockIdx.x * (blockDim.x / 8) + (threadIdx.x >> 3); r < n_rows; r += groups * 4) {
+    uint4 a[4];
+    for (int u = 0; u < 4; ++u) {
+      a[u] = make_uint4(0, 0, 0, 0);
+      const uint32_t rr = r + groups * u;
+      if (rr < n_rows && 2 * sub < deg) {
+        const uint2* p = wn + (size_t)starts[rr] + 2 * sub;
+        const uint2 x = p[0], y = p[1];  // (8-byte aligned rows: two dwordx2 loads that the compiler may not merge)
+        a[u] = make_uint4(x.x, x.y, y.x, y.y);
+      }
+    }
+    for (int u = 0; u < 4; ++u) acc += a[u].x + a[u].y + a[u].z + a[u].w;
+  }
+  if (acc == 0x123456789ull) sink[0] = acc;
+}
 int main() {
   const uint32_t deg = 10;
   for (int big = 0; big < 2; ++big) {
@@ -30,8 +50,8 @@ int main() {
     CK(hipMemset(wn, 1, n_units * 8));
     const uint32_t n_rows = 500000;
     CK(hipMalloc(&starts, n_rows * 4));
-    const char* names[] = {"rows at random 8-byte offsets", "rows inside one 128-byte line (start % 16 <= 6)", "rows 64-byte aligned", "rows 128-byte aligned", "rows in ascending order, random 8-byte offsets (sorted gather)"};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[] = {"rows at random 8-byte offsets", "rows inside one 128-byte line (start % 16 <= 6)", "rows 64-byte aligned", "rows 128-byte aligned", "rows in ascending order, random 8-byte offsets (sorted gather)", "8 lanes x 2 arcs per row, random offsets", "8 lanes x 2 arcs per row, 128-byte aligned rows"};
+    for (int mode = 0; mode < 7; ++mode) {
       std::vector<uint32_t> h(n_rows);
       uint64_t s = 12345 + mode;
       for (uint32_t i = 0; i < n_rows; ++i) {
@@ -39,7 +59,7 @@ int main() {
         uint64_t u = (s >> 20) % (n_units - 32);
         if (mode == 1) { u = (u & ~15ull) | ((s >> 7) % 7); }
         if (mode == 2) u &= ~7ull;
-        if (mode == 3) u &= ~15ull;
+        if (mode == 3 || mode == 6) u &= ~15ull;
         h[i] = (uint32_t)u;
       }
       if (mode == 4) std::sort(h.begin(), h.end());
@@ -48,7 +68,8 @@ int main() {
       float best = 1e9;
       for (int rep = 0; rep < 5; ++rep) {
         CK(hipEventRecord(e0));
-        gather<<<245, 1024>>>(wn, starts, n_rows, deg, sink);
+        if (mode >= 5) gather16<<<245, 1024>>>(wn, starts, n_rows, deg, sink);
+        else gather<<<245, 1024>>>(wn, starts, n_rows, deg, sink);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
