@@ -84,6 +84,73 @@ constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
          (size_t)nb * stg * 8 + 3 * (size_t)nb * 4;
 }
 
+// One round of a level's expansion: 16 lanes per listed state, U states per 16-lane group (U = 1, 2, 4, 8 by the length
+// of the level's list: a thin level runs the short instances).  No arrays of flags, no branch around a load, one LDS
+// read per state for the row's bounds: the body is a third of the instructions of sssp_mbox_kernel's.  Candidate per
+// arc -> LDS (a state of the same block: its key is lowered at once and it waits for the next level) or the destination's
+// staging slots.  l_cur[d] counts the round's messages for destination d; one that finds the slots full is stored directly at
+// its place in the region.  Returns nonzero if this lane sent anything.
+template <uint32_t LOG, uint32_t U>
+__device__ __forceinline__ uint32_t rs_expand_round(uint32_t r0, uint32_t an, uint32_t grp, uint32_t sub, const uint2* __restrict__ wn,
+                                                    const uint16_t* a_state, unsigned long long* lkey, uint32_t* l_pend, const uint32_t* l_off,
+                                                    uint32_t j, uint32_t* l_cur, const uint32_t* l_base, uint2* l_stage, uint32_t stg,
+                                                    const uint32_t* l_roff_out, unsigned long long* __restrict__ msgs_out,
+                                                    uint32_t* __restrict__ pad) {
+  constexpr uint32_t B = 1u << LOG, HOP_BITS = 32 - LOG, G = MB_THREADS / 16;
+  if (!__any(r0 + grp < an)) return 0u;  // (a lane's first state is its lowest: none there, none at all)
+  uint32_t tl[U];
+  for (uint32_t u = 0; u < U; ++u) {
+    const uint32_t e = r0 + grp + G * u;
+    tl[u] = a_state[e < an ? e : r0];
+  }
+  uint32_t i[U], end[U], hs[U], ovf = 0;
+  float d[U];
+  for (uint32_t u = 0; u < U; ++u) {
+    const bool has = r0 + grp + G * u < an;
+    const unsigned long long k = lkey[tl[u]];
+    const uint32_t b = l_off[tl[u]], en = l_off[tl[u] + 1];
+    const uint32_t h1 = (uint32_t)k + 1u;
+    d[u] = dec_f32((uint32_t)(k >> 32));
+    hs[u] = h1 << LOG;
+    i[u] = has ? b + sub : 0u;
+    end[u] = has ? en : 0u;
+    ovf |= has && i[u] < end[u] ? h1 >> HOP_BITS : 0u;
+  }
+  if (ovf) *pad = 1u;  // hop count beyond the message format: the host refuses the result
+  uint2 a[U];
+  for (uint32_t u = 0; u < U; ++u) a[u] = wn[i[u] < end[u] ? i[u] : 0u];  // (a lane without an arc reads arc 0 and drops it)
+  uint32_t sent = 0;
+  for (;;) {
+    uint32_t enc[U], slot[U];
+    for (uint32_t u = 0; u < U; ++u) {
+      const float c = (d[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+      enc[u] = enc_f32(c);
+      slot[u] = 0xFFFFFFFFu;
+      if (i[u] < end[u] && c < INF && (a[u].y >> LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
+        const uint32_t tl_ = a[u].y & (B - 1u);
+        const unsigned long long c_ = ((unsigned long long)enc[u] << 32) | (hs[u] >> LOG);
+        if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
+      } else
+      if (i[u] < end[u] && c < INF) slot[u] = atomicAdd(&l_cur[a[u].y >> LOG], 1u);  // +inf never improves (shortest_path.rs:226)
+    }
+    uint32_t more = 0;
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t db = a[u].y >> LOG;
+      const uint2 msg = make_uint2(hs[u] | (a[u].y & (B - 1u)), enc[u]);
+      if (slot[u] < stg) l_stage[db * stg + slot[u]] = msg;
+      else if (slot[u] != 0xFFFFFFFFu)
+        __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + slot[u]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      sent |= ~slot[u];
+      i[u] += 16;
+      more |= i[u] < end[u] ? 1u : 0u;
+    }
+    if (!__any(more)) break;
+    for (uint32_t u = 0; u < U; ++u) a[u] = wn[i[u] < end[u] ? i[u] : 0u];
+  }
+  return sent;
+}
+
 template <uint32_t LOG>
 __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn,
                                                                         uint64_t* __restrict__ key, MboxView mb, ResView rv, uint32_t par_in,
@@ -277,7 +344,8 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      // the senders' figures: one header per 4 lanes (the other lanes hold zeros)
+      // the senders' figures: one header per 4 lanes (the other lanes hold zeros).  (245 LDS atomics on one address instead of
+      // these shifts cost ~1 us per level: measured)
       const uint32_t a_near = wave_sum_to_last(t_nf & 0xFFFFu), a_far = wave_sum_to_last(t_nf >> 16);
       const uint32_t a_pend = wave_sum_to_last(t_ps & 0xFFFFu), a_sent = wave_sum_to_last(t_ps >> 16);
       if (lane == 63) {
@@ -326,37 +394,33 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
 
     // ---------------- the marked states: near ones listed (and unmarked), far ones keep waiting
     {
-      bool near_[R];
+      const uint32_t enc_tau = enc_f32(tau);  // (the encoding is monotone: d <= tau <=> enc(d) <= enc(tau); +inf lists every marked state)
+      unsigned long long nm[R];
       uint32_t n_near = 0, n_far = 0;
       for (uint32_t r = 0; r < R; ++r) {
         const uint32_t tl = tid + MB_THREADS * r;
         const uint32_t w = l_pend[tl >> 5];
-        const bool act = ((w >> (tl & 31u)) & 1u) != 0;
+        nm[r] = 0;
+        if (__ballot(w != 0u) == 0ull) continue;  // (nobody marked among the wave's 64 states)
         const uint32_t ed = (uint32_t)(lkey[tl] >> 32);
-        near_[r] = act && dec_f32(ed) <= tau;
-        const bool far = act && !near_[r];
-        const unsigned long long fm = __ballot(far), nm = __ballot(near_[r]);
-        if (w != 0u && (lane & 31u) == 0) {  // (the 32 lanes of a half read the word before its first lane rewrites it)
-          const uint32_t fw = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
-          l_pend[tl >> 5] = fw;
-          n_far += (uint32_t)__popc(fw);
-        }
-        n_near += (uint32_t)__popcll(nm);
+        const bool act = ((w >> (tl & 31u)) & 1u) != 0;
+        const bool near = act && ed <= enc_tau;
+        const unsigned long long fm = __ballot(act && !near);
+        nm[r] = __ballot(near);
+        if (w != 0u && (lane & 31u) == 0) l_pend[tl >> 5] = (lane & 32u) ? (uint32_t)(fm >> 32) : (uint32_t)fm;  // (its 32 lanes have read the word)
+        n_near += (uint32_t)__popcll(nm[r]);
+        n_far += (uint32_t)__popcll(fm);
       }
-      uint32_t base = 0;
       if (n_near) {
+        uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&s_lv[ps][0], n_near);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t r = 0; r < R; ++r) {
+          if ((nm[r] >> lane) & 1ull) a_state[base + (uint32_t)__popcll(nm[r] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + MB_THREADS * r);
+          base += (uint32_t)__popcll(nm[r]);
+        }
       }
-      for (uint32_t r = 0; r < R; ++r) {
-        const unsigned long long nm = __ballot(near_[r]);
-        if (near_[r]) a_state[base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (uint16_t)(tid + MB_THREADS * r);
-        base += (uint32_t)__popcll(nm);
-      }
-      if (__ballot(n_far != 0u)) {
-        n_far += __shfl_xor(n_far, 32);
-        if (lane == 0 && n_far) atomicAdd(&s_lv[ps][3], n_far);
-      }
+      if (n_far && lane == 0) atomicAdd(&s_lv[ps][3], n_far);
     }
     __syncthreads();  // B2
     RS_STAMP(1);
@@ -376,104 +440,73 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       break;
     }
 
-    // ---------------- expansion: as sssp_mbox_kernel's, messages into the regions of level lvl + 1 (write-through stores)
-    uint32_t sent = 0;
+    // ---------------- expansion (rs_expand_round), messages into the regions of level lvl + 1 (write-through stores)
     {
       const uint32_t sub = tid & 15u, grp = tid >> 4;
       unsigned long long* __restrict__ msgs_out = (unsigned long long*)rv.msgs[ps ^ 1u];
-      constexpr uint32_t ROUND = (MB_THREADS / 16) * MB_UNROLL;
-      for (uint32_t r0 = 0; r0 < an; r0 += ROUND) {
-        uint32_t tl_[MB_UNROLL];
-        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-          const uint32_t e = r0 + grp + (MB_THREADS / 16) * u;
-          tl_[u] = e < an ? (uint32_t)a_state[e] : 0xFFFFFFFFu;
-        }
-        uint32_t i_[MB_UNROLL], end_[MB_UNROLL], h1_[MB_UNROLL];
-        float d_[MB_UNROLL];
-        bool more = false;
-        for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-          i_[u] = end_[u] = h1_[u] = 0;
-          d_[u] = 0.0f;
-          if (tl_[u] != 0xFFFFFFFFu) {
-            const unsigned long long k = lkey[tl_[u]];
-            const uint32_t b = l_off[tl_[u]];
-            end_[u] = l_off[tl_[u] + 1];
-            d_[u] = dec_f32((uint32_t)(k >> 32));
-            h1_[u] = (uint32_t)k + 1u;
-            i_[u] = b + sub;
-          }
-          more |= i_[u] < end_[u];
-        }
-        more = __any(more);
-        while (more) {
-          uint2 a[MB_UNROLL];
-          bool v[MB_UNROLL];
-          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-            v[u] = i_[u] < end_[u];
-            a[u] = make_uint2(0x7F800000u, 0u);
-            if (v[u]) a[u] = wn[i_[u]];
-          }
-          uint32_t enc[MB_UNROLL], slot[MB_UNROLL];
-          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-            const float c = (d_[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-            v[u] = v[u] && c < INF;                                    // +inf never improves (shortest_path.rs:226)
-            enc[u] = enc_f32(c);
-            if (v[u] && (a[u].y >> MB_LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
-              RS_APPLY(a[u].y & (MB_B - 1u), ((unsigned long long)enc[u] << 32) | h1_[u]);
-              v[u] = false;
-            }
-          }
-          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-            slot[u] = 0;
-            if (v[u]) slot[u] = atomicAdd(&l_cur[a[u].y >> MB_LOG], 1u);
-          }
-          more = false;
-          for (uint32_t u = 0; u < MB_UNROLL; ++u) {
-            if (v[u]) {
-              const uint2 msg = make_uint2((h1_[u] << MB_LOG) | (a[u].y & (MB_B - 1u)), enc[u]);
-              const uint32_t db = a[u].y >> MB_LOG, rel = slot[u] - l_base[db];
-              if (rel < stg) l_stage[db * stg + rel] = msg;
-              else __hip_atomic_store(&msgs_out[l_roff_out[db] + slot[u]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-              if (h1_[u] >> MB_HOP_BITS) ctl->pad = 1u;
-            }
-            sent += (uint32_t)__popcll(__ballot(v[u]));
-            i_[u] += 16;
-            more |= i_[u] < end_[u];
-          }
-          more = __any(more);
-        }
+      const __amdgpu_buffer_rsrc_t rs_out = ps ? rs0 : rs1;
+      constexpr uint32_t G = MB_THREADS / 16, ROUND = G * 8u;
+      static_assert(MB_THREADS == 1024, "a resident workgroup is sixteen waves");
+      const uint32_t an_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)an);
+      uint32_t sent = 0;
+#define RS_EXPAND(U_, r0_) rs_expand_round<LOG, U_>(r0_, an_u, grp, sub, wn, a_state, lkey, l_pend, l_off, j, l_cur, l_base, l_stage, stg, l_roff_out, msgs_out, &ctl->pad)
+      if (an_u <= ROUND) {
+        // one round (every level but a band's widest): the staged runs start at the regions' first slots
+        if (an_u > 4u * G) sent = RS_EXPAND(8, 0u);
+        else if (an_u > 2u * G) sent = RS_EXPAND(4, 0u);
+        else if (an_u > G) sent = RS_EXPAND(2, 0u);
+        else if (an_u) sent = RS_EXPAND(1, 0u);
         __syncthreads();
         // flush: destination d's staged messages leave as one contiguous run (4 lanes per destination), two messages per
         // 16-byte write-through store (an 8-byte `sc1` store is a fabric write of its own: half the transactions to drain);
-        // message k sits at unit ro + k, and ro is even: pairs start at even k
-        for (uint32_t rg = reg; rg < nb; rg += MB_THREADS / MB_LPR) {
-          const uint32_t first = l_base[rg], last = first + min(l_cur[rg] - first, stg), ro = l_roff_out[rg];
-          const uint2* __restrict__ stv = l_stage + rg * stg - first;  // staged message k at stv[k]
-          const uint32_t p_lo = (first + 1u) & ~1u;
-          if (q == 0 && (first & 1u) && last > first) {
-            const uint2 msg = stv[first];
-            __hip_atomic_store(&msgs_out[ro + first], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          for (uint32_t k = p_lo + 2u * q; k + 1u < last; k += 2u * MB_LPR) {
+        // message k sits at unit ro + k, and ro is even
+        if (reg < nb) {
+          const uint32_t last = min(l_cur[reg], stg), ro = l_roff_out[reg];
+          const uint2* __restrict__ stv = l_stage + reg * stg;
+          for (uint32_t k = 2u * q; k + 1u < last; k += 2u * MB_LPR) {
             const uint2 m0 = stv[k], m1 = stv[k + 1u];
             const rs_u32x4 pr = {m0.x, m0.y, m1.x, m1.y};
-            __builtin_amdgcn_raw_buffer_store_b128(pr, ps ? rs0 : rs1, (int)((ro + k) * 8u), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(pr, rs_out, (int)((ro + k) * 8u), 0, 16);
           }
-          if (q == 1 && last > p_lo && ((last - p_lo) & 1u)) {
+          if (q == 1 && (last & 1u)) {
             const uint2 msg = stv[last - 1u];
             __hip_atomic_store(&msgs_out[ro + last - 1u], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        if (r0 + ROUND < an) {
+      } else {
+        // several rounds: after each, the staged runs go out behind what the earlier rounds wrote (l_base) and the counts start again
+        for (uint32_t r0 = 0; r0 < an_u; r0 += ROUND) {
+          sent |= RS_EXPAND(8, r0);
           __syncthreads();
-          for (uint32_t d = tid; d < nb; d += MB_THREADS) l_base[d] = l_cur[d];
+          if (reg < nb) {
+            const uint32_t first = l_base[reg], cnt = l_cur[reg], last = first + min(cnt, stg), ro = l_roff_out[reg];
+            const uint2* __restrict__ stv = l_stage + reg * stg - first;  // staged message k at stv[k]
+            const uint32_t p_lo = (first + 1u) & ~1u;
+            if (q == 0 && (first & 1u) && last > first) {
+              const uint2 msg = stv[first];
+              __hip_atomic_store(&msgs_out[ro + first], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (uint32_t k = p_lo + 2u * q; k + 1u < last; k += 2u * MB_LPR) {
+              const uint2 m0 = stv[k], m1 = stv[k + 1u];
+              const rs_u32x4 pr = {m0.x, m0.y, m1.x, m1.y};
+              __builtin_amdgcn_raw_buffer_store_b128(pr, rs_out, (int)((ro + k) * 8u), 0, 16);
+            }
+            if (q == 1 && last > p_lo && ((last - p_lo) & 1u)) {
+              const uint2 msg = stv[last - 1u];
+              __hip_atomic_store(&msgs_out[ro + last - 1u], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (q == 0) {  // (the four lanes of a destination are one wave: they have read both)
+              l_base[reg] = first + cnt;
+              l_cur[reg] = 0;
+            }
+          }
           __syncthreads();
         }
       }
+#undef RS_EXPAND
+      if (__any(sent != 0u) && lane == 0) s_lv[ps][1] = 1u;
     }
     RS_STAMP(2);
-    if (lane == 0 && sent) atomicAdd(&s_lv[ps][1], sent);
     // ---------------- what waits now: the far states of the scan and the states lowered from inside the block (every
     //                  expansion's LDS atomics are behind the last round's barrier; no round at all: the scan's are behind B2)
     if (tid < MB_B / 32) {
@@ -488,7 +521,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       const uint32_t total_sent = s_lv[ps][1], npend = s_lv[ps][2], nfar = s_lv[ps][3];
       last_nfar = nfar;
       if (tid < nb) {
-        const uint32_t c = l_cur[tid];
+        const uint32_t c = l_base[tid] + l_cur[tid];
         const rs_u32x4 h = {tag_base | (lvl + 1u), c, (an & 0xFFFFu) | (nfar << 16), (npend & 0xFFFFu) | ((total_sent != 0u ? 1u : 0u) << 16)};
         __builtin_amdgcn_raw_buffer_store_b128(h, ps ? rs0 : rs1, (int)((l_roff_out[tid] - RS_HDR) * 8u), 0, 16);
         l_cur[tid] = 0;
