@@ -76,8 +76,11 @@ def parse_args():
                          "context gets the rest; hipExtStreamCreateWithCUMask).  0 = no partitioning (default: with the "
                          "string o T kernel the batch is 0.19 ms and partitioning only takes CUs from shortest_path; it "
                          "paid, 1.04 -> 0.88 ms, while the batch ran on the general 0.7 ms kernel).")
-    ap.add_argument("--order", choices=["s2-first", "s1-first"], default="s2-first",
-                    help="which request of a step is enqueued first when they overlap")
+    ap.add_argument("--order", choices=["s2-first", "s1-first"], default="s1-first",
+                    help="which request of a step is enqueued first when they overlap.  s1-first (default): the "
+                         "relaxation is the longer chain of the two now that a batch's results cost the host ~6 us "
+                         "(round 4), and its resident launch leaves the batch kernel the compute units it needs.  "
+                         "s2-first was the order of rounds 2-3, when every sweep was a GPU-wide launch.")
     args = ap.parse_args()
     args.overlap = not args.serial
     return args
@@ -446,9 +449,11 @@ def main():
             sp = dt.shortest_path()
             outs, n_arcs = rustfst_amd.compose_shortest_path_batch(daccs, dt2)
         else:
-            # S2 first: its one long, narrow kernel (one wave per acceptor) must be in flight BEFORE the chain of
-            # GPU-wide relaxation sweeps is queued, or the hardware runs the chain to its end first
-            # (tools/ubench_concurrency.hip: 623 us overlapped vs 904 us serialised).
+            # Order of the two requests (--order).  Rounds 2-3 queued S2 first: its one long, narrow kernel (one wave per
+            # acceptor) had to be in flight BEFORE a chain of GPU-wide relaxation sweeps, or the hardware ran the chain
+            # to its end first (tools/ubench_concurrency.hip: 623 us overlapped vs 904 us serialised).  The resident
+            # relaxation launch (one workgroup on 245 of 256 compute units for the whole WIDE phase) leaves the batch its
+            # compute units whenever it arrives, and S1 is the longer of the two: it goes first (measured: 0.330 -> 0.323 ms).
             p0 = time.perf_counter()
             if args.order == "s2-first":
                 job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
@@ -787,7 +792,7 @@ def main():
             "step_host_phases_us": step_phases_us,
             "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist), "batch_only": batch_only,
             "s1_start_states": "T's own" if world == 1 else f"rank r: ({int(t['start'])} + 104729 r) mod {int(t['n_states'])}",
-            "step_schedule": "serial (one stream)" if (not args.overlap) else "S2 batch enqueued async on stream 2, S1 on stream 1, then S2 collected (two contexts, one host thread); "
+            "step_schedule": "serial (one stream)" if (not args.overlap) else ("S1 (shortest_path(T)) enqueued async on stream 1, then the S2 batch on stream 2" if args.order == "s1-first" else "S2 batch enqueued async on stream 2, then S1 on stream 1") + ", S2 collected, S1 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {

@@ -78,6 +78,44 @@ PinnedBuf::~PinnedBuf() {
   if (p) (void)hipHostFree(p);
 }
 
+std::shared_ptr<PinnedBlock> PinnedRing::take(size_t bytes) {
+  PinnedBlock* blk = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    size_t best = free_.size();
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i]->cap >= bytes && (best == free_.size() || free_[i]->cap < free_[best]->cap)) best = i;
+    if (best != free_.size()) {
+      blk = free_[best];
+      free_.erase(free_.begin() + (std::ptrdiff_t)best);
+    }
+  }
+  if (!blk) {
+    auto fresh = std::make_unique<PinnedBlock>();
+    fresh->cap = (std::max<size_t>(bytes, 4096) + 65535) & ~(size_t)65535;
+    HIP_CHECK(hipHostMalloc(&fresh->p, fresh->cap, hipHostMallocDefault));
+    blk = fresh.release();
+  }
+  std::weak_ptr<PinnedRing> ring = weak_from_this();
+  return std::shared_ptr<PinnedBlock>(blk, [ring](PinnedBlock* b) {
+    if (auto r = ring.lock()) {
+      std::lock_guard<std::mutex> lk(r->mu_);
+      if (r->free_.size() < 8) {
+        r->free_.push_back(b);
+        return;
+      }
+    }
+    (void)hipHostFree(b->p);
+    delete b;
+  });
+}
+PinnedRing::~PinnedRing() {
+  for (PinnedBlock* b : free_) {
+    (void)hipHostFree(b->p);
+    delete b;
+  }
+}
+
 }  // namespace wfst
 
 DeviceArena::~DeviceArena() {

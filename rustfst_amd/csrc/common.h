@@ -100,6 +100,23 @@ struct PinnedBuf {
   ~PinnedBuf();
 };
 
+// Pinned host blocks handed out by reference count: the kernel of a fused batch writes its results and path arcs into one,
+// and the path FSTs the batch returns point into it (wfst_fst::path_form) until somebody asks for their arrays.  The
+// block goes back to the ring when the job and every such result are gone (a serving loop alternates between two).
+struct PinnedBlock {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+class PinnedRing : public std::enable_shared_from_this<PinnedRing> {
+ public:
+  std::shared_ptr<PinnedBlock> take(size_t bytes);
+  ~PinnedRing();
+
+ private:
+  std::mutex mu_;
+  std::vector<PinnedBlock*> free_;
+};
+
 }  // namespace wfst
 
 // ---------------------------------------------------------------- handles
@@ -135,6 +152,7 @@ struct wfst_ctx {
     uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   } sweep_graph[3];  // [0]: first batch of a solve (predicted length), [1]: 8 sweeps per replay, [2]: 64
   wfst::PinnedBuf pinned_flags;  // host mirror of the per-sweep activity flags (its address is baked into the graphs)
+  std::shared_ptr<wfst::PinnedRing> pinned_ring = std::make_shared<wfst::PinnedRing>();  // result blocks of the fused batches
   int n_cus = 256;
 };
 
@@ -219,6 +237,14 @@ struct wfst_fst {
   bool has_negative = false;  // some arc weight < 0
   HostCsr host;
   DeviceCsr dev;
+  // A linear path whose host arrays have not been built (has_host and has_dev both false): the result of a fused batch.
+  // Its n_arcs arcs sit at path_arcs inside path_block — the pinned block the kernel wrote the whole batch's results into,
+  // shared by them — and path_final is the final weight of the path's end (state 0 of the path FST, shortest_path.rs:257-272).
+  // ensure_host() builds the three arrays on first use and lets go of the block.
+  std::shared_ptr<wfst::PinnedBlock> path_block;
+  const wfst_tr* path_arcs = nullptr;
+  float path_final = 0.0f;
+  bool path_form = false;
   // reverse(fst) (reverse.rs:33-87) as host CSR: built on the GPU on first use by the n>1 shortest-path search
   mutable std::shared_ptr<wfst::RevFst> rev_host;
   // transpose (in-arcs as {source state, arc position}) for the shortest-path backtrace; built on the second

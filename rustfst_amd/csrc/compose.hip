@@ -92,6 +92,10 @@ struct Result {
   float final_weight, total;
   uint32_t path_off;  // offset of the path arcs in the packed path buffer
   uint32_t n_levels;
+  uint32_t facts;     // string_compose_sp_kernel: OR of the path arcs' property facts (fst_props.h: path_arc_facts), or
+                      // PATH_FACTS_NONE: the host knows the path FST's properties without reading its arcs back
+  uint32_t done;      // string_compose_sp_kernel, results in pinned memory: the run's ticket, written after everything else of
+                      // the problem (system-scope fence in between): the host waits for these words instead of the stream
 #ifdef WFST_PHASE_TIMING
   unsigned long long dbg[8];
 #endif
@@ -578,6 +582,7 @@ __global__ void __launch_bounds__(64) compose_wave_kernel(const ProblemDesc* __r
   res.final_weight = res.total = INF;
   res.path_off = 0;
   res.n_levels = 0;
+  res.facts = props::PATH_FACTS_NONE;
 
   __shared__ FastStage stg;
   PT_DECL
@@ -1030,7 +1035,7 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
                                                                 Result* __restrict__ results, wfst_tr* __restrict__ path_buf,
                                                                 uint32_t path_cap, uint32_t* __restrict__ path_cursor,
                                                                 uint32_t n_problems, uint32_t maxs, uint64_t f2_n_arcs,
-                                                                uint32_t scalar_rows) {
+                                                                uint32_t scalar_rows, uint32_t done_ticket) {
   extern __shared__ uint32_t s_dyn[];
   const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= n_problems) return;
@@ -1039,6 +1044,13 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
   float* const s_w = reinterpret_cast<float*>(s_ol + maxs);                 // weight of that arc (w1 (x) w2)
   uint32_t* const s_pth = s_ol + 2u * maxs;                                 // states of the best path, from the final one backwards
   const uint32_t lane = lane_id();
+  // the problem's result, then (everything this wave wrote is in host memory) its ticket
+#define STR_RESULT() do {                                                                                  \
+    res.done = 0u;                                                                                         \
+    if (lane == 0) results[p] = res;                                                                       \
+    __threadfence_system();                                                                                \
+    if (lane == 0) __hip_atomic_store(&results[p].done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+  } while (0)
   const FstView f1 = descs[p].f1;
   Result res;
   res.status = ST_OK;
@@ -1048,8 +1060,9 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
   res.final_weight = res.total = INF;
   res.path_off = 0;
   res.n_levels = 0;
+  res.facts = props::PATH_FACTS_NONE;
   if (f1.start < 0 || f2.start < 0) {  // compute_start -> None
-    if (lane == 0) results[p] = res;
+    STR_RESULT();
     return;
   }
   const uint32_t L = f1.n_states - 1u;  // number of arcs of the string
@@ -1201,7 +1214,7 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
   }
   if (!ok) {
     res.status = ST_NOT_A_STRING_CASE;
-    if (lane == 0) results[p] = res;
+    STR_RESULT();
     return;
   }
   res.n_states = hi;
@@ -1244,15 +1257,27 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
       res.status = ST_OVERFLOW_PATH;
     } else {
       res.path_off = poff;
+      uint32_t facts = 0;
       for (uint32_t k = lane; k < L; k += 64) {  // arc k enters the k-th state created by the backtrace (shortest_path.rs:257-272)
         const uint32_t st = s_pth[k];
         const uint32_t il = ld_global16(f1.arcs + (L - 1u - k)).x;
-        store_arc(path_buf + poff + k, il, s_ol[st], s_w[st], k);
+        const uint32_t ol = s_ol[st];
+        const float w = s_w[st];
+        store_arc(path_buf + poff + k, il, ol, w, k);
+        // fst_props.h path_arc_facts (is_zero / is_one: the reference's approximate ==, semiring.rs:68-73,159-168)
+        const bool w_zero = w <= INF + props::KDELTA && INF <= w + props::KDELTA;
+        const bool w_one = w <= props::KDELTA && 0.0f <= w + props::KDELTA;
+        facts |= (il != ol ? 1u : 0u) | (il == WFST_EPS_LABEL ? 2u : 0u) | (il == WFST_EPS_LABEL && ol == WFST_EPS_LABEL ? 4u : 0u) |
+                 (ol == WFST_EPS_LABEL ? 8u : 0u) | (!w_zero && !w_one ? 64u : 0u) | 128u;
       }
+      for (int d = 32; d >= 1; d >>= 1) facts |= __shfl_xor(facts, d);
+      res.facts = facts;
     }
   }
-  if (lane == 0) results[p] = res;
+  STR_RESULT();
 }
+
+#undef STR_RESULT
 
 // ---------------------------------------------------------------- host side
 // ComposeFstOp::match_type (compose_fst_op.rs:169-197) with SortedMatcher::match_type
@@ -1326,6 +1351,7 @@ struct BatchRun {
   uint32_t eager = 0;
   const wfst_tr* host_paths = nullptr;
   bool string_kernel = false;  // this run went through string_compose_sp_kernel
+  uint32_t done_ticket = 0;    // ... with results in pinned memory: what every Result::done holds when its problem is finished
   // descriptors read from, results and path arcs written to pinned host memory by the kernel itself: no copy commands
   // (each is a ~3 us API call on the host and a ~5 us command on the GPU) — when the whole path buffer fits there
   bool zero_copy = false;
@@ -1386,11 +1412,15 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
       maxs = need <= 512 ? 512u : (need <= 1024 ? 1024u : STR_MAXS);
       wpb = (64u << 10) / (16u * maxs);
     }
+    static std::atomic<uint32_t> tickets{0};
+    do run.done_ticket = tickets.fetch_add(1, std::memory_order_relaxed) + 1u; while (run.done_ticket == 0u);
+    if (run.zero_copy)
+      for (size_t i = 0; i < n; ++i) run.h_res[i].done = 0u;
     string_compose_sp_kernel<<<(uint32_t)((n + wpb - 1) / wpb), 64 * wpb, (size_t)wpb * 16u * maxs, st>>>(
         k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p, (uint32_t)n, maxs, f2.n_arcs,
         // scalar arc-block loads where a wave is alone on its SIMD (a handful of strings): -7 % per level; with eight waves
         // per compute unit the other waves hide the vector latency anyway and the extra scalar instructions cost 3 %
-        std::getenv("WFST_STRING_SCALAR") ? (uint32_t)std::atoi(std::getenv("WFST_STRING_SCALAR")) : (n <= 8 ? 1u : 0u));
+        std::getenv("WFST_STRING_SCALAR") ? (uint32_t)std::atoi(std::getenv("WFST_STRING_SCALAR")) : (n <= 8 ? 1u : 0u), run.done_ticket);
   } else
     compose_wave_kernel<FLAGS><<<(uint32_t)n, 64, 0, st>>>(k_desc, f2, caps, run.arena.p, run.stride, k_res, k_paths, path_cap,
                                                             run.d_cursor.p);
@@ -1411,7 +1441,24 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
   uint32_t* h_cursor = run.h_cursor;
   const bool want_paths = run.want_paths;
   const uint32_t path_cap = run.path_cap;
-  HIP_CHECK(hipStreamSynchronize(st));
+  // The string kernel's results in pinned memory carry a ticket each: the host reads them as they land — a stream wait first
+  // retires whatever else has finished on the stream and wakes up ~10 us after the kernel — and falls back to the stream.
+  bool seen = false;
+  if (run.string_kernel && run.zero_copy && !ctx->profiling && !std::getenv("WFST_BATCH_STREAM_WAIT")) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t next = 0;
+    for (uint32_t spins = 0;; ++spins) {
+      while (next < n && ((const volatile Result*)h_res)[next].done == run.done_ticket) ++next;
+      if (next == n) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;  // (a long batch: sleep on the stream)
+    }
+  }
+  if (!seen) HIP_CHECK(hipStreamSynchronize(st));
   if (ctx->profiling) {
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -1466,8 +1513,30 @@ wfst_fst* path_to_fst(wfst_ctx* ctx, const Result& r, const wfst_tr* path_arcs) 
   } else {
     h.offsets.push_back(0);
   }
-  return make_host_fst(ctx, n_states, start, props::linear_path_props(r.has_path != 0, r.hops, r.final_weight, path_arcs),
-                       std::move(h));
+  const uint64_t p = r.has_path && r.facts != props::PATH_FACTS_NONE
+                         ? props::linear_path_props_from_facts(true, r.hops, r.final_weight, r.facts)
+                         : props::linear_path_props(r.has_path != 0, r.hops, r.final_weight, path_arcs);
+  return make_host_fst(ctx, n_states, start, p, std::move(h));
+}
+
+// ... the same FST as a view: the arcs stay where the kernel wrote them (the job's pinned block, kept alive by the handle)
+// until somebody reads the FST's arrays (ensure_host).  A batch of 64 costs ~8 us this way instead of ~47 (three vectors,
+// 5 KB written and 3 KB copied per path), behind the kernel, on the critical path of a serving loop.
+wfst_fst* path_view_fst(wfst_ctx* ctx, const Result& r, const wfst_tr* path_arcs, const std::shared_ptr<PinnedBlock>& block) {
+  auto f = std::make_unique<wfst_fst>();
+  f->ctx = ctx;
+  f->owner_pool = ctx->pool;
+  f->device = ctx->device;
+  f->n_states = r.hops + 1;
+  f->n_arcs = r.hops;
+  f->start = r.hops;
+  f->props = (r.facts != props::PATH_FACTS_NONE ? props::linear_path_props_from_facts(true, r.hops, r.final_weight, r.facts)
+                                                : props::linear_path_props(true, r.hops, r.final_weight, path_arcs)) & props::ALL;
+  f->path_block = block;
+  f->path_arcs = path_arcs;
+  f->path_final = r.final_weight;
+  f->path_form = true;
+  return f.release();
 }
 
 const char* status_name(uint32_t s) {
@@ -1567,6 +1636,7 @@ struct wfst_batch_job {
   std::vector<size_t> todo_s;
   wfst::BatchRun run_s;
   wfst::FstView v2_s{};  // fst2 with its per-arc destination ranges
+  std::shared_ptr<wfst::PinnedBlock> pin_block;  // descriptors, results and path arcs of the job's runs (pinned host memory)
 };
 
 namespace wfst {
@@ -1638,7 +1708,9 @@ wfst_batch_job* compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst*
   }
   const size_t pin_s = d_str.empty() ? 0 : run_pinned_bytes(d_str.size(), e_s);
   const size_t pin_g = d_gen.empty() ? 0 : run_pinned_bytes(d_gen.size(), e_g);
-  char* pin = (char*)ctx->pinned_big.get(pin_s + pin_g + 256);
+  // (a block of the context's ring, not its one staging buffer: the path FSTs this job returns keep pointing into it)
+  job->pin_block = ctx->pinned_ring->take(pin_s + pin_g + 256);
+  char* pin = (char*)job->pin_block->p;
   if (!d_str.empty())
     launch_begin<FLAG_SP>(ctx, d_str, job->v2_s, make_caps(job->est_s, job->est_a), job->run_s, true, e_s, pin, true, max_str_states,
                           (uint32_t)std::min<uint64_t>(eager_s, 0x7FFFFFFFull));
@@ -1657,8 +1729,11 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
     for (size_t i = 0; i < n; ++i) outs[i] = nullptr;
   // result i: a path FST handle, or (sink) its record — straight from the kernel's result and path buffers
   const size_t rec_words = sink ? 4 + 4 * (size_t)sink->max_arcs : 0;
-  auto emit = [&](size_t i, const Result& r, const wfst_tr* arcs) {
+  // (views only into blocks of serving size: one surviving result would otherwise keep tens of MB pinned)
+  const bool views = job->pin_block && job->pin_block->cap <= (4u << 20) && !std::getenv("WFST_BATCH_EAGER_PATHS");
+  auto emit = [&](size_t i, const Result& r, const wfst_tr* arcs, bool in_block) {
     if (sink) pack_path_record(sink->out + i * rec_words, sink->max_arcs, r.has_path != 0, r.hops, r.final_weight, arcs);
+    else if (views && in_block && r.has_path && r.hops) outs[i] = path_view_fst(ctx, r, arcs, job->pin_block);
     else outs[i] = path_to_fst(ctx, r, arcs);
   };
   uint64_t tot_arcs = 0, tot_states = 0, n_string_ok = 0;
@@ -1691,7 +1766,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
       parallel_chunks(n_thr, ok.size(), 64, [&](unsigned, uint64_t b, uint64_t e) {
         for (uint64_t q = b; q < e; ++q) {
           const Result& r = job->run_s.results[ok[q]];
-          emit(job->todo_s[ok[q]], r, r.has_path && r.hops ? job->run_s.host_paths + r.path_off : nullptr);
+          emit(job->todo_s[ok[q]], r, r.has_path && r.hops ? job->run_s.host_paths + r.path_off : nullptr, job->run_s.zero_copy);
         }
       });
       if (timing)
@@ -1710,7 +1785,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
             }
             tot_arcs += r.n_arcs;
             tot_states += r.n_states;
-            emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
+            emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr, job->run.zero_copy && job->run.host_paths == job->run.h_eager);
           }
           more.insert(more.end(), again.begin(), again.end());
         }
@@ -1735,7 +1810,7 @@ void compose_shortest_path_batch_end(wfst_batch_job* job_raw, wfst_fst** outs, u
         }
         tot_arcs += r.n_arcs;
         tot_states += r.n_states;
-        emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr);
+        emit(job->todo[k], r, r.has_path && r.hops ? job->run.host_paths + r.path_off : nullptr, job->run.zero_copy && job->run.host_paths == job->run.h_eager);
       }
       if (timing) std::fprintf(stderr, "[batch_end] assemble %.1f us\n", std::chrono::duration<double, std::micro>(tnow() - t_b).count());
       job->todo.swap(again);

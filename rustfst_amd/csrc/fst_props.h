@@ -182,6 +182,30 @@ inline uint64_t linear_path_props(bool has_path, uint32_t hops, float final_weig
   return shortest_path(p, true) & ALL;
 }
 
+// The same word from the UNION of the arcs' facts, in add_trs_by_facts's encoding (1 il != ol | 2 il == 0 | 4 il == 0 and
+// ol == 0 | 8 ol == 0 | 64 weighted | 128 nextstate <= state; a path's states have one arc each: no label-order facts).
+// Every effect of add_tr is a sticky set / clear decided by one fact, followed by masks that are the same for every
+// arc: the order of the arcs does not matter, and three applications of the union reach the fixed point.  The
+// string o T kernel ORs the facts of a path's arcs while it writes them (compose.hip: Result::facts), so that the host
+// does not read the arcs back to know the properties; tests/test_host.py (props_check) compares this function with
+// linear_path_props on every fact sequence of up to four arcs.
+constexpr uint32_t PATH_FACTS_NONE = 0xFFFFFFFFu;  // the kernel did not provide them: scan the arcs
+inline uint32_t path_arc_facts(uint32_t ilabel, uint32_t olabel, float weight) {
+  return (ilabel != olabel ? 1u : 0u) | (ilabel == WFST_EPS_LABEL ? 2u : 0u) |
+         (ilabel == WFST_EPS_LABEL && olabel == WFST_EPS_LABEL ? 4u : 0u) | (olabel == WFST_EPS_LABEL ? 8u : 0u) |
+         (!is_zero(weight) && !is_one(weight) ? 64u : 0u) | 128u;
+}
+inline uint64_t linear_path_props_from_facts(bool has_path, uint32_t hops, float final_weight, uint32_t facts_union) {
+  uint64_t p = NULL_PROPS;
+  if (has_path) {
+    p = add_state(p);
+    p = set_final(p, nullptr, &final_weight);
+    for (uint32_t j = 0; j < (hops < 3u ? hops : 3u); ++j) p = add_trs_by_facts(add_state(p), facts_union);
+    p = set_start(p);
+  }
+  return shortest_path(p, true) & ALL;
+}
+
 // project_properties (fst_properties/mutate_properties.rs:365-445) as applied by project() with the all_properties() mask
 // (algorithms/projection.rs:91-94)
 inline uint64_t project(uint64_t in, bool project_output) {

@@ -177,6 +177,7 @@ bool has_input_epsilons(wfst_ctx* ctx, const wfst_fst* f) {
       f->ieps_state = 2;
     } else if (!f->has_dev || f->n_states == 0) {
       f->ieps_state = 1;
+      if (f->path_form) ensure_host(f);
       if (f->has_host)
         for (const wfst_tr& a : f->host.arcs)
           if (a.ilabel == WFST_EPS_LABEL) f->ieps_state = 2;
@@ -557,6 +558,7 @@ void project_device(wfst_ctx* ctx, wfst_fst* f, bool project_output) {
 
 void ensure_device(wfst_fst* f) {
   if (f->has_dev) return;
+  if (f->path_form) ensure_host(f);
   if (!f->has_host) throw Error("FST handle holds no data");
   wfst_ctx* ctx = f->ctx;
   std::unique_ptr<wfst_fst> tmp(upload_from_host(ctx, f->n_states, f->start, f->host.offsets.data(), f->host.arcs.data(),
@@ -601,6 +603,10 @@ void pack_path_record(uint32_t* rec, uint32_t max_arcs, bool valid, uint32_t n_a
 }
 
 void pack_path_record(uint32_t* rec, uint32_t max_arcs, const wfst_fst* f) {
+  if (f->path_form) {  // straight from the batch's block
+    pack_path_record(rec, max_arcs, f->n_states != 0, (uint32_t)f->n_arcs, f->n_states ? f->path_final : INF, f->n_arcs ? f->path_arcs : nullptr);
+    return;
+  }
   ensure_host(f);
   if (f->n_states && f->n_arcs + 1 != f->n_states) throw Error("wfst_fst_pack_paths: not a linear path FST");
   pack_path_record(rec, max_arcs, f->n_states != 0, (uint32_t)f->n_arcs, f->n_states ? f->host.finals[0] : INF,
@@ -610,6 +616,22 @@ void pack_path_record(uint32_t* rec, uint32_t max_arcs, const wfst_fst* f) {
 void ensure_host(const wfst_fst* cf) {
   if (cf->has_host) return;
   wfst_fst* f = const_cast<wfst_fst*>(cf);  // cache fill only
+  if (f->path_form) {  // a batch result still pointing into its block: the reference's linear path FST (shortest_path.rs:257-272)
+    const uint32_t hops = (uint32_t)f->n_arcs;
+    f->host.finals.assign(f->n_states, INF);
+    f->host.offsets.assign(1, 0u);
+    if (f->n_states) {
+      f->host.finals[0] = f->path_final;
+      if (hops) f->host.arcs.assign(f->path_arcs, f->path_arcs + hops);
+      f->host.offsets.resize((size_t)f->n_states + 1);
+      for (uint32_t k = 0; k <= hops; ++k) f->host.offsets[k + 1] = k;
+    }
+    f->has_host = true;
+    f->path_form = false;
+    f->path_arcs = nullptr;
+    f->path_block.reset();
+    return;
+  }
   if (!f->has_dev) throw Error("FST handle holds no data");
   wfst_ctx* ctx = f->ctx;
   HIP_CHECK(hipSetDevice(ctx->device));

@@ -14,6 +14,7 @@
 // SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
 #include <cstdlib>
 #include <cstddef>
+#include <chrono>
 #include <cstring>
 
 #include <rocprim/device/device_scan.hpp>
@@ -90,6 +91,10 @@ constexpr uint32_t TAIL_BLOCKS = 128;
 struct TailOut {
   uint32_t has_path, hops, pad, f_parent;
   float final_weight, total;
+  uint32_t done;  // the launch's ticket, written last (after a system-scope fence): the host waits for this word instead of
+                  // a HIP event (an event / stream wait retires the stream's finished launches first: ~15 us when ten of them
+                  // are waiting, on the critical path of every query)
+  uint32_t pad_;
 };
 
 // threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
@@ -645,7 +650,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
                                                          const uint4* __restrict__ rev_arc, wfst_tr* __restrict__ out,
                                                          uint32_t out_cap, TailOut* __restrict__ hout,
                                                          uint32_t* __restrict__ improved_ring, uint32_t adv_count,
-                                                         uint32_t* __restrict__ host_ring) {
+                                                         uint32_t* __restrict__ host_ring, uint32_t done_ticket) {
   __shared__ unsigned long long s_best[16];
   __shared__ uint2 s_walk[WALK_LDS];
   __shared__ uint32_t s_last;
@@ -660,6 +665,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
       improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
     }
     if (threadIdx.x == 0) ctl->base = base + adv_count;  // (every lane of the wave has read the old value above)
+    __threadfence_system();  // the mirrored flags are in host memory before this workgroup takes its ticket below
   }
   unsigned long long best = KEY_INF;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -705,7 +711,14 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
     if (lane == 0) {
       ctl->has_path = 0;
       ctl->hops = 0;
-      *hout = TailOut{0u, 0u, pad, 0u, INF, INF};
+      hout->has_path = 0u;
+      hout->hops = 0u;
+      hout->pad = pad;
+      hout->f_parent = 0u;
+      hout->final_weight = INF;
+      hout->total = INF;
+      __threadfence_system();
+      __hip_atomic_store(&hout->done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
@@ -721,8 +734,16 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
     ctl->final_weight = final_weight;
     ctl->total = total;
     // (the walk's own flags go to the host only: a tail that ran ahead of the last sweeps is run again on this block)
-    *hout = TailOut{1u, (pad & 12u) ? (uint32_t)key[fp] : k, pad, fp, final_weight, total};
+    hout->has_path = 1u;
+    hout->hops = (pad & 12u) ? (uint32_t)key[fp] : k;
+    hout->pad = pad;
+    hout->f_parent = fp;
+    hout->final_weight = final_weight;
+    hout->total = total;
   }
+  // (the walk's arcs were written by several lanes of this wave)
+  __threadfence_system();
+  if (lane == 0) __hip_atomic_store(&hout->done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- the reference's tie order on acyclic inputs (wfst_ctx_set_tie_order; include/wfst.h).  rank[s] = position of s in
@@ -1324,11 +1345,32 @@ struct SweepDriver {
 
   void start(bool defer_advance = false) { cur = enqueue_batch(evs[0], defer_advance); }
 
+  // The fused tail's ticket in pinned memory (wfst_sp_job::h_tail->done), when the first batch ends with one: the host waits
+  // for that word — every result of the launch chain is in host memory before it — and falls back to the event.
+  const volatile uint32_t* done_word = nullptr;
+  uint32_t done_ticket = 0;
+  bool done_seen = false;  // the ticket arrived: nothing of this job is still running on the stream
+  void wait_first_batch() {
+    if (done_word && !std::getenv("WFST_SSSP_EVENT_WAIT")) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spins = 0;; ++spins) {
+        if (*done_word == done_ticket) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          done_seen = true;
+          return;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;  // (a long solve: sleep on the event)
+      }
+    }
+    HIP_CHECK(hipEventSynchronize(evs[0]));
+  }
+
   void finish() {
     int which = 0;
     bool done = false;
     if (predicted) {  // expected to finish inside the first batch: no idle sweeps were queued behind it
-      HIP_CHECK(hipEventSynchronize(evs[0]));
+      wait_first_batch();
       done = scan_flags(cur);
       if (!done) {
         extended = true;
@@ -1621,6 +1663,7 @@ struct wfst_sp_job {
   wfst::Ctl* hc = nullptr;
   wfst_tr* h_path = nullptr;
   wfst::TailOut* h_tail = nullptr;  // header of the result, written by sssp_tail_kernel (transpose cached)
+  uint32_t done_ticket = 0;         // what the fused tail writes into h_tail->done when everything else is in host memory
 };
 
 namespace wfst {
@@ -1637,7 +1680,7 @@ void queue_tail(wfst_sp_job* j, const SweepBatch* adv = nullptr) {
   if (j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL")) {  // one launch, header straight into pinned memory
     sssp_tail_kernel<<<std::min<uint32_t>(TAIL_BLOCKS, (n + 1023) / 1024), 1024, 0, st>>>(
         f->dev.finals, sv.key.p, n, sv.ctl.p, f->dev.offsets, f->dev.arcs, j->rev->off.p, j->rev->arc.p, j->h_path,
-        PATH_PINNED, j->h_tail, sv.improved.p, adv ? adv->count : 0u, adv ? j->drv.host_flags(*adv) : nullptr);
+        PATH_PINNED, j->h_tail, sv.improved.p, adv ? adv->count : 0u, adv ? j->drv.host_flags(*adv) : nullptr, j->done_ticket);
     j->fused_tail = true;
     return;
   }
@@ -1674,6 +1717,10 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   j->hc = (Ctl*)pin;
   j->h_tail = (TailOut*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
   j->h_path = (wfst_tr*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63) + 64);
+  static_assert(sizeof(TailOut) <= 64, "the path's arcs follow the header at + 64");
+  static std::atomic<uint32_t> tickets{0};
+  do j->done_ticket = tickets.fetch_add(1, std::memory_order_relaxed) + 1u; while (j->done_ticket == 0u);
+  j->h_tail->done = 0u;
   j->rev = reverse_csr(ctx, f);  // may build the transpose (second query of a large FST): before anything is queued
   if (ctx->profiling) {
     run_relaxation(ctx, f, j->sv);  // per-sweep events: synchronous
@@ -1685,10 +1732,12 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   const bool fuse = j->drv.predicted && j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL") &&
                     !(j->drv.use_graphs && !j->sv.mbox);  // (a sweep graph carries its own advance node)
   j->drv.start(/*defer_advance=*/fuse);
-  if (fuse) {  // the tail closes the batch: flags to the host, base advanced, then the event finish() waits for
+  if (fuse) {  // the tail closes the batch: flags to the host, base advanced, then the ticket (and the event) finish() waits for
     queue_tail(j.get(), &j->drv.cur);
     HIP_CHECK(hipEventRecord(j->drv.evs[0], ctx->stream));
     j->tail_queued = true;
+    j->drv.done_word = &j->h_tail->done;
+    j->drv.done_ticket = j->done_ticket;
   } else if (j->drv.predicted && j->rev) {
     queue_tail(j.get());
     j->tail_queued = true;
@@ -1727,7 +1776,8 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     j->tail_queued = false;
   }
   if (!j->tail_queued) queue_tail(j.get());
-  HIP_CHECK(hipStreamSynchronize(st));
+  // (the ticket of the fused tail was the last thing this job had on the stream: nothing to wait for)
+  if (!(j->tail_queued && j->fused_tail && j->drv.done_seen && !j->drv.extended) || ctx->chain_timing) HIP_CHECK(hipStreamSynchronize(st));
   if (ctx->chain_timing && !ctx->profiling) {  // the sweeps of this query as one chain (wfst_ctx_set_profiling(ctx, 2))
     ctx->stats.relax_ms = 0.0;
     ctx->stats.relax_launches = 0;

@@ -1509,6 +1509,54 @@ def test_fused_batch_as_packed_records(gpu_ctx, n_acc):
     np.testing.assert_array_equal(again, want)
 
 
+def test_batch_results_as_views_into_the_result_block(gpu_ctx, monkeypatch):
+    """The path FSTs of a serving-size fused batch point into the batch's pinned result block until their arrays are asked for
+    (wfst_fst::path_form): every way of reading one — download, pack_paths (straight from the block), the OpenFST writer,
+    a second algorithm on it (upload), conversion to a VectorFst — gives exactly what the eager construction
+    (WFST_BATCH_EAGER_PATHS=1) gives, results outlive later batches on the same context (each batch has a block of its own
+    while results point into it), and a result nobody reads is released like any other."""
+    from rustfst_amd import dist
+    rng = np.random.default_rng(4242)
+    t = random_fst_flat(rng, 300, 6, 5, p_final=0.2, sort="ilabel", min_fanout=2, weight_grid=512)
+    def walk(length):
+        s, labs = int(t["start"]), []
+        for _ in range(length):
+            b, e = int(t["offsets"][s]), int(t["offsets"][s + 1])
+            k = int(rng.integers(b, e))
+            labs.append(int(t["arcs"]["ilabel"][k]))
+            s = int(t["arcs"]["nextstate"][k])
+        return np.array(labs, dtype=np.uint32)
+    accs = [synth.linear_acceptor_flat(walk(int(rng.integers(1, 60))), final_weight=0.5 * (k % 2)) for k in range(40)]
+    accs.append(synth.linear_acceptor_flat(np.array([1, 99, 1], dtype=np.uint32)))  # no path: built eagerly (an empty FST)
+    ctx = rustfst_amd.default_context()
+    dacc, dt = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(accs, ctx)), to_device(t)
+    monkeypatch.setenv("WFST_BATCH_EAGER_PATHS", "1")
+    eager, n_e = rustfst_amd.compose_shortest_path_batch(dacc, dt)
+    eager_flats = [eager[k].to_flat() for k in range(len(accs))]
+    want_rec = dist.pack_device_paths(eager, 64)
+    monkeypatch.delenv("WFST_BATCH_EAGER_PATHS")
+    views, n_v = rustfst_amd.compose_shortest_path_batch(dacc, dt)
+    assert n_v == n_e
+    np.testing.assert_array_equal(dist.pack_device_paths(views, 64), want_rec)  # (read from the block: no arrays built)
+    later = [rustfst_amd.compose_shortest_path_batch(dacc, dt)[0] for _ in range(3)]  # later batches: other blocks
+    np.testing.assert_array_equal(dist.pack_device_paths(views, 64), want_rec)
+    for k in range(len(accs)):
+        assert_flat_identical(views[k].to_flat(), eager_flats[k], f"result {k}")  # download: builds the arrays
+    np.testing.assert_array_equal(dist.pack_device_paths(views, 64), want_rec)  # ... and packing still agrees afterwards
+    fresh = later[0]
+    k = next(i for i in range(len(accs)) if eager_flats[i]["n_states"] > 3)
+    # a second algorithm on a view (upload), the writer, the VectorFst conversion
+    assert_flat_identical(fresh[k].shortest_path().to_flat(), eager[k].shortest_path().to_flat(), "shortest_path of a view")
+    assert later[1][k].to_bytes() == eager[k].to_bytes()
+    va, vb = later[2][k].to_vector_fst(), eager[k].to_vector_fst()
+    assert va.num_states() == vb.num_states() and va.start() == vb.start()
+    for s_ in range(va.num_states()):
+        assert va.num_trs(s_) == vb.num_trs(s_) and va.final_weight(s_) == vb.final_weight(s_)
+    del later, fresh, views  # (results nobody read: released with their blocks)
+    again, _ = rustfst_amd.compose_shortest_path_batch(dacc, dt)
+    np.testing.assert_array_equal(dist.pack_device_paths(again, 64), want_rec)
+
+
 def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
     """Levels wider than one wave, input epsilons in T, epsilons or branching in fst1, explicit non-sequence filters: the
     batch silently takes the general kernel (per problem) and still matches the oracle."""

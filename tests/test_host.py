@@ -226,3 +226,21 @@ def test_label_reachable_host_precompute_matches_oracle(wfst_lib, oracle, seed):
         bad["nextstate"][0] = f["n_states"] + 3
         with pytest.raises(rustfst_amd.WfstError, match="does not exist"):
             rustfst_amd.LookAhead.reachable_from_arrays(f["n_states"], f["offsets"], bad, f["finals"])
+
+
+def test_path_props_from_fact_union(tmp_path):
+    """The property word of a batch result is computed from the OR of its arcs' facts (the string kernel gathers them while
+    it writes the path; fst_props.h: linear_path_props_from_facts) instead of a walk over the arcs (linear_path_props, the
+    reference's incremental add_state / add_tr bookkeeping): the two agree on every sequence of up to six arcs over the
+    fact combinations a single arc can have (3.3 M cases, exhaustive)."""
+    import shutil, subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "props_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(root, "rustfst_amd", "csrc"), "-o", str(exe),
+                           os.path.join(root, "tests", "props_check.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 mismatches" in out.stdout
