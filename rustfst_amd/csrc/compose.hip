@@ -1048,7 +1048,7 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
 #define STR_RESULT() do {                                                                                  \
     res.done = 0u;                                                                                         \
     if (lane == 0) results[p] = res;                                                                       \
-    __threadfence_system();                                                                                \
+    __threadfence_system(); /* (the stores' acknowledgements alone are not enough: measured) */               \
     if (lane == 0) __hip_atomic_store(&results[p].done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
   } while (0)
   const FstView f1 = descs[p].f1;

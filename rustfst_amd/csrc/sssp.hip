@@ -35,6 +35,12 @@ inline uint32_t __float_as_uint_host(float f) {
 constexpr uint64_t KEY_INF = ~0ull;
 constexpr uint32_t GROUP = 16;  // lanes cooperating on one frontier state (average fan-out ~10)
 
+// What the tail writes for the host is in host memory before a ticket stored after this is.  (Waiting for the stores'
+// acknowledgements alone — `s_waitcnt vmcnt(0)`, without the L2 write-back of the system-scope fence — is NOT enough even
+// for fine-grained pinned memory: measured, a 512-problem batch read results that had not landed.  The fence costs the
+// tail kernel ~2 us.)
+__device__ __forceinline__ void host_stores_done() { __threadfence_system(); }
+
 __device__ __forceinline__ uint32_t enc_f32(float f) {
   uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -665,7 +671,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
       improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
     }
     if (threadIdx.x == 0) ctl->base = base + adv_count;  // (every lane of the wave has read the old value above)
-    __threadfence_system();  // the mirrored flags are in host memory before this workgroup takes its ticket below
+    host_stores_done();  // the mirrored flags are in host memory before this workgroup takes its ticket below
   }
   unsigned long long best = KEY_INF;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -717,7 +723,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
       hout->f_parent = 0u;
       hout->final_weight = INF;
       hout->total = INF;
-      __threadfence_system();
+      host_stores_done();
       __hip_atomic_store(&hout->done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
@@ -742,7 +748,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
     hout->total = total;
   }
   // (the walk's arcs were written by several lanes of this wave)
-  __threadfence_system();
+  host_stores_done();
   if (lane == 0) __hip_atomic_store(&hout->done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
