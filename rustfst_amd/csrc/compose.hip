@@ -1048,8 +1048,10 @@ __global__ void __launch_bounds__(512) string_compose_sp_kernel(const ProblemDes
 #define STR_RESULT() do {                                                                                  \
     res.done = 0u;                                                                                         \
     if (lane == 0) results[p] = res;                                                                       \
-    __threadfence_system(); /* (the stores' acknowledgements alone are not enough: measured) */               \
-    if (lane == 0) __hip_atomic_store(&results[p].done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    if (done_ticket != 0u) { /* (0: a large batch — the host waits for the stream, see launch_begin) */     \
+      __threadfence_system(); /* (the stores' acknowledgements alone are not enough: measured) */             \
+      if (lane == 0) __hip_atomic_store(&results[p].done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    }                                                                                                      \
   } while (0)
   const FstView f1 = descs[p].f1;
   Result res;
@@ -1412,10 +1414,14 @@ void launch_begin(wfst_ctx* ctx, const std::vector<ProblemDesc>& descs, const Fs
       maxs = need <= 512 ? 512u : (need <= 1024 ? 1024u : STR_MAXS);
       wpb = (64u << 10) / (16u * maxs);
     }
+    // tickets for serving-size batches only: the fence in front of a ticket writes the L2 back, and thousands of waves doing
+    // that made a 4096-problem batch 0.7 ms slower; a kernel of milliseconds does not care about 10 us of wake-up latency
     static std::atomic<uint32_t> tickets{0};
-    do run.done_ticket = tickets.fetch_add(1, std::memory_order_relaxed) + 1u; while (run.done_ticket == 0u);
-    if (run.zero_copy)
+    run.done_ticket = 0;
+    if (run.zero_copy && n <= 1024 && !ctx->profiling && !std::getenv("WFST_BATCH_STREAM_WAIT")) {
+      do run.done_ticket = tickets.fetch_add(1, std::memory_order_relaxed) + 1u; while (run.done_ticket == 0u);
       for (size_t i = 0; i < n; ++i) run.h_res[i].done = 0u;
+    }
     string_compose_sp_kernel<<<(uint32_t)((n + wpb - 1) / wpb), 64 * wpb, (size_t)wpb * 16u * maxs, st>>>(
         k_desc, f2, k_res, k_paths, path_cap, run.d_cursor.p, (uint32_t)n, maxs, f2.n_arcs,
         // scalar arc-block loads where a wave is alone on its SIMD (a handful of strings): -7 % per level; with eight waves
@@ -1444,7 +1450,7 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
   // The string kernel's results in pinned memory carry a ticket each: the host reads them as they land — a stream wait first
   // retires whatever else has finished on the stream and wakes up ~10 us after the kernel — and falls back to the stream.
   bool seen = false;
-  if (run.string_kernel && run.zero_copy && !ctx->profiling && !std::getenv("WFST_BATCH_STREAM_WAIT")) {
+  if (run.string_kernel && run.done_ticket != 0u) {
     const auto t0 = std::chrono::steady_clock::now();
     size_t next = 0;
     for (uint32_t spins = 0;; ++spins) {
