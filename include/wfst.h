@@ -222,7 +222,9 @@ wfst_status wfst_shortest_path_end(wfst_sp_job* job, wfst_fst** out);
 /* asynchronous form of the fused batch: _begin enqueues the whole pipeline on ctx's stream and returns at once
  * (so that the caller can issue other work, e.g. wfst_shortest_path on ANOTHER context, which then overlaps on
  * the GPU); _end waits, fills outs[0..n) / composed_arcs exactly like the synchronous call and frees the job
- * (also on error).  One job in flight per context; acceptors and t must stay alive until _end. */
+ * (also on error).  One job in flight per context; acceptors and t must stay alive until _end.
+ * The outs[] of a batch of up to a few thousand strings are views into the batch's pinned result block: complete FST
+ * handles whose arrays are built on first access (download, an algorithm, a writer); see INTEGRATION.md. */
 typedef struct wfst_batch_job wfst_batch_job;
 wfst_status wfst_compose_shortest_path_batch_begin(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
                                                    const wfst_fst* t, const wfst_compose_config* ccfg,
