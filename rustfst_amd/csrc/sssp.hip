@@ -661,18 +661,6 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   __shared__ uint2 s_walk[WALK_LDS];
   __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
-  if (adv_count && blockIdx.x == 0 && threadIdx.x < 64) {
-    // closes the sweep batch queued in front of this launch (what sssp_advance_kernel does: the flags of its sweeps go to
-    // pinned host memory, the slots half a ring ahead are recycled, the base moves on) — one launch and one flush of
-    // host-memory writes less at the end of a predicted solve
-    const uint32_t base = ctl->base;
-    for (uint32_t i = threadIdx.x; i < adv_count; i += 64) {
-      host_ring[(base + i) % IMP_RING] = improved_ring[(base + i) % IMP_RING];
-      improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
-    }
-    if (threadIdx.x == 0) ctl->base = base + adv_count;  // (every lane of the wave has read the old value above)
-    host_stores_done();  // the mirrored flags are in host memory before this workgroup takes its ticket below
-  }
   unsigned long long best = KEY_INF;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const float f = finals[s];
@@ -698,6 +686,18 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   }
   __syncthreads();
   if (!s_last || threadIdx.x >= 64) return;
+  if (adv_count) {
+    // closes the sweep batch queued in front of this launch (what sssp_advance_kernel does: the flags of its sweeps go to
+    // pinned host memory, the slots half a ring ahead are recycled, the base moves on) — one launch and one flush of
+    // host-memory writes less at the end of a predicted solve.  By the wave that writes the ticket at the end: ONE
+    // system-scope fence orders all of it.
+    const uint32_t base = ctl->base;
+    for (uint32_t i = lane; i < adv_count; i += 64) {
+      host_ring[(base + i) % IMP_RING] = improved_ring[(base + i) % IMP_RING];
+      improved_ring[(base + IMP_RING / 2 + i) % IMP_RING] = 0;
+    }
+    if (lane == 0) ctl->base = base + adv_count;  // (every lane of the wave has read the old value above)
+  }
   // the last workgroup's first wave: every other workgroup's result is in memory
   best = KEY_INF;
   for (uint32_t b = lane; b < gridDim.x; b += 64) {
