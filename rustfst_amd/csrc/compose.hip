@@ -1461,7 +1461,7 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
         break;
       }
       __builtin_ia32_pause();
-      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;  // (a long batch: sleep on the stream)
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // (a long batch: sleep on the stream)
     }
   }
   if (!seen) HIP_CHECK(hipStreamSynchronize(st));

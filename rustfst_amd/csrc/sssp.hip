@@ -1366,7 +1366,7 @@ struct SweepDriver {
           return;
         }
         __builtin_ia32_pause();
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;  // (a long solve: sleep on the event)
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // (a long solve: sleep on the event)
       }
     }
     HIP_CHECK(hipEventSynchronize(evs[0]));
