@@ -1557,6 +1557,32 @@ def test_batch_results_as_views_into_the_result_block(gpu_ctx, monkeypatch):
     np.testing.assert_array_equal(dist.pack_device_paths(again, 64), want_rec)
 
 
+@pytest.mark.parametrize("waits", ["tickets", "hip"])
+def test_completion_by_ticket_and_by_hip_wait_agree(gpu_ctx, oracle, monkeypatch, waits):
+    """_end calls learn that their kernels are done from tickets the kernels store into pinned memory (behind a system-scope
+    fence), and fall back to the HIP event / stream wait (long kernels, WFST_SSSP_EVENT_WAIT / WFST_BATCH_STREAM_WAIT): both
+    ways, repeated asynchronous shortest_path queries overlapped with fused batches give the oracle's results every time."""
+    if waits == "hip":
+        monkeypatch.setenv("WFST_SSSP_EVENT_WAIT", "1")
+        monkeypatch.setenv("WFST_BATCH_STREAM_WAIT", "1")
+    t = synth.make_transducer(120_000, 8, 64, 0.0, seed=5)
+    accs = synth.make_acceptors(t, 48, 60, seed0=77)
+    ot = to_oracle(oracle, t)
+    ref_sp = ot.shortest_path_canonical().to_flat()
+    refs = [to_oracle(oracle, a).compose(ot).shortest_path_canonical().to_flat() for a in accs[:6]]
+    ctx2 = rustfst_amd.Context(0)
+    dt, dt2 = to_device(t), rustfst_amd.DeviceFst.from_arrays(t["n_states"], t["start"], t["offsets"], t["arcs"], t["finals"], t["props"], ctx2)
+    dacc = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(accs, ctx2))
+    for it in range(12):
+        sp_job = dt.shortest_path_begin()
+        job = rustfst_amd.compose_shortest_path_batch_begin(dacc, dt2, ctx=ctx2)
+        outs, _ = job.finish()
+        sp = sp_job.finish()
+        assert_flat_identical(sp.to_flat(), ref_sp, f"{waits}: query {it}")
+        for k in range(6):
+            assert_flat_identical(outs[k].to_flat(), refs[k], f"{waits}: step {it} result {k}")
+
+
 def test_string_kernel_falls_back_where_it_does_not_apply(gpu_ctx, oracle):
     """Levels wider than one wave, input epsilons in T, epsilons or branching in fst1, explicit non-sequence filters: the
     batch silently takes the general kernel (per problem) and still matches the oracle."""
