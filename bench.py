@@ -430,16 +430,16 @@ def main():
     comm = wdist.Comm.from_torch_group(ctx, device) if (world > 1 or force_dist) else None
 
     def exchange(outs=None):
-        # RCCL all-gather of this step's batch results: packed and queued as soon as the batch is collected, WHILE the
-        # relaxation sweeps of the same step are still running (the host would only wait for them), on the communicator's
-        # own stream, and collected one step later; the last one is drained before the closing barrier, inside the
-        # timed region.
+        # RCCL all-gather of a step's batch results on the communicator's own stream.  The host side of it (collecting the
+        # previous exchange, packing 64 paths, the events, the RCCL launch: ~90 us) sits where the host only waits: a
+        # step's results are handed over right after the NEXT step's two requests are enqueued, and collected one step
+        # after that; the last ones are drained before the closing barrier, inside the timed region.
         if last.get("pending"):
             last["gathered"] = comm.gather_paths_end()
             last["pending"] = False
         if outs is not None:
-            # behind this step's relaxation (already queued on ctx's stream): its sweeps need every compute unit, the
-            # all-gather kernel runs beside the one-workgroup head of the NEXT solve instead
+            # behind the relaxation that is queued on ctx's stream right now: its resident launch needs (nearly) every
+            # compute unit, the all-gather kernel runs beside the one-workgroup head of the solve after it instead
             comm.order_after(ctx)
             comm.gather_paths_begin(outs, args.acc_len + 8)
             last["pending"] = True
@@ -465,10 +465,13 @@ def main():
                 p1 = time.perf_counter()
                 job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
             p2 = time.perf_counter()
+            if (world > 1 or force_dist) and last.get("to_send") is not None:
+                exchange(last["to_send"])  # the previous step's results (both requests of this step are running)
+                last["to_send"] = None
             outs, n_arcs = job.finish()
             p3 = time.perf_counter()
             if world > 1 or force_dist:
-                exchange(outs)
+                last["to_send"] = outs
             sp = sp_job.finish()
             p4 = time.perf_counter()
             phases[:] = [phases[0] + p1 - p0, phases[1] + p2 - p1, phases[2] + p3 - p2, phases[3] + p4 - p3, phases[4] + 1]
@@ -480,7 +483,10 @@ def main():
 
     def drain():
         if world > 1 or force_dist:
-            exchange()  # collects the last step's results
+            if last.get("to_send") is not None:
+                exchange(last["to_send"])  # the last step's results
+                last["to_send"] = None
+            exchange()  # ... collected
 
     def barrier():
         torch.cuda.synchronize(device)
