@@ -1555,6 +1555,17 @@ def test_batch_results_as_views_into_the_result_block(gpu_ctx, monkeypatch):
     del later, fresh, views  # (results nobody read: released with their blocks)
     again, _ = rustfst_amd.compose_shortest_path_batch(dacc, dt)
     np.testing.assert_array_equal(dist.pack_device_paths(again, 64), want_rec)
+    # in-place operations and further algorithms on views: what they do to the eagerly built FST
+    ops = [lambda f: f.tr_sort(False), lambda f: f.project(), lambda f: f.reverse(), lambda f: f.rm_epsilon(), lambda f: f.connect(),
+           lambda f: f.compose(dt) if False else f.shortest_path()]
+    for j, op in enumerate(ops):
+        a, b = op(again[k + j] if k + j < 40 else again[k]), op(eager[k + j] if k + j < 40 else eager[k])
+        assert_flat_identical(a.to_flat(), b.to_flat(), f"operation {j} on a view")
+    # more batches with live results than the ring keeps free blocks: every batch still has a block of its own
+    held = [rustfst_amd.compose_shortest_path_batch(dacc, dt)[0] for _ in range(12)]
+    for h in held:
+        np.testing.assert_array_equal(dist.pack_device_paths(h, 64), want_rec)
+    del held
 
 
 @pytest.mark.parametrize("waits", ["tickets", "hip"])
