@@ -205,12 +205,16 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
   const uint32_t bmind = mb.blk_mind[j], bfar = mb.blk_far[j];
   const bool wrote_out = mb.wrote[par_in ^ 1u][j] != 0u;
   const uint32_t wl_n = min(mb.wl_cnt[j], NW_SEG);
+  // (launch 0 of a solve with NARROW launches is the head of the search: it never looks at the block's keys or offsets — this
+  // kernel runs it for FSTs of 8192-state blocks, and 96 KB per workgroup is a trip and 23 MB nobody needs)
+  const bool narrow0 = sweep == 0u && narrow_t != 0u;
   unsigned long long kreg[R];
   uint32_t oreg[R], o_last = 0;
   for (uint32_t r = 0; r < R; ++r) {
     const uint32_t s = s0 + tid + MB_THREADS * r;
     kreg[r] = KEY_INF;
     oreg[r] = 0;
+    if (narrow0) continue;
     if (s < n) {
       kreg[r] = key[s];
       oreg[r] = offsets[s];
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       oreg[r] = offsets[n];
     }
   }
-  if (tid == MB_THREADS - 1 && s0 + MB_B <= n) {
+  if (tid == MB_THREADS - 1 && s0 + MB_B <= n && !narrow0) {
     uint32_t t = tid;
     asm volatile("" : "+v"(t));
     o_last = offsets[s0 + t + MB_THREADS * (R - 1) + 1];
