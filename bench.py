@@ -243,7 +243,7 @@ def roofline_vs_size(ctx, sizes, fanout, sigma):
     import numpy as np
     import rustfst_amd
     from rustfst_amd import synth
-    names = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel")
+    names = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel", "sssp_relax_kernel + sssp_bin_expand/apply_kernel (per level)")
     rows = []
     for n in sizes:
         c0 = time.perf_counter()
@@ -505,6 +505,17 @@ def main():
         for _ in range(PRIMING_STEPS):
             step()
         drain()
+        gather_check = None
+        if world > 1 or force_dist:
+            # (untimed) what the exchange delivered for the last priming step must be a ONE-rank run of the whole global batch:
+            # every rank composes all n_total acceptors on its own GPU once and compares, record for record, in global order
+            whole, _ = rustfst_amd.compose_shortest_path_batch(rustfst_amd.DeviceFst.upload_many(accs_all, ctx2), dt2, ctx=ctx2)
+            whole_packed = wdist.pack_device_paths(whole, args.acc_len + 8)
+            got = wdist.interleave(last["gathered"], n_total)
+            assert got.shape == whole_packed.shape and np.array_equal(got, whole_packed), \
+                "the gathered records differ from a single-rank run of the same global batch"
+            gather_check = {"records": int(n_total), "equal_to_single_rank_run": True}
+            del whole, whole_packed, got
         barrier()
         gen_s += time.time() - t1
         for _ in range(args.warmup):
@@ -553,7 +564,7 @@ def main():
         ms_sp_t = alone(lambda: dt.shortest_path())
         ms_batch = alone(lambda: rustfst_amd.compose_shortest_path_batch(daccs, dt2, ctx=ctx2))
         sweeps = ctx.stats()["sweeps"]
-        relax_kernel = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel")[int(ctx.stats()["relax_kernel"])]
+        relax_kernel = ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel", "sssp_relax_kernel + sssp_bin_expand/apply_kernel")[int(ctx.stats()["relax_kernel"])]
 
         # ------------------------------------------------------------------ configs[1]: ONE 1000-arc string against a
         # 100k-state T (the case a lone dependent chain makes the GPU lose to one CPU core; reported, not timed above)
@@ -796,7 +807,8 @@ def main():
                                   "p50": round(float(np.percentile(ms, 50)), 4), "p99": round(float(np.percentile(ms, 99)), 4),
                                   "timed_seconds": round(elapsed, 3), "clock": "host perf_counter per step on rank 0"},
             "step_host_phases_us": step_phases_us,
-            "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist), "batch_only": batch_only,
+            "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist), "gather_check": gather_check,
+            "batch_only": batch_only,
             "s1_start_states": "T's own" if world == 1 else f"rank r: ({int(t['start'])} + 104729 r) mod {int(t['n_states'])}",
             "step_schedule": "serial (one stream)" if (not args.overlap) else ("S1 (shortest_path(T)) enqueued async on stream 1, then the S2 batch on stream 2" if args.order == "s1-first" else "S2 batch enqueued async on stream 2, then S1 on stream 1") + ", S2 collected, S1 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),

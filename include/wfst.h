@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 4 /* 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
+#define WFST_ABI_VERSION 5 /* 5: wfst_ctx_get_sweep_modes, relax_kernel may be 3, wfst_stats gained tied_choices;
+                             * 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
                              * 4: wfst_stats gained resident_aborts, relax_kernel may be 2; wfst_comm_create_host, wfst_gather_records_begin */
 
 typedef enum { WFST_OK = 0, WFST_KO = 1 } wfst_status; /* RUSTFST_FFI_RESULT, rustfst-ffi/src/lib.rs:29-37 */
@@ -351,8 +352,12 @@ wfst_status wfst_comm_allgatherv(wfst_comm* comm, const void* send, size_t bytes
  * order of its depth-first visit (queues/auto_queue.rs:23-99 -> TopOrderQueue, top_sort.rs:12-61, dfs_visit.rs:97-187) and
  * keeps the FIRST arc, in (order of the source, arc position), that attains the final distance (shortest_path.rs:214-232),
  * and the first final state in that order.  The visit runs on the host (it is sequential by definition), distances and
- * the predecessor pass on the GPU.  Cyclic inputs keep the canonical rule under either setting (the reference's FIFO order
- * inside a cycle is a schedule, not a rule). */
+ * the predecessor pass on the GPU.  On CYCLIC inputs (and inputs rustfst relaxes LIFO) its choice among tied optima is a
+ * function of its whole relaxation history, which no rule reproduces: there, tie order 1 returns the path only when the
+ * optimum is UNIQUE (wfst_stats.tied_choices == 0: no state of the path has a second optimal predecessor, one final state
+ * attains the optimum) — then it is provably rustfst's path — and is KO ("ambiguous optimum") otherwise, so that a caller
+ * that needs rustfst's structure falls back to rustfst (the convention for unsupported cases).  Tie order 0 never fails
+ * and reports the same count in wfst_stats.tied_choices. */
 wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order);
 
 /* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
@@ -373,12 +378,21 @@ typedef struct {
                                epsilon-free acceptor, fst2 without input epsilons) */
   uint64_t relax_kernel;    /* kernel of the last relaxation: 0 sssp_relax_kernel (atomic sweeps), 1 sssp_mbox_kernel
                                (owner-computes mailbox launches: WIDE / COLLECT / NARROW, one level per launch), 2 the
-                               same with the WIDE levels inside one sssp_mbox_resident_kernel launch */
+                               same with the WIDE levels inside one sssp_mbox_resident_kernel launch, 3 atomic sweeps with
+                               their dense levels as binned owner-computes passes (sssp_bin_expand / _apply_kernel) */
   uint64_t nbest_device_problems; /* inputs of the last wfst_shortest_path_batch (nshortest > 1) searched by the wave kernel
                                      (the others went through the host search) */
   uint64_t resident_aborts; /* resident relaxation launches that gave up waiting for their own workgroups (the solve was
-                               then repeated with one launch per level, and the context stays in that mode), cumulative */
+                               then repeated with one launch per level; the context tries resident launches again after a
+                               pause that doubles with every abort in a row), cumulative */
+  uint64_t tied_choices;    /* last wfst_shortest_path (nshortest = 1): states of the returned path that had more than one optimal
+                               predecessor, + 1 when several final states attain the optimum.  0 = the optimum is UNIQUE: the
+                               path is what rustfst returns whatever its queue discipline.  > 0 = rustfst may return another path
+                               of the same weight.  WFST_TIES_UNKNOWN when the call did not count (first query of an FST, FSTs
+                               of < 2^18 arcs in the default tie order, tiny inputs, paths beyond 4096 arcs, acyclic inputs
+                               under tie order 1 — exact there anyway) */
 } wfst_stats;
+#define WFST_TIES_UNKNOWN (~(uint64_t)0)
 /* on = 1: every relaxation launch is bracketed by HIP events and followed by a synchronisation (per-launch trace below;
  * never on in timed runs).  on = 2: no per-launch events; the sweeps of a repeated shortest_path query (one pre-queued
  * batch) are timed as ONE chain between two events on the stream: relax_ms = that time, relax_launches = its sweeps
@@ -389,6 +403,9 @@ wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx);
 /* per-launch trace of the last profiled relaxation (profiling on): launch k relaxed arcs[k] arcs leaving
  * states[k] frontier states in ms[k] milliseconds.  Copies min(cap, *n) entries; arrays may be NULL to query *n. */
 wfst_status wfst_ctx_get_sweep_trace(wfst_ctx* ctx, double* ms, uint64_t* arcs, uint64_t* states, size_t cap, size_t* n);
+/* ... and what ran launch k: 0 the atomic sweep, 7 a binned level (the same level as an owner-computes pass: expand +
+ * apply kernels, chosen per level on the device), or the mailbox launches' mode (0 WIDE, 1 COLLECT, 2 NARROW). */
+wfst_status wfst_ctx_get_sweep_modes(wfst_ctx* ctx, uint32_t* modes, size_t cap, size_t* n);
 
 #ifdef __cplusplus
 }

@@ -23,12 +23,15 @@ class ShortestPathConfig(C.Structure):
     _fields_ = [("delta", C.c_float), ("nshortest", C.c_uint64), ("unique", C.c_uint32)]
 
 
+TIES_UNKNOWN = (1 << 64) - 1  # WFST_TIES_UNKNOWN
+
+
 class Stats(C.Structure):
     _fields_ = [("relax_launches", C.c_uint64), ("relax_ms", C.c_double), ("relax_arcs", C.c_uint64),
                 ("relax_states", C.c_uint64), ("sweeps", C.c_uint64), ("compose_states", C.c_uint64),
                 ("compose_arcs", C.c_uint64), ("compose_retries", C.c_uint64), ("compose_ms", C.c_double),
                 ("string_problems", C.c_uint64), ("relax_kernel", C.c_uint64), ("nbest_device_problems", C.c_uint64),
-                ("resident_aborts", C.c_uint64)]
+                ("resident_aborts", C.c_uint64), ("tied_choices", C.c_uint64)]
 
 
 # every symbol include/wfst.h declares: (name, restype, argtypes)
@@ -118,6 +121,7 @@ SYMBOLS = [
     ("wfst_ctx_get_stats", C.c_int, [_vp, _P(Stats)]),
     ("wfst_ctx_reset_stats", C.c_int, [_vp]),
     ("wfst_ctx_get_sweep_trace", C.c_int, [_vp, _vp, _vp, _vp, _sz, _P(_sz)]),
+    ("wfst_ctx_get_sweep_modes", C.c_int, [_vp, _vp, _sz, _P(_sz)]),
 ]
 
 _lib = None

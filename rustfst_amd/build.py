@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwfst_amd.so")
 SOURCES = ["api.cpp", "vector_fst.cpp", "fst_store.hip", "openfst_io.cpp", "sssp.hip", "nshortest.hip", "nbest_batch.hip", "tr_sort.hip", "compose.hip", "lookahead.cpp", "compose_lookahead.hip", "compose_wide.hip", "rm_epsilon.hip", "gather.cpp"]
-HEADERS = ["common.h", "sssp_mailbox.h", "sssp_resident.h", "fst_props.h", "lookahead.h", "compose_wide.h", "compose_filters.h", "host_parallel.h", os.path.join("..", "..", "include", "wfst.h")]
+HEADERS = ["common.h", "sssp_mailbox.h", "sssp_resident.h", "sssp_binned.h", "fst_props.h", "lookahead.h", "compose_wide.h", "compose_filters.h", "host_parallel.h", os.path.join("..", "..", "include", "wfst.h")]
 ARCH = "gfx950"
 
 

@@ -676,6 +676,14 @@ wfst_status wfst_ctx_get_sweep_trace(wfst_ctx* ctx, double* ms, uint64_t* arcs, 
     }
   });
 }
+wfst_status wfst_ctx_get_sweep_modes(wfst_ctx* ctx, uint32_t* modes, size_t cap, size_t* n) {
+  return wrap([&] {
+    if (!ctx || !n) throw Error("null pointer");
+    *n = ctx->sweep_trace.size();
+    for (size_t i = 0; i < std::min(cap, *n); ++i)
+      if (modes) modes[i] = ctx->sweep_trace[i].mode;
+  });
+}
 wfst_status wfst_ctx_reset_stats(wfst_ctx* ctx) {
   return wrap([&] {
     if (!ctx) throw Error("null ctx");

@@ -19,6 +19,17 @@ namespace wfst {
 
 constexpr float INF = __builtin_huge_valf();
 
+// one turn of a host spin loop on a word in pinned memory (the completion tickets)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
 // ---------------------------------------------------------------- errors
 struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -131,7 +142,15 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
   bool tie_reference = false;  // wfst_ctx_set_tie_order: the reference's predecessor choice on acyclic inputs
-  bool resident_off = false;   // a resident relaxation launch gave up waiting on this context: one launch per level from now on
+  // A resident relaxation launch of this context gave up waiting (its grid was not resident as a whole: another tenant held
+  // compute units): solves take one launch per level until `resident_retry_at`, then a resident launch is tried again;
+  // the pause doubles with every abort in a row (50 ms .. 3.2 s) and is forgotten by the first resident solve that completes.
+  int64_t resident_retry_at_ns = 0;  // steady clock; 0 = resident launches allowed
+  bool resident_hold = false;        // the repeat of a solve whose resident launch gave up: never a resident one
+  uint32_t resident_abort_streak = 0;
+  bool resident_allowed() const;
+  void resident_aborted();
+  void resident_completed() { resident_abort_streak = 0; }
   // wfst_ctx_set_profiling(ctx, 2): no per-launch events; the sweeps of a repeated (predicted) shortest_path query are timed
   // as ONE chain between two events on the stream, without any synchronisation between launches
   bool chain_timing = false;
@@ -142,6 +161,7 @@ struct wfst_ctx {
   struct SweepSample {
     double ms;
     uint64_t arcs, states;
+    uint32_t mode = 0;  // what ran the level (Ctl::mode of its slot): mailbox MODE_*, or 0 atomic sweep / 7 binned level
   };
   std::vector<SweepSample> sweep_trace;  // profiling only: one entry per relaxation launch of the last solve
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -206,6 +226,14 @@ struct MboxPlan {
   DBuf<uint32_t> roffh_t;  // [nb*nb]     source-major copy
   uint64_t res_units = 0;  // units of one parity buffer
 };
+// Region plan of the binned levels of the atomic sweeps (sssp_binned.h): source states in G contiguous ranges of `sg`
+// states, destination states in `nbin` bins of 1 << logd; region (g -> b) holds one slot per arc from range g to bin b.
+struct BinPlan {
+  uint32_t nbin = 0, G = 0, sg = 0, logd = 13;
+  uint64_t slots = 0;     // message slots in all (regions rounded up to whole 128-byte lines)
+  DBuf<uint32_t> roff;    // [nbin*G + 1] destination-major
+  DBuf<uint32_t> roff_t;  // [G*nbin]     source-major copy
+};
 }  // namespace wfst
 
 namespace wfst {
@@ -253,6 +281,7 @@ struct wfst_fst {
   // region plan of the mailbox relaxation sweeps; depends on (source, target) pairs only, built on first use
   mutable std::shared_ptr<wfst::MboxPlan> mbox;
   mutable std::shared_ptr<wfst::MboxPlan> mbox13;  // the same with blocks of 8192 states (resident launches of 1M .. 2M-state FSTs)
+  mutable std::shared_ptr<wfst::BinPlan> binplan;  // region plan of the binned levels (FSTs beyond the mailbox range)
   // a linear, epsilon-free, single-final acceptor ("string": utils::acceptor, labels_to_fst.rs:111-132), detected at
   // upload from the host arrays; such an fst1 takes the specialised string o T kernel of the fused batch
   bool is_string = false;

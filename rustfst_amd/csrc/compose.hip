@@ -1460,11 +1460,12 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
         seen = true;
         break;
       }
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // (a long batch: sleep on the stream)
     }
   }
   if (!seen) HIP_CHECK(hipStreamSynchronize(st));
+  else HIP_CHECK(hipGetLastError());  // (no stream wait on this path: a fault of the chain is still reported here)
   if (ctx->profiling) {
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

@@ -581,8 +581,18 @@ wfst_fst* compose_lookahead_wide(wfst_ctx* ctx, const wfst_lookahead* la, const 
   const LaPolicy pol{view_of(f1), view_of(fst2), Reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label}};
   WideOutput w;
   const double d1 = (double)f1->n_arcs / std::max<uint32_t>(f1->n_states, 1), d2 = (double)fst2->n_arcs / std::max<uint32_t>(fst2->n_states, 1);
+  // (a serving loop composes many inputs of one kind against the operand: the last result sizes the arena, + 1/8)
+  if (!std::getenv("WFST_WIDE_EST_STATES")) {
+    const uint64_t ls = la->last_wide_states.load(std::memory_order_relaxed), lw = la->last_wide_arcs.load(std::memory_order_relaxed);
+    if (ls + ls / 8 + 1024 < 0x7FFFFFF0ull && lw + lw / 4 + 65536 < 0x7FFFFFF0ull) {
+      est_s = std::max<uint64_t>(est_s, ls + ls / 8 + 1024);
+      est_a = std::max<uint64_t>(est_a, lw + lw / 4 + 65536);  // (the arc arena is cut into 64 slices: room for their skew)
+    }
+  }
   run_wide(ctx, pol, ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)fst2->start, pack_hi(FState{0u, 0.0f, NO_LABEL}), est_s,
            est_a, 1.0 + std::min(d1, d2), w);
+  la->last_wide_states.store(w.n_states, std::memory_order_relaxed);
+  la->last_wide_arcs.store(w.n_arcs, std::memory_order_relaxed);
   ctx->stats.compose_states = w.n_states;
   ctx->stats.compose_arcs = w.n_arcs;
   return adopt_device(ctx, w.n_states, w.n_arcs, 0, out_props, w.off, w.arcs, w.fin);

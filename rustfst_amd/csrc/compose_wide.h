@@ -248,16 +248,24 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
       }
       seg_total += group_sum<G>(cnt);
     }
-    uint32_t seg = 0;
-    const uint32_t shard = (wave * SPW + grp) % CUR_SHARDS;
+    // one reservation per WAVE (its 64 / G states): the cursors are 64 words, and same-address atomics serialise at ~12 ns —
+    // one per composed state was 90 M of them in a 90 M-state run (profiles/r05c_wide_lookahead.md)
+    uint32_t wave_total = 0, before = 0;
+#pragma unroll
+    for (uint32_t g2 = 0; g2 < SPW; ++g2) {
+      const uint32_t v = (uint32_t)__shfl((int)(valid ? seg_total : 0u), (int)(g2 * G));
+      before += g2 < grp ? v : 0u;
+      wave_total += v;
+    }
+    const uint32_t shard = wave % CUR_SHARDS;
+    uint32_t wbase = 0;
+    if (lane == 0 && wave_total) wbase = atomicAdd(&ctl->cursor[shard * CUR_STRIDE], wave_total);
+    wbase = (uint32_t)__shfl((int)wbase, 0);
+    const uint32_t seg = wbase + before;
+    const bool fits = (uint64_t)wbase + wave_total <= (uint64_t)ctl->limit[shard];
     if (sub == 0 && valid) {
-      seg = seg_total ? atomicAdd(&ctl->cursor[shard * CUR_STRIDE], seg_total) : 0u;
       ar.seg_base[q] = seg;
       ar.fin[q] = x.final_weight;
-    }
-    seg = __shfl(seg, 0, G);
-    const bool fits = (uint64_t)seg + seg_total <= (uint64_t)ctl->limit[shard];
-    if (sub == 0 && valid) {
       ar.seg_cnt[q] = fits ? seg_total : 0u;
       if (!fits) atomicMax(&ctl->status, (uint32_t)LA_OVERFLOW_ARCS);
     }
@@ -547,7 +555,8 @@ void run_wide_g(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_
     // whoever calls the wide driver has already seen the result outgrow one wave: room for a quarter of a million states
     // to begin with (clearing that table takes ~20 us)
     est_s = std::max<uint64_t>(est_s, 1ull << 18);
-    est_a = std::max<uint64_t>(est_a, 4 * est_s);
+    // (four arcs per state while nothing is known; a caller that starts from a measured size gives both figures)
+    est_a = std::max<uint64_t>(est_a, est_s <= (1ull << 22) ? 4 * est_s : est_s);
   }
   WideBuffers w;
   wide_alloc(ctx, est_s, est_a, w);

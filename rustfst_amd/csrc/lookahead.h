@@ -1,6 +1,7 @@
 // Look-ahead composition: shared declarations of lookahead.cpp (host precompute) and
 // compose_lookahead.hip (the kernel and the C-ABI entry points' implementation).
 #pragma once
+#include <atomic>
 #include <memory>
 #include <unordered_map>
 #include <vector>
@@ -46,6 +47,9 @@ struct wfst_lookahead {
   wfst::LabelReachData data;
   wfst_fst* fst1 = nullptr;  // relabelled, olabel-sorted copy of the first operand (owned)
   std::unique_ptr<wfst::DBuf<uint32_t>> d_iv_off, d_iv;
+  // what the last composition on the wide driver came to (states, arcs before the gather): the next one against this
+  // operand starts with an arena of that size instead of growing into it (eight growths, a quarter of a 90 M-state run)
+  mutable std::atomic<uint64_t> last_wide_states{0}, last_wide_arcs{0};
   ~wfst_lookahead();
 };
 

@@ -17,6 +17,10 @@
 #include <chrono>
 #include <cstring>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
@@ -73,6 +77,10 @@ struct Ctl {
   uint32_t tau[RING];     // f32 bits of the threshold used by sweep k (written by sweep k, read by sweep k+1)
   // number of activations with d <= tau_k made by sweep k: counter sharded 16 ways, shard j at [j * NEAR_STRIDE]
   uint32_t near[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
+  // atomic sweeps / binned levels: states left in the frontier BEYOND the threshold by sweep k (re-flagged far states and
+  // far activations; an upper bound — a state may be counted twice), sharded like `near`.  With `near` it predicts the
+  // next level's frontier, which decides the kernel that relaxes it (sssp_binned.h)
+  uint32_t far[NEAR_RING][NEAR_SHARDS * NEAR_STRIDE];
   uint32_t streak[RING];  // consecutive sweeps before k that activated nothing near
   // mailbox sweeps: the mode launch k ran in (MODE_*), and the number of states waiting beyond the threshold (sharded like
   // `near`; a block adds the change of its own count, unsigned wrap-around)
@@ -100,38 +108,51 @@ struct TailOut {
   uint32_t done;  // the launch's ticket, written last (after a system-scope fence): the host waits for this word instead of
                   // a HIP event (an event / stream wait retires the stream's finished launches first: ~15 us when ten of them
                   // are waiting, on the critical path of every query)
-  uint32_t pad_;
+  uint32_t ties;  // states of the returned path with more than one optimal predecessor (the start state: with any), + 1 when
+                  // several final states attain the optimum: 0 = the optimum is unique (wfst_stats.tied_choices)
 };
 
 // threshold of sweep k from what sweep k-1 left in the ring (every thread computes the same value)
 // Called by one full wave (all 64 lanes): lanes 0..15 fetch the shards of sweep-1's counter, lanes 16..31 those of
 // sweep-2's, so the whole decision costs one load latency.
 __device__ __forceinline__ float sweep_tau(const Ctl* ctl, uint32_t sweep, float delta, uint32_t near_low,
-                                           uint32_t* streak, uint32_t* prev_near) {
+                                           uint32_t* streak, uint32_t* prev_near, uint32_t* frontier_est = nullptr) {
   *streak = 0;
   *prev_near = 0;
+  if (frontier_est) *frontier_est = 1u;
   if (sweep == 0) return ctl->tau0;
   const uint32_t p = (sweep - 1) % RING;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t mine = 0;
   if (lane < NEAR_SHARDS) mine = ctl->near[(sweep - 1) % NEAR_RING][lane * NEAR_STRIDE];
   else if (lane < 2 * NEAR_SHARDS && sweep >= 2) mine = ctl->near[(sweep - 2) % NEAR_RING][(lane - NEAR_SHARDS) * NEAR_STRIDE];
+  else if (lane >= 2 * NEAR_SHARDS && lane < 3 * NEAR_SHARDS && frontier_est) mine = ctl->far[(sweep - 1) % NEAR_RING][(lane - 2 * NEAR_SHARDS) * NEAR_STRIDE];
   const float prev = __uint_as_float(ctl->tau[p]);
   const uint32_t prev_streak = ctl->streak[p];
   for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);  // sums inside each group of 16 lanes
-  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16);
+  const uint32_t cnt = __shfl(mine, 0), before = __shfl(mine, 16), far = __shfl(mine, 32);
   *prev_near = cnt;
-  if (cnt >= near_low) return prev;
-  // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
-  // widen the band by delta and keep relaxing
-  if (cnt) return cnt < before ? prev + delta : prev;
-  const uint32_t st = min(prev_streak + 1u, 30u);
-  *streak = st;
-  return prev + delta * (float)(1u << (st - 1u));
+  float t = prev;
+  if (cnt >= near_low) {
+    t = prev;
+  } else if (cnt) {
+    // a near set that cannot fill the GPU AND is shrinking (the tail of a band, not its growing head):
+    // widen the band by delta and keep relaxing
+    t = cnt < before ? prev + delta : prev;
+  } else {
+    const uint32_t st = min(prev_streak + 1u, 30u);
+    *streak = st;
+    t = prev + delta * (float)(1u << (st - 1u));
+  }
+  // the states this sweep will find near: what the last one activated below the threshold, plus — when the threshold moves —
+  // at most everything that waits beyond it
+  if (frontier_est) *frontier_est = cnt + (t != prev ? far : 0u);
+  return t;
 }
 
 #include "sssp_mailbox.h"
 #include "sssp_resident.h"
+#include "sssp_binned.h"
 
 // Initial state of a solve in ONE launch (five memsets + an init kernel cost five more launch gaps): every key and shadow
 // +inf except the start state (d = 1-bar, 0 hops: shortest_path.rs:204), both flag buffers clear except the start state's
@@ -180,7 +201,10 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
                                                          uint32_t sweep_offset, float delta, uint32_t near_low,
                                                          uint32_t* __restrict__ shadow, uint32_t chase_cap,
-                                                         uint32_t chase_rounds, uint32_t chase_low, uint32_t profile) {
+                                                         uint32_t chase_rounds, uint32_t chase_low, uint32_t profile,
+                                                         uint32_t dense_low) {
+  // `dense_low` (binned levels, sssp_binned.h; 0xFFFFFFFF = never): this launch is the first of its slot — it predicts the
+  // level's frontier, publishes the mode, and leaves the level to the binned kernels behind it when the frontier is that large
   // the sweep index is (device-side batch base) + (static offset of this launch / graph node)
   const uint32_t sweep = ctl->base + sweep_offset;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
@@ -189,11 +213,14 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   __shared__ float s_tau;
   __shared__ unsigned long long s_prof[2];  // arcs, states relaxed by this workgroup (profiling)
   __shared__ uint32_t s_small;             // the previous sweep left fewer than chase_low near activations
+  __shared__ uint32_t s_far, s_dense;
   __shared__ uint2 s_chase[4][CHASE_MAX];  // {state, enc(d) it was listed with}
   const uint32_t slot = sweep % RING;
+  const bool bin_on = dense_low != 0xFFFFFFFFu;
   if (threadIdx.x < 64) {
-    uint32_t streak, prev_near;
-    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak, &prev_near);
+    uint32_t streak, prev_near, est = 0;
+    const float t0 = sweep_tau(ctl, sweep, delta, near_low, &streak, &prev_near, bin_on ? &est : nullptr);
+    const bool dense = bin_on && sweep > 0 && est >= dense_low;
     if (threadIdx.x == 0) {
       s_small = prev_near < chase_low ? 1u : 0u;
       s_prof[0] = 0;
@@ -201,22 +228,29 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
       s_tau = t0;
       s_any = 0;
       s_near = 0;
+      s_far = 0;
+      s_dense = dense ? 1u : 0u;
     }
     if (blockIdx.x == 0) {
       if (threadIdx.x == 0) {
         ctl->tau[slot] = __float_as_uint(t0);
         ctl->streak[slot] = streak;
+        if (bin_on) ctl->mode[slot] = dense ? BN_MODE_DENSE : 0u;
       }
-      if (threadIdx.x < NEAR_SHARDS) ctl->near[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;  // recycle
+      if (threadIdx.x < NEAR_SHARDS) {  // recycle
+        ctl->near[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;
+        if (bin_on) ctl->far[(sweep + 1) % NEAR_RING][threadIdx.x * NEAR_STRIDE] = 0;
+      }
     }
   }
   __syncthreads();
+  if (s_dense) return;  // a dense level: sssp_bin_expand_kernel / sssp_bin_apply_kernel, queued behind this launch, relax it
   const float tau = s_tau;
   // only sweeps that follow a small one chase (a big sweep is not bound by its launch, and relaxing a state the moment
   // it is first improved, before the rest of the sweep's candidates for it have arrived, costs re-relaxations)
   if (!s_small) chase_cap = 0;
   uint32_t own_states = 0;  // flagged near states this wave relaxed itself
-  uint32_t near_cnt = 0;
+  uint32_t near_cnt = 0, far_cnt = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t sub = lane % GROUP;         // lane inside its group
   const uint32_t grp = lane / GROUP;         // group inside the wave (0..3)
@@ -251,6 +285,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
       flags_next[t] = 1;
       any = true;
       near_cnt += near ? 1u : 0u;
+      far_cnt += near ? 0u : 1u;
     }
   };
 
@@ -329,6 +364,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
         flags_next[sc] = 1;
         any = true;
         act = false;
+        far_cnt += 1u;
       }
     }
     own_states += (uint32_t)__popcll(__ballot(act));
@@ -366,10 +402,13 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   // one conditional plain store + one sharded atomicAdd per workgroup (thousands of same-address atomics per
   // sweep would serialise at ~12 ns each)
   for (int d = 32; d >= 1; d >>= 1) near_cnt += __shfl_xor(near_cnt, d);
+  if (bin_on)
+    for (int d = 32; d >= 1; d >>= 1) far_cnt += __shfl_xor(far_cnt, d);
   const bool wave_any = __any(any);
   if (lane == 0) {
     if (wave_any) s_any = 1u;
     if (near_cnt) atomicAdd(&s_near, near_cnt);
+    if (bin_on && far_cnt) atomicAdd(&s_far, far_cnt);
   }
   if (profile) {
     for (int d = 32; d >= 1; d >>= 1) {
@@ -385,6 +424,7 @@ __global__ void __launch_bounds__(256) sssp_relax_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) {
     if (s_any && *improved == 0u) *improved = 1u;
     if (s_near) atomicAdd(&ctl->near[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_near);
+    if (s_far) atomicAdd(&ctl->far[sweep % NEAR_RING][(blockIdx.x % NEAR_SHARDS) * NEAR_STRIDE], s_far);
     if (profile && (s_prof[0] | s_prof[1])) {
       atomicAdd(&ctl->arcs[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[0]);
       atomicAdd(&ctl->states[(blockIdx.x % PROF_SHARDS) * PROF_STRIDE], s_prof[1]);
@@ -555,13 +595,26 @@ constexpr uint32_t WALK_LDS = 1024;
 __device__ __forceinline__ uint32_t sssp_walk_back(const uint32_t* __restrict__ offsets, const wfst_tr* __restrict__ arcs,
                                                    const uint64_t* __restrict__ key, const uint32_t* __restrict__ rev_off,
                                                    const uint4* __restrict__ rev_arc, uint32_t fp, wfst_tr* __restrict__ out,
-                                                   uint32_t out_cap, uint32_t& pad, uint2* s_walk /* LDS [WALK_LDS] */) {
+                                                   uint32_t out_cap, uint32_t& pad, uint2* s_walk /* LDS [WALK_LDS] */, uint32_t& ties) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t k = 0;
   uint64_t kt = key[fp];
   uint32_t rb = rev_off[fp], re = rev_off[fp + 1];
+  // `ties`: states on the walk with more than one in-arc that is tight in the DISTANCE (d[s] (x) w == d[t]: any of them
+  // continues an optimal path, whatever rule picks one) — the start state: with any (a zero-weight cycle through it)
   for (;;) {
-    if ((uint32_t)kt == 0u) break;  // the start state
+    if ((uint32_t)kt == 0u) {  // the start state
+      uint32_t tn = 0;
+      for (uint32_t j = rb + lane; j < re; j += 64) {
+        const uint4 ra = rev_arc[j];
+        const uint64_t ks = key[ra.x];
+        if (ks == KEY_INF) continue;
+        const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(ra.z)) + 0.0f;
+        if (c < INF && enc_f32(c) == (uint32_t)(kt >> 32)) tn += 1u;
+      }
+      if (__any(tn != 0u)) ties += 1u;
+      break;
+    }
     if (k >= out_cap) {
       pad |= 8u;
       break;
@@ -569,6 +622,7 @@ __device__ __forceinline__ uint32_t sssp_walk_back(const uint32_t* __restrict__ 
     unsigned long long bp = PARENT_NONE;
     uint64_t my_ks = 0;
     uint32_t my_rb = 0, my_re = 0;
+    uint32_t tn = 0;
     for (uint32_t j = rb + lane; j < re; j += 64) {
       const uint4 ra = rev_arc[j];
       const uint64_t ks = key[ra.x];
@@ -576,6 +630,7 @@ __device__ __forceinline__ uint32_t sssp_walk_back(const uint32_t* __restrict__ 
       if (ks == KEY_INF) continue;
       const float c = (dec_f32((uint32_t)(ks >> 32)) + __uint_as_float(ra.z)) + 0.0f;
       if (!(c < INF)) continue;
+      if (enc_f32(c) == (uint32_t)(kt >> 32)) tn += 1u;
       const uint64_t ck = ((uint64_t)enc_f32(c) << 32) | ((uint32_t)ks + 1u);
       const unsigned long long cls = parent_class(ck, ks, kt);
       if (cls != PARENT_NONE) {
@@ -596,6 +651,10 @@ __device__ __forceinline__ uint32_t sssp_walk_back(const uint32_t* __restrict__ 
     if (best == PARENT_NONE) {  // no admissible predecessor: reported, not followed
       pad |= 4u;
       break;
+    }
+    {
+      const unsigned long long tm = __ballot(tn != 0u);
+      if (__popcll(tm) > 1 || __any(tn > 1u)) ties += 1u;
     }
     const int wl = __ffsll((unsigned long long)__ballot(bp == best)) - 1;  // (source, position) is unique: one lane holds it
     kt = __shfl(my_ks, wl);
@@ -635,8 +694,8 @@ __global__ void __launch_bounds__(64) sssp_backtrace_rev_kernel(const uint32_t* 
     if (lane == 0) ctl->pad |= 8u;
     return;
   }
-  uint32_t pad = 0;
-  const uint32_t k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, ctl->f_parent, out, out_cap, pad, s_walk);
+  uint32_t pad = 0, ties = 0;
+  const uint32_t k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, ctl->f_parent, out, out_cap, pad, s_walk, ties);
   if (lane == 0) {
     if (pad) ctl->pad |= pad;
     else ctl->hops = k;  // the real length of the walk
@@ -661,7 +720,21 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   __shared__ uint2 s_walk[WALK_LDS];
   __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
+  // (enc(total) << 32 | final state) and whether ANOTHER final state attains the same total: merged pairwise; between
+  // workgroups the flag travels in bit 31 of the state word (state ids have 31 bits)
+  constexpr unsigned long long TIE_BIT = 1ull << 31;
+  auto merge = [](unsigned long long& best, bool& tie, unsigned long long o, bool o_tie) {
+    if (o == KEY_INF) return;
+    if ((o >> 32) == (best >> 32)) {
+      tie = true;
+      best = o < best ? o : best;
+    } else if (o < best) {
+      best = o;
+      tie = o_tie;
+    }
+  };
   unsigned long long best = KEY_INF;
+  bool tie = false;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const float f = finals[s];
     if (!(f < INF)) continue;  // most states are not final: their key is never fetched
@@ -669,18 +742,24 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
     if (k == KEY_INF) continue;
     const float tot = (dec_f32((uint32_t)(k >> 32)) + f) + 0.0f;  // d[s] (x) rho(s), shortest_path.rs:214-220
     if (!(tot < INF)) continue;
-    const unsigned long long c = ((unsigned long long)enc_f32(tot) << 32) | s;
-    best = c < best ? c : best;
+    merge(best, tie, ((unsigned long long)enc_f32(tot) << 32) | s, false);
   }
   for (int d = 32; d >= 1; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d);
-    best = o < best ? o : best;
+    const bool ot = __shfl_xor((int)tie, d) != 0;
+    merge(best, tie, o, ot);
   }
-  if (lane == 0) s_best[threadIdx.x >> 6] = best;
+  if (lane == 0) s_best[threadIdx.x >> 6] = best == KEY_INF ? best : (best | (tie ? TIE_BIT : 0ull));
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) best = s_best[w] < best ? s_best[w] : best;
-    __hip_atomic_store(&ctl->tail_best[blockIdx.x], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    best = KEY_INF;
+    tie = false;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+      const unsigned long long o = s_best[w];
+      merge(best, tie, o == KEY_INF ? o : (o & ~TIE_BIT), o != KEY_INF && (o & TIE_BIT) != 0ull);
+    }
+    __hip_atomic_store(&ctl->tail_best[blockIdx.x], best == KEY_INF ? best : (best | (tie ? TIE_BIT : 0ull)), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     s_last = atomicAdd(&ctl->tail_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   }
@@ -700,13 +779,15 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   }
   // the last workgroup's first wave: every other workgroup's result is in memory
   best = KEY_INF;
+  tie = false;
   for (uint32_t b = lane; b < gridDim.x; b += 64) {
     const unsigned long long o = __hip_atomic_load(&ctl->tail_best[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    best = o < best ? o : best;
+    merge(best, tie, o == KEY_INF ? o : (o & ~TIE_BIT), o != KEY_INF && (o & TIE_BIT) != 0ull);
   }
   for (int d = 32; d >= 1; d >>= 1) {
     const unsigned long long o = __shfl_xor(best, d);
-    best = o < best ? o : best;
+    const bool ot = __shfl_xor((int)tie, d) != 0;
+    merge(best, tie, o, ot);
   }
   uint32_t pad = ctl->pad;
   if (lane == 0) {
@@ -723,6 +804,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
       hout->f_parent = 0u;
       hout->final_weight = INF;
       hout->total = INF;
+      hout->ties = 0u;
       host_stores_done();
       __hip_atomic_store(&hout->done, done_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -730,9 +812,9 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
   }
   const uint32_t fp = (uint32_t)best;
   const float final_weight = finals[fp], total = dec_f32((uint32_t)(best >> 32));
-  uint32_t k = 0;
+  uint32_t k = 0, ties = tie ? 1u : 0u;
   if ((uint32_t)key[fp] > out_cap) pad |= 8u;  // the host falls back to the parent pass
-  else k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, fp, out, out_cap, pad, s_walk);
+  else k = sssp_walk_back(offsets, arcs, key, rev_off, rev_arc, fp, out, out_cap, pad, s_walk, ties);
   if (lane == 0) {
     ctl->has_path = 1;
     ctl->f_parent = fp;
@@ -746,6 +828,7 @@ __global__ void __launch_bounds__(1024) sssp_tail_kernel(const float* __restrict
     hout->f_parent = fp;
     hout->final_weight = final_weight;
     hout->total = total;
+    hout->ties = ties;
   }
   // (the walk's arcs were written by several lanes of this wave)
   host_stores_done();
@@ -839,26 +922,73 @@ __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __re
 }
 
 // One resident solve per device at a time: a grid that waits for its own workgroups must be resident as a whole, and two
-// such grids started together could each hold half of the CUs.  (Another process is not covered: the wait limit is.)
+// such grids started together could each hold half of the CUs.  Inside a process the lease is a flag per device; between
+// processes it is an advisory lock on a file per device (flock, non-blocking: whoever does not get it takes one launch
+// per level for that solve).  Neither covers a tenant that is not this library: the wait limit of the launch does.
 struct ResidentLease {
   std::atomic<int>* slot = nullptr;
+  int lock_fd = -1;
   ResidentLease() = default;
   ResidentLease(const ResidentLease&) = delete;
   ResidentLease& operator=(const ResidentLease&) = delete;
+  static int device_lock_fd(int device) {  // one descriptor per device and process, opened once (-1: no lock file, in-process lease only)
+    static std::atomic<int> fds[64];
+    static std::once_flag once[64];
+    const unsigned d = (unsigned)device & 63u;
+    std::call_once(once[d], [d] {
+      int fd = -1;
+      if (!std::getenv("WFST_SSSP_NO_LOCKFILE")) {
+        const char* dir = std::getenv("WFST_LOCK_DIR");
+        char path[512];
+        std::snprintf(path, sizeof(path), "%s/.wfst_amd_resident_gpu%u.lock", dir ? dir : "/tmp", d);
+        fd = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+      }
+      fds[d].store(fd);
+    });
+    return fds[d].load();
+  }
   bool acquire(int device) {
     static std::atomic<int> busy[64];
     std::atomic<int>* s = &busy[(unsigned)device & 63u];
     int expect = 0;
     if (!s->compare_exchange_strong(expect, 1)) return false;
+    const int fd = device_lock_fd(device);
+    if (fd >= 0 && ::flock(fd, LOCK_EX | LOCK_NB) != 0) {  // another process holds the device's resident slot
+      s->store(0);
+      return false;
+    }
+    lock_fd = fd;
     slot = s;
     return true;
   }
   void release() {
-    if (slot) slot->store(0);
+    if (slot) {
+      if (lock_fd >= 0) (void)::flock(lock_fd, LOCK_UN);
+      slot->store(0);
+    }
+    lock_fd = -1;
     slot = nullptr;
   }
   ~ResidentLease() { release(); }
 };
+
+}  // namespace
+}  // namespace wfst
+bool wfst_ctx::resident_allowed() const {
+  if (resident_hold) return false;
+  if (resident_retry_at_ns == 0) return true;
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() >= resident_retry_at_ns;
+}
+void wfst_ctx::resident_aborted() {
+  int64_t pause_ms = 50ll << std::min<uint32_t>(resident_abort_streak, 6u);
+  if (const char* e = std::getenv("WFST_SSSP_RES_RETRY_MS")) pause_ms = std::max<long long>(0ll, std::atoll(e));  // tests
+  resident_abort_streak += 1;
+  resident_retry_at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() +
+                         pause_ms * 1000000ll;
+  if (resident_retry_at_ns == 0) resident_retry_at_ns = 1;
+}
+namespace wfst {
+namespace {
 
 struct Solve {
   DBuf<uint64_t> key;
@@ -896,6 +1026,14 @@ struct Solve {
   ResView rv{};
   uint32_t res_max_levels = RS_LEVEL_CAP;
   ResidentLease lease;       // at most one resident solve per device at a time (two half-resident grids would wait for each other)
+  // binned levels (sssp_binned.h): the dense levels of the atomic sweeps as an owner-computes pass, chosen per level on the device
+  bool binned = false;
+  std::shared_ptr<BinPlan> bplan;
+  DBuf<uint2> bn_msgs;       // one slot per arc
+  DBuf<uint32_t> bn_cnt;     // [nbin * G]
+  BinView bv{};
+  uint32_t dense_low = 0xFFFFFFFFu;  // predicted frontier from which a level is a binned one
+  size_t bn_dyn_expand = 0, bn_dyn_apply = 0;
 };
 
 constexpr uint32_t MAX_BATCH = 64;
@@ -951,6 +1089,44 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f, uint32_t l
   return p;
 }
 
+// Region plan of the binned levels (sssp_binned.h), cached on the handle like the mailbox plan.
+bool bin_eligible(const wfst_fst* f) {
+  return f->n_states <= (BN_MAXBINS << 14) && f->n_arcs > 0 && f->n_arcs < 0x7FFFFFFFull && !f->has_negative;
+}
+std::shared_ptr<BinPlan> bin_plan(wfst_ctx* ctx, const wfst_fst* f, uint32_t logd) {
+  std::lock_guard<std::mutex> lk(f->cache_mu);
+  if (f->binplan && f->binplan->logd == logd) return f->binplan;
+  const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;
+  auto p = std::make_shared<BinPlan>();
+  p->logd = logd;
+  p->nbin = (uint32_t)(((uint64_t)n + (1u << logd) - 1) >> logd);
+  // two expand workgroups per compute unit; a workgroup's range is a whole number of chunks
+  const uint32_t g_max = (uint32_t)std::min<int>(512, std::max<int>(1, 2 * ctx->n_cus));
+  p->sg = (uint32_t)(((((uint64_t)n + g_max - 1) / g_max) + BN_CH - 1) / BN_CH * BN_CH);
+  p->G = (uint32_t)(((uint64_t)n + p->sg - 1) / p->sg);
+  const size_t cells = (size_t)p->nbin * p->G;
+  p->roff = DBuf<uint32_t>(owner_pool, cells + 1);
+  p->roff_t = DBuf<uint32_t>(owner_pool, cells);
+  DBuf<uint32_t> hist(*ctx->pool, cells + 1);
+  if (logd == 14) bin_hist_kernel<14><<<p->G, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, p->sg, p->nbin, p->G, hist.p);
+  else bin_hist_kernel<13><<<p->G, 1024, 0, st>>>(f->dev.offsets, f->dev.wn, n, p->sg, p->nbin, p->G, hist.p);
+  HIP_CHECK(hipMemsetAsync(hist.p + cells, 0, sizeof(uint32_t), st));
+  size_t temp_bytes = 0;
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
+  bin_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roff.p, p->nbin, p->G, p->roff_t.p);
+  uint32_t h_slots = 0;
+  HIP_CHECK(hipMemcpyAsync(&h_slots, p->roff.p + cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));  // hist / temp are released here
+  p->slots = h_slots;
+  f->binplan = p;
+  return p;
+}
+
 // what the next solve of this FST is sized from: the launches this one needed, and how long that count has been the same
 void note_sweeps(const wfst_fst* f, uint32_t sweeps) {
   const uint32_t prev = f->last_sweeps.exchange(sweeps, std::memory_order_relaxed);
@@ -988,10 +1164,26 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
                                                                        sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
                                                                        profile, hint, sv.narrow_t);
   }
-  else
+  else {
     sssp_relax_kernel<<<sv.blocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u], sv.fl[(j & 1u) ^ 1u], n,
                                                  sv.improved.p, sv.ctl.p, off, sv.delta, sv.near_low, sv.shadow.p, sv.chase_cap,
-                                                 sv.chase_rounds, sv.chase_low, profile);
+                                                 sv.chase_rounds, sv.chase_low, profile, sv.binned ? sv.dense_low : 0xFFFFFFFFu);
+    if (sv.binned) {  // the same level as an owner-computes pass: both leave at once unless the launch above published a dense level
+      if (sv.bplan->logd == 14) {
+        sssp_bin_expand_kernel<14><<<sv.bv.G, BN_THREADS, sv.bn_dyn_expand, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u],
+                                                                                  sv.fl[(j & 1u) ^ 1u], n, sv.improved.p, sv.ctl.p, off,
+                                                                                  sv.shadow.p, sv.bv, profile);
+        sssp_bin_apply_kernel<14><<<sv.bv.nbin, BN_THREADS, sv.bn_dyn_apply, st>>>(sv.key.p, sv.shadow.p, sv.fl[(j & 1u) ^ 1u], n,
+                                                                                   sv.improved.p, sv.ctl.p, off, sv.bv);
+      } else {
+        sssp_bin_expand_kernel<13><<<sv.bv.G, BN_THREADS, sv.bn_dyn_expand, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.fl[j & 1u],
+                                                                                  sv.fl[(j & 1u) ^ 1u], n, sv.improved.p, sv.ctl.p, off,
+                                                                                  sv.shadow.p, sv.bv, profile);
+        sssp_bin_apply_kernel<13><<<sv.bv.nbin, BN_THREADS, sv.bn_dyn_apply, st>>>(sv.key.p, sv.shadow.p, sv.fl[(j & 1u) ^ 1u], n,
+                                                                                   sv.improved.p, sv.ctl.p, off, sv.bv);
+      }
+    }
+  }
 }
 
 // relax_setup allocates and initialises the state of a solve (keys, frontier flags, control block) and fixes its schedule parameters
@@ -1043,28 +1235,17 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     uint32_t log = 0;
     if (nb12 <= cus) log = 12;
     else if (nb13 <= cus && !std::getenv("WFST_SSSP_LOG12")) log = 13;
-    if (want && log && !ctx->profiling && !ctx->resident_off && !big_env && sv.lease.acquire(ctx->device)) {
+    if (want && log && !ctx->profiling && ctx->resident_allowed() && !big_env && sv.lease.acquire(ctx->device)) {
       want_res = true;
       sv.log = log;
     }
   }
   if (mbox_mode >= 1) {
     // Two message buffers of one slot per arc, the nb^2 region tables and counts come from the pool: on a tight pool (or a
-    // dense graph) the atomic sweeps, which need none of it, run instead.
-    try {
-      sv.plan = mbox_plan(ctx, f, sv.log);
-      const uint32_t nb = sv.plan->nb;
-      sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
-      const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * ((1u << sv.log) / 32);
-      sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 4 * nb);
-      sv.mb_wl = DBuf<uint4>(pool, (size_t)nb << sv.log);
-      if (want_res) {
-        sv.rs_msgs = DBuf<uint2>(pool, 2 * (size_t)sv.plan->res_units);
-        sv.rs_abort = DBuf<uint32_t>(pool, 16);
-      }
-      sv.mbox = true;
-    } catch (const Error&) {
-      if (sv.log == 13) throw;  // (a pool too tight for the 8192-state plan: the caller's next solve takes the default path)
+    // dense graph) the atomic sweeps, which need none of it, run instead.  The 8192-state plan exists in the resident kernel
+    // only: when it cannot be had (the pool, a region buffer beyond the buffer-descriptor range, no room for staging), the
+    // solve is planned again with 4096-state blocks and one launch per level — never refused.
+    auto release_all = [&] {
       want_res = false;
       sv.rs_msgs.reset();
       sv.rs_abort.reset();
@@ -1074,7 +1255,47 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       sv.mb_words.reset();
       sv.mb_wl.reset();
       sv.mbox = false;
+    };
+    auto try_plan = [&](uint32_t log, bool res) -> bool {
+      try {
+        sv.log = log;
+        sv.plan = mbox_plan(ctx, f, log);
+        const uint32_t nb = sv.plan->nb;
+        if (res) {  // what the resident launch needs beyond the plan
+          const uint64_t bytes = sv.plan->res_units * sizeof(uint2);
+          const size_t fixed = res_lds_bytes(log, nb, 0);
+          const bool fits = sv.plan->res_units != 0 && bytes < 0x7FFFFFF0ull && fixed + 8u * 4u * nb <= 160u * 1024u;
+          if (!fits) {
+            if (log == 13) throw Error("resident launch not possible");
+            res = false;
+            sv.lease.release();
+          }
+        }
+        sv.mb_msgs = DBuf<uint2>(pool, 2 * (size_t)f->n_arcs);
+        const size_t w_cnt = (size_t)nb * nb, w_pend = (size_t)nb * ((1u << log) / 32);
+        sv.mb_words = DBuf<uint32_t>(pool, 2 * w_cnt + 2 * nb + w_pend + 4 * nb);
+        sv.mb_wl = DBuf<uint4>(pool, (size_t)nb << log);
+        if (res) {
+          sv.rs_msgs = DBuf<uint2>(pool, 2 * (size_t)sv.plan->res_units);
+          sv.rs_abort = DBuf<uint32_t>(pool, 16);
+        }
+        want_res = res;
+        sv.mbox = true;
+        return true;
+      } catch (const Error&) {
+        (void)hipGetLastError();  // (a refused allocation must not surface at the next launch check)
+        release_all();
+        return false;
+      }
+    };
+    if (std::getenv("WFST_SSSP_TEST_FAIL_LOG13") && sv.log == 13) {  // tests: the 8192-state plan refused
+      release_all();
+      sv.log = 12;
+      try_plan(12, false);
+    } else if (!try_plan(sv.log, want_res) && sv.log == 13) {
+      try_plan(12, false);
     }
+    if (!sv.mbox) sv.log = 12;
   }
   if (sv.mbox) {
     const uint32_t nb = sv.plan->nb;
@@ -1184,12 +1405,65 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
                                                             delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f), sv.narrow_t, sv.rv.msgs[0],
                                                             sv.rv.msgs[1], sv.rv.roffh, sv.rv.abort);
   } else {
+    // Binned levels (sssp_binned.h): the dense levels of the solve as owner-computes passes, chosen per level on the device.
+    // Parity-green and measured (profiles/r05*): NOT faster than the atomic sweeps on MI355X at any size tried (5M states:
+    // 2.9 vs 2.4 ms; a binned level costs ~50 us + 25 ps per arc against 14.5 ps per arc + 78 ps per atomic), so it is an
+    // option, not the default.  WFST_SSSP_BINNED=1: on wherever the message format allows.
+    sv.binned = false;
+    sv.bplan.reset();
+    int bin_mode = 0;
+    if (const char* e = std::getenv("WFST_SSSP_BINNED")) bin_mode = bin_eligible(f) && delta < INF ? std::atoi(e) : 0;
+    if (bin_mode >= 1 && !(ctx->n_cus > 0)) bin_mode = 0;
+    if (bin_mode >= 1) {
+      uint32_t logd = n <= (BN_MAXBINS << 13) ? 13u : 14u;
+      if (const char* e = std::getenv("WFST_SSSP_BIN_LOG")) logd = std::atoi(e) == 14 ? 14u : logd;
+      try {  // (a slot per arc and the region tables come from the pool: on a tight pool the atomic sweeps run every level)
+        sv.bplan = bin_plan(ctx, f, logd);
+        const BinPlan& bp = *sv.bplan;
+        if (bp.slots == 0 || bp.slots >= 0xFFFF0000ull) throw Error("binned levels: region table out of range");
+        sv.bn_msgs = DBuf<uint2>(pool, (size_t)bp.slots);
+        sv.bn_cnt = DBuf<uint32_t>(pool, (size_t)bp.nbin * bp.G);
+        HIP_CHECK(hipMemsetAsync(sv.bn_cnt.p, 0, (size_t)bp.nbin * bp.G * sizeof(uint32_t), st));
+        BinView& bv = sv.bv;
+        bv.roff = bp.roff.p;
+        bv.roff_t = bp.roff_t.p;
+        bv.msgs = sv.bn_msgs.p;
+        bv.cnt = sv.bn_cnt.p;
+        bv.nbin = bp.nbin;
+        bv.G = bp.G;
+        bv.sg = bp.sg;
+        bv.hop_cap = 1u << (32u - logd);
+        if (const char* e = std::getenv("WFST_SSSP_BIN_HOPCAP")) bv.hop_cap = std::max<uint32_t>(1u, std::min<uint32_t>(bv.hop_cap, (uint32_t)std::atol(e)));
+        sv.bn_dyn_expand = bin_expand_lds(bp.nbin);
+        sv.bn_dyn_apply = bin_apply_lds(logd);
+        static std::once_flag bn_once[64];  // (a function attribute is per device)
+        std::call_once(bn_once[(unsigned)ctx->device & 63u], [] {
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_bin_expand_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS_MAX));
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_bin_expand_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS_MAX));
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_bin_apply_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS_MAX));
+          HIP_CHECK(hipFuncSetAttribute((const void*)sssp_bin_apply_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS_MAX));
+        });
+        // a binned level costs two launches and the keys of every bin that receives anything (12 B per state when all do):
+        // it pays from a frontier of ~1/64 of the states (measured, profiles/r05*: the atomic sweep relaxes ~10 G arcs/s there)
+        sv.dense_low = std::max<uint32_t>(16384u, n / 64u);
+        if (const char* e = std::getenv("WFST_SSSP_DENSE_LOW")) sv.dense_low = (uint32_t)std::min<long long>(0xFFFFFFFEll, std::atoll(e));
+        sv.binned = true;
+      } catch (const Error&) {
+        (void)hipGetLastError();  // (a refused allocation must not surface at the next launch check)
+        sv.binned = false;
+      }
+      if (!sv.binned) {
+        sv.bplan.reset();
+        sv.bn_msgs.reset();
+        sv.bn_cnt.reset();
+      }
+    }
     sssp_setup_kernel<<<sv.blocks, 256, 0, st>>>(sv.key.p, sv.shadow.p, (uint32_t*)sv.flags.p, (uint32_t)(2 * n_pad / 4),
                                                  sv.improved.p, sv.ctl.p, n, (uint32_t)f->start,
                                                  delta * (tau0_mult > 0.0f ? tau0_mult : 1.0f));
   }
   HIP_CHECK(hipGetLastError());
-  ctx->stats.relax_kernel = sv.mbox ? (sv.resident ? 2u : 1u) : 0u;
+  ctx->stats.relax_kernel = sv.mbox ? (sv.resident ? 2u : 1u) : (sv.binned ? 3u : 0u);
   sv.sweep_cap = 4ull * n + 64;
   if (const char* e = std::getenv("WFST_SSSP_CHASE_CAP")) sv.chase_cap = std::min<uint32_t>((uint32_t)std::atol(e), CHASE_MAX);
   if (const char* e = std::getenv("WFST_SSSP_CHASE_ROUNDS")) sv.chase_rounds = (uint32_t)std::atol(e);
@@ -1267,13 +1541,13 @@ struct SweepDriver {
     float a_delta = delta;
     uint32_t a_low = near_low;
     uint32_t* a_shadow = sv->shadow.p;
-    uint32_t a_cap = sv->chase_cap, a_rounds = sv->chase_rounds, a_clow = sv->chase_low, a_profile = 0;
+    uint32_t a_cap = sv->chase_cap, a_rounds = sv->chase_rounds, a_clow = sv->chase_low, a_profile = 0, a_dense = 0xFFFFFFFFu;
     for (uint32_t j = 0; j < count; ++j) {
       uint8_t* a_fc = sv->fl[j & 1u];
       uint8_t* a_fn = sv->fl[(j & 1u) ^ 1u];
       uint32_t a_off = j;
       void* args[] = {&a_offsets, &a_wn,  &a_key,   &a_fc,  &a_fn,     &a_n,   &a_imp,    &a_ctl,
-                      &a_off,     &a_delta, &a_low, &a_shadow, &a_cap, &a_rounds, &a_clow,   &a_profile};
+                      &a_off,     &a_delta, &a_low, &a_shadow, &a_cap, &a_rounds, &a_clow,   &a_profile, &a_dense};
       hipKernelNodeParams kp{};
       kp.func = (void*)sssp_relax_kernel;
       kp.gridDim = dim3(blocks);
@@ -1310,7 +1584,7 @@ struct SweepDriver {
     SweepBatch b{next_sweep, 8u, 1};
     if (next_sweep == 0) b = SweepBatch{0u, first_count, 0};
     else if (next_sweep >= 64) b = SweepBatch{next_sweep, MAX_BATCH, 2};
-    if (use_graphs && !sv->mbox) {
+    if (use_graphs && !sv->mbox && !sv->binned) {
       HIP_CHECK(hipGraphLaunch(get_graph(b.which, b.count), st));
     } else {
       // plain launches: the GPU starts on the first sweep while the host is still queueing the rest (a graph replay of
@@ -1365,7 +1639,7 @@ struct SweepDriver {
           done_seen = true;
           return;
         }
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // (a long solve: sleep on the event)
       }
     }
@@ -1461,7 +1735,7 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
       const uint64_t arcs = shard_sum(h_ctl->arcs), states = shard_sum(h_ctl->states);
-      ctx->sweep_trace.push_back({(double)ms, arcs - prev_arcs, states - prev_states});
+      ctx->sweep_trace.push_back({(double)ms, arcs - prev_arcs, states - prev_states, (sv.mbox || sv.binned) ? h_ctl->mode[k % RING] : 0u});
       prev_arcs = arcs;
       prev_states = states;
       ctx->stats.relax_ms += ms;
@@ -1478,12 +1752,18 @@ void run_relaxation(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     drv.finish();
     if (drv.aborted) {  // a resident launch gave up waiting (its grid was not resident as a whole): one launch per level
       HIP_CHECK(hipStreamSynchronize(st));
-      ctx->resident_off = true;
+      ctx->resident_aborted();
       ctx->stats.resident_aborts += 1;
       sv.lease.release();
+      struct Hold {
+        wfst_ctx* c;
+        ~Hold() { c->resident_hold = false; }
+      } hold{ctx};
+      ctx->resident_hold = true;
       run_relaxation(ctx, f, sv);
       return;
     }
+    if (sv.resident) ctx->resident_completed();
     sweeps_done = drv.sweeps_done;
     f->last_hint_mask.store(drv.hint_mask(), std::memory_order_relaxed);
   }
@@ -1618,11 +1898,13 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
 
 // Transpose of f (in-arcs as {source, position}); built the SECOND time shortest_path sees the same large FST —
 // a one-shot query keeps the parent pass, a resident transducer that is queried again pays ~1 ms once.
-const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f) {
+const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f, bool force = false) {
   std::lock_guard<std::mutex> lk(f->cache_mu);
   if (f->rev_dev) return f->rev_dev.get();
-  if (f->sp_queries.fetch_add(1) + 1 < 2 || f->n_arcs < (1u << 18) || f->n_arcs >= 0xFFFFFFFFull) return nullptr;
-  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return nullptr;
+  if (f->n_arcs >= 0xFFFFFFFFull || f->n_arcs == 0) return nullptr;
+  // (`force`: the caller needs the in-arcs of the path's states now — the uniqueness check of tie order 1 on a cyclic input)
+  if (!force && (f->sp_queries.fetch_add(1) + 1 < 2 || f->n_arcs < (1u << 18))) return nullptr;
+  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0 && !force) return nullptr;
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
   auto r = std::make_shared<RevCsr>();
@@ -1670,6 +1952,8 @@ struct wfst_sp_job {
   wfst_tr* h_path = nullptr;
   wfst::TailOut* h_tail = nullptr;  // header of the result, written by sssp_tail_kernel (transpose cached)
   uint32_t done_ticket = 0;         // what the fused tail writes into h_tail->done when everything else is in host memory
+  bool need_unique = false;         // tie order 1 on an input the reference does not relax in a topological order: the result
+                                    // is returned only when the optimum is unique (then it IS the reference's), KO otherwise
 };
 
 namespace wfst {
@@ -1714,11 +1998,17 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   ensure_device(const_cast<wfst_fst*>(f));
   if (ctx->tie_reference) {  // the reference's own choice among tied optima, where its relaxation order is a topological one
     std::vector<uint32_t> rank;
+    ctx->stats.tied_choices = WFST_TIES_UNKNOWN;
     if (reference_top_rank(f, rank)) {
       j->ready = shortest_path_reference_order(ctx, f, rank);
       return j.release();
     }
+    // A cycle (the reference relaxes inside an SCC queue) or unit weights (LIFO): its choice among tied optima is a function
+    // of its whole relaxation history there.  A UNIQUE optimum needs no choice: the canonical path is then the reference's
+    // path, and the tail kernel counts the tied choices along it (sssp_walk_back) — with any, the call is KO.
+    j->need_unique = true;
   }
+  ctx->stats.tied_choices = WFST_TIES_UNKNOWN;
   char* pin = (char*)ctx->pinned.get(sizeof(Ctl) + 128 + PATH_PINNED * sizeof(wfst_tr));
   j->hc = (Ctl*)pin;
   j->h_tail = (TailOut*)(pin + ((sizeof(Ctl) + 63) & ~(size_t)63));
@@ -1727,7 +2017,7 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   static std::atomic<uint32_t> tickets{0};
   do j->done_ticket = tickets.fetch_add(1, std::memory_order_relaxed) + 1u; while (j->done_ticket == 0u);
   j->h_tail->done = 0u;
-  j->rev = reverse_csr(ctx, f);  // may build the transpose (second query of a large FST): before anything is queued
+  j->rev = reverse_csr(ctx, f, j->need_unique);  // may build the transpose (second query of a large FST): before anything is queued
   if (ctx->profiling) {
     run_relaxation(ctx, f, j->sv);  // per-sweep events: synchronous
     return j.release();
@@ -1736,7 +2026,7 @@ wfst_sp_job* shortest_path_n1_begin(wfst_ctx* ctx, const wfst_fst* f) {
   ctx->stats.sweeps = 0;
   j->drv.init(ctx, f, &j->sv);
   const bool fuse = j->drv.predicted && j->rev && !std::getenv("WFST_SSSP_SPLIT_TAIL") &&
-                    !(j->drv.use_graphs && !j->sv.mbox);  // (a sweep graph carries its own advance node)
+                    !(j->drv.use_graphs && !j->sv.mbox && !j->sv.binned);  // (a sweep graph carries its own advance node)
   j->drv.start(/*defer_advance=*/fuse);
   if (fuse) {  // the tail closes the batch: flags to the host, base advanced, then the ticket (and the event) finish() waits for
     queue_tail(j.get(), &j->drv.cur);
@@ -1755,7 +2045,10 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   std::unique_ptr<wfst_sp_job> j(job);
   wfst_ctx* ctx = j->ctx;
   const wfst_fst* f = j->f;
-  if (j->trivial) return build_path_fst(ctx, false, 0, INF, nullptr);
+  if (j->trivial) {
+    ctx->stats.tied_choices = 0;
+    return build_path_fst(ctx, false, 0, INF, nullptr);
+  }
   if (j->ready) return j->ready;
   const uint32_t n = f->n_states;
   hipStream_t st = ctx->stream;
@@ -1764,11 +2057,17 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
     j->drv.finish();
     if (j->drv.aborted) {  // a resident launch gave up waiting: the whole query again, one launch per level
       HIP_CHECK(hipStreamSynchronize(st));
-      ctx->resident_off = true;
+      ctx->resident_aborted();
       ctx->stats.resident_aborts += 1;
       j.reset();  // (its buffers go back to the pool, the lease with them)
+      struct Hold {
+        wfst_ctx* c;
+        ~Hold() { c->resident_hold = false; }
+      } hold{ctx};
+      ctx->resident_hold = true;
       return shortest_path_n1_end(shortest_path_n1_begin(ctx, f));
     }
+    if (sv.resident) ctx->resident_completed();
     sv.lease.release();
     sv.sweeps = j->drv.sweeps_done;
     ctx->stats.sweeps = sv.sweeps;
@@ -1784,10 +2083,11 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   if (!j->tail_queued) queue_tail(j.get());
   // (the ticket of the fused tail was the last thing this job had on the stream: nothing to wait for)
   if (!(j->tail_queued && j->fused_tail && j->drv.done_seen && !j->drv.extended) || ctx->chain_timing) HIP_CHECK(hipStreamSynchronize(st));
+  else HIP_CHECK(hipGetLastError());  // (no stream wait on this path: a fault of the chain is still reported here)
   if (ctx->chain_timing && !ctx->profiling) {  // the sweeps of this query as one chain (wfst_ctx_set_profiling(ctx, 2))
     ctx->stats.relax_ms = 0.0;
     ctx->stats.relax_launches = 0;
-    if (j->drv.predicted && !j->drv.extended && !(j->drv.use_graphs && !sv.mbox)) {
+    if (j->drv.predicted && !j->drv.extended && !(j->drv.use_graphs && !sv.mbox && !sv.binned)) {
       float ms = 0.0f;
       HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_chain[0], ctx->ev_chain[1]));
       ctx->stats.relax_ms = ms;
@@ -1798,9 +2098,23 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   const uint32_t r_pad = j->fused_tail ? j->h_tail->pad : hc->pad, r_has_path = j->fused_tail ? j->h_tail->has_path : hc->has_path;
   if (r_pad & 1u) throw Error("shortest_path: hop count overflow in the mailbox sweeps (internal error)");
   if (r_pad & 4u) throw Error("shortest_path: no admissible predecessor on the path (inexact weight sums with negative weights)");
-  if (!r_has_path) return build_path_fst(ctx, false, 0, INF, nullptr);
+  if (!r_has_path) {  // no final state is reachable: the empty FST, and nothing to choose
+    ctx->stats.tied_choices = 0;
+    return build_path_fst(ctx, false, 0, INF, nullptr);
+  }
   const uint32_t hops = j->fused_tail ? j->h_tail->hops : hc->hops;
   const float final_weight = j->fused_tail ? j->h_tail->final_weight : hc->final_weight;
+  // tied choices along the returned path: counted by the one-launch tail's walk over the in-arcs (unknown on the other paths)
+  const uint64_t ties = j->fused_tail && !(r_pad & 8u) ? (uint64_t)j->h_tail->ties : WFST_TIES_UNKNOWN;
+  ctx->stats.tied_choices = ties;
+  if (j->need_unique) {
+    if (ties == WFST_TIES_UNKNOWN)
+      throw Error("shortest_path: tie order 1 on a cyclic input: the optimum could not be certified unique (no transpose for this input, or a path "
+                  "beyond the walk's buffer)");
+    if (ties != 0)
+      throw Error("shortest_path: ambiguous optimum: " + std::to_string(ties) + " tied choice(s) on the optimal path of a cyclic input — the "
+                  "reference's choice there depends on its relaxation order (tie order 1 returns only what is provably its result)");
+  }
   if (j->rev && !(r_pad & 8u)) return build_path_fst(ctx, true, hops, final_weight, j->h_path);
   // the parent pass (first query of an FST, or a path longer than the pinned buffer): a path has at most n - 1 arcs
   std::vector<wfst_tr> path;

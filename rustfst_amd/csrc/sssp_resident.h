@@ -363,7 +363,9 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
     RS_STAMP(0);
     if (lvl > 0) {
       if (s_abort) {
-        if (tid == 0) *improved = FLAG_RES_ABORT;
+        // (sticky: FLAG_RES_ABORT is the largest flag value and every writer of this launch's flag takes the maximum, so a
+        // workgroup that finishes its levels normally next to one that gave up cannot put another value over it)
+        if (tid == 0) atomicMax(improved, FLAG_RES_ABORT);
         return;
       }
       const unsigned long long ta = s_tot[ps][0], tb = s_tot[ps][1];
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
     mb.blk_far[j] = 0;
     mb.wl_cnt[j] = collect_exit ? last_an : 0u;
     if (collect_exit) {
-      if (last_an && *improved == 0u) *improved = 1u + MODE_COLLECT;
+      if (last_an) atomicMax(improved, 1u + MODE_COLLECT);
       if (last_an | last_nfar) atomicAdd(nf, ((unsigned long long)last_nfar << 32) | last_an);
     } else if (j == 0) {
       atomicMax(improved, FLAG_NARROW_CLEAN);

@@ -101,6 +101,14 @@ class Context:
                                                   n.value, C.byref(n)))
         return ms, arcs, states
 
+    def sweep_modes(self):
+        """What ran each launch of the last profiled solve: 0 atomic sweep, 7 binned level, or the mailbox mode."""
+        n = C.c_size_t()
+        check(_lib.lib().wfst_ctx_get_sweep_modes(self._h, None, 0, C.byref(n)))
+        modes = np.zeros(n.value, dtype=np.uint32)
+        check(_lib.lib().wfst_ctx_get_sweep_modes(self._h, modes.ctypes.data, n.value, C.byref(n)))
+        return modes
+
     def stats(self) -> dict:
         st = _lib.Stats()
         check(_lib.lib().wfst_ctx_get_stats(self._h, C.byref(st)))

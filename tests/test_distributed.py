@@ -337,3 +337,36 @@ print("RCCL-1 OK")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL-1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_multi_rank_exchange_matches_host_transport():
+    """The RCCL branch of the C-ABI exchange with MORE THAN ONE rank (csrc/gather.cpp: ncclCommInitRank(world > 1),
+    ncclAllGather behind wfst_gather_paths_* / wfst_comm_allgather_* / wfst_comm_allgatherv, wfst_comm_order_after): one process
+    per visible GPU (at most 8), every rank composing its shard of one global batch on its own device.  The gathered records
+    equal those of the host transport (the same exchange code over a gloo all-gather of the same processes: what the CPU
+    suite runs at world = 2) and, interleaved, a one-GPU run of the whole batch; ragged and resized exchanges included.
+    Skips on a box with one GPU (the builder's): it runs the day the suite meets a multi-GPU node."""
+    import subprocess
+    torch = pytest.importorskip("torch")
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"needs at least 2 GPUs (visible: {n})")
+    world = min(n, 8)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "rccl_exchange_check.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and f"RCCL-N OK world={world}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_check_script_runs_at_world_1():
+    """The same script at one rank (the hardware that exists here): keeps tools/rccl_exchange_check.py itself green, so that
+    the multi-rank test above cannot fail on the day it first runs for a reason that has nothing to do with RCCL."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "rccl_exchange_check.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "RCCL-N OK world=1" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -388,12 +388,17 @@ def test_config3_properties_1m_states(gpu_ctx, oracle):
             assert_flat_identical(f, can.to_flat(), f"1M batch item {i}")
 
 
-@pytest.mark.parametrize("kernel", ["mailbox", "mailbox_no_narrow", "mailbox_one_level", "atomic"])
+@pytest.mark.parametrize("kernel", ["mailbox", "mailbox_no_narrow", "mailbox_one_level", "atomic", "binned", "binned_every_level"])
 def test_config3_benched_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
     """The solve bench.py times — shortest_path(T), T = 1M states / 10M arcs, seed 3 — against the canonical oracle at full
     size: every distance, every hop count and the path itself bit-identical, for the mailbox launches (with and without
-    the NARROW hand-over) and for the atomic sweeps, on a first and on a repeated (predicted, gate-hinted) query."""
-    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0" if kernel == "atomic" else "1")
+    the NARROW hand-over), for the atomic sweeps, and for the atomic sweeps with their dense levels as binned passes (chosen
+    per level on the device / every level), on a first and on a repeated (predicted, gate-hinted) query."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0" if kernel in ("atomic", "binned", "binned_every_level") else "1")
+    if kernel.startswith("binned"):
+        monkeypatch.setenv("WFST_SSSP_BINNED", "1")
+    if kernel == "binned_every_level":
+        monkeypatch.setenv("WFST_SSSP_DENSE_LOW", "0")
     if kernel == "mailbox_no_narrow":
         monkeypatch.setenv("WFST_SSSP_NARROW", "0")
     if kernel == "mailbox_one_level":
@@ -404,7 +409,7 @@ def test_config3_benched_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
     can = to_oracle(oracle, t).shortest_path_canonical()
     for q in range(3):
         dist, hops = d.shortest_distance(want_hops=True)
-        assert ctx.stats()["relax_kernel"] == {"atomic": 0, "mailbox_one_level": 1}.get(kernel, 2)
+        assert ctx.stats()["relax_kernel"] == {"atomic": 0, "mailbox_one_level": 1, "binned": 3, "binned_every_level": 3}.get(kernel, 2)
         np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
         np.testing.assert_array_equal(hops, can.hops)
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"benched solve, {kernel}, query {q}")
@@ -454,13 +459,14 @@ def test_config5_lookahead_compose_and_nbest_at_scale_invariants_only():
 
 
 @pytest.mark.parametrize("delta", ["0", "0.7", "3", "1000"])
-def test_near_far_schedule_does_not_change_results(oracle, delta):
+def test_near_far_schedule_does_not_change_results(oracle, delta, monkeypatch):
     """The near-far threshold schedule only reorders relaxations: distances, hops and the path are the
     fixed point regardless of delta (0 = plain frontier sweeps)."""
     os.environ["WFST_SSSP_DELTA"] = delta
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0")
     try:
         ctx = rustfst_amd.Context(0)
-        for n, fan, seed in ((20_000, 8, 1), (3_000, 20, 2)):
+        for n, fan, seed in ((20_000, 8, 1), (3_000, 20, 2), (200_000, 10, 3)):
             t = synth.make_transducer(n, fan, 64, 0.02, seed=seed)
             d = to_device(t, ctx)
             dist, hops = d.shortest_distance(want_hops=True)
@@ -516,6 +522,7 @@ def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delt
     limit of zero (the first header that is not there yet makes the launch give up: the solve is repeated with one launch
     per level and the context stays in that mode)."""
     monkeypatch.setenv("WFST_SSSP_MAILBOX", mailbox.split(":")[0])
+    monkeypatch.setenv("WFST_SSSP_RES_RETRY_MS", "600000")  # (after an abort: no second resident attempt inside this test)
     if ":" in mailbox:
         k, v = mailbox.split(":")[1].split("=")
         monkeypatch.setenv({"narrow": "WFST_SSSP_NARROW", "hint": "WFST_SSSP_HINT", "res": "WFST_SSSP_RESIDENT",
@@ -559,16 +566,95 @@ def test_mailbox_sweeps_beyond_2_20_states(oracle, monkeypatch, narrow):
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"2.1M states q={q}")
 
 
-@pytest.mark.parametrize("variant", [None, "reslevels=3", "restlim=0", "narrow=0"])
+@pytest.mark.parametrize("variant", ["default", "dense_low=0", "dense_low=3000", "dense_low=4000000000", "log=14", "hopcap=3",
+                                     "dense_low=0,log=14,hopcap=2"])
+@pytest.mark.parametrize("delta", ["0.7", "3", "1000"])
+def test_binned_levels_do_not_change_results(oracle, monkeypatch, variant, delta):
+    """The dense levels of the atomic sweeps as owner-computes passes (sssp_bin_expand_kernel / sssp_bin_apply_kernel, chosen
+    per level on the device: sssp_binned.h) reach the same fixed point: distances, hop counts and the path bit-identical to
+    the canonical oracle — with the choice left to the device, with every level but the first binned (dense_low=0), with a
+    low and an unreachable threshold, with 16384-state bins, and with a hop limit of two / three arcs in the message format (deeper states relax through the atomic path inside the
+    expand kernel) — on graphs of one bin, a partial last bin, several source ranges, epsilons, a sparse deep graph."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0")
+    monkeypatch.setenv("WFST_SSSP_BINNED", "1")
+    monkeypatch.setenv("WFST_SSSP_DELTA", delta)
+    if variant != "default":
+        for kv in variant.split(","):
+            k, v = kv.split("=")
+            monkeypatch.setenv({"dense_low": "WFST_SSSP_DENSE_LOW", "log": "WFST_SSSP_BIN_LOG", "hopcap": "WFST_SSSP_BIN_HOPCAP"}[k], v)
+    ctx = rustfst_amd.Context(0)
+    for n, fan, p_eps, seed in ((70_000, 8, 0.02, 1), (3_000, 20, 0.0, 2), (30_000, 2, 0.3, 3), (8_192, 6, 0.0, 4),
+                                (8_193, 6, 0.0, 5), (300_000, 10, 0.0, 6)):
+        t = synth.make_transducer(n, fan, 64, p_eps, seed=seed)
+        d = to_device(t, ctx)
+        can = to_oracle(oracle, t).shortest_path_canonical()
+        for q in range(3):
+            dist, hops = d.shortest_distance(want_hops=True)
+            assert ctx.stats()["relax_kernel"] == 3
+            np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+            np.testing.assert_array_equal(hops, can.hops)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"binned {variant} delta={delta} n={n} q={q}")
+    rng = np.random.default_rng(78)
+    for k in range(8):  # small cyclic FSTs with epsilons and ties (integer weights)
+        f = random_fst_flat(rng, int(rng.integers(2, 300)), 5, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2, weight_grid=1, max_w=4)
+        ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
+        assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"binned small {k}")
+
+
+def test_binned_levels_are_what_runs_the_dense_levels(monkeypatch):
+    """A profiled solve reports what ran each level (wfst_ctx_get_sweep_modes): with the choice left to the device, the
+    first levels of a 400k-state search are atomic sweeps, its widest ones binned passes; the per-level arc counts add up
+    to the same relaxation whichever kernel ran them."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0")
+    monkeypatch.setenv("WFST_SSSP_BINNED", "1")
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(400_000, 10, 256, 0.0, seed=9)
+    d = to_device(t, ctx)
+    d.shortest_path()
+    ctx.reset_stats(); ctx.set_profiling(True); d.shortest_path(); ctx.set_profiling(False)
+    ms, arcs, states = ctx.sweep_trace()
+    modes = ctx.sweep_modes()
+    assert ctx.stats()["relax_kernel"] == 3
+    assert modes[0] == 0 and set(modes.tolist()) == {0, 7}
+    assert states[modes == 7].min() > states[modes == 0].max() // 8  # (the prediction is a bound, not the count)
+    assert int(arcs.sum()) >= int(t["arcs"].shape[0])  # every arc of a strongly connected T at least once
+
+
+@pytest.mark.parametrize("kernel", ["hybrid", "binned_every_level", "atomic"])
+def test_config5_size_solve_bit_exact_vs_oracle(oracle, monkeypatch, kernel):
+    """configs[4]'s size — 5M states / 50M arcs, the generator of `roofline_vs_size` — against the canonical oracle at FULL size:
+    every distance, every hop count and the path bit-identical with the atomic sweeps (the default there), with their dense
+    levels as binned passes chosen per level on the device, and with every level binned."""
+    if not kernel.startswith("atomic"):
+        monkeypatch.setenv("WFST_SSSP_BINNED", "1")
+    if kernel == "binned_every_level":
+        monkeypatch.setenv("WFST_SSSP_DENSE_LOW", "0")
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(5_000_000, 10, 256, 0.0, seed=3)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    for q in range(2):
+        dist, hops = d.shortest_distance(want_hops=True)
+        assert ctx.stats()["relax_kernel"] == (0 if kernel.startswith("atomic") else 3)
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"5M-state solve, {kernel}, query {q}")
+
+
+@pytest.mark.parametrize("variant", [None, "reslevels=3", "restlim=0", "narrow=0", "fail13=1"])
 def test_resident_launches_with_8192_state_blocks(oracle, monkeypatch, variant):
     """Between 2^20 and 2^21 states a block of 4096 states per compute unit no longer covers the FST: the resident kernel
     then owns blocks of 8192 states (64 KB of keys in LDS) and runs EVERY launch of the solve, the NARROW ones included.
     1.3M states / 6.5M arcs: distances, hop counts and the path bit-identical to the canonical oracle; with launches cut
     after three levels (hand-overs inside the one kernel), without the NARROW hand-over, and with a wait limit of zero
-    (the launch gives up, the solve is repeated with 4096-state blocks and one launch per level)."""
+    (the launch gives up, the solve is repeated with 4096-state blocks and one launch per level), and with the 8192-state plan
+    refused (a pool too tight for it, a region buffer beyond the descriptor range: the solve is planned again with 4096-state
+    blocks, never refused)."""
+    monkeypatch.setenv("WFST_SSSP_RES_RETRY_MS", "600000")  # (after an abort: no second resident attempt inside this test)
     if variant:
         k, v = variant.split("=")
-        monkeypatch.setenv({"reslevels": "WFST_SSSP_RES_LEVELS", "restlim": "WFST_SSSP_RES_TLIM_US", "narrow": "WFST_SSSP_NARROW"}[k], v)
+        monkeypatch.setenv({"reslevels": "WFST_SSSP_RES_LEVELS", "restlim": "WFST_SSSP_RES_TLIM_US", "narrow": "WFST_SSSP_NARROW",
+                            "fail13": "WFST_SSSP_TEST_FAIL_LOG13"}[k], v)
     ctx = rustfst_amd.Context(0)
     t = synth.make_transducer(1_300_000, 5, 64, 0.0, seed=12)
     d = to_device(t, ctx)
@@ -578,11 +664,93 @@ def test_resident_launches_with_8192_state_blocks(oracle, monkeypatch, variant):
         st = ctx.stats()
         if variant == "restlim=0":
             assert st["resident_aborts"] == 1 and st["relax_kernel"] == 1
+        elif variant == "fail13=1":
+            assert st["resident_aborts"] == 0 and st["relax_kernel"] == 1
         else:
             assert st["resident_aborts"] == 0 and st["relax_kernel"] == 2
         np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
         np.testing.assert_array_equal(hops, can.hops)
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"1.3M states ({variant}) q={q}")
+
+
+def test_resident_launches_are_tried_again_after_an_abort(oracle, monkeypatch):
+    """A resident launch that gives up waiting (wait limit 0 here) costs that solve a repeat with one launch per level and
+    the context a PAUSE, not the resident path for good: inside the pause solves take one launch per level without trying,
+    after it the next solve is a resident one again (wfst_ctx::resident_retry_at_ns; the pause doubles with every abort in a
+    row and is forgotten by the first resident solve that completes).  Every result bit-identical to the canonical oracle."""
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(300_000, 8, 64, 0.0, seed=14)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical().to_flat()
+
+    def solve(label, kernel, aborts):
+        got = d.shortest_path().to_flat()
+        st = ctx.stats()
+        assert (st["relax_kernel"], st["resident_aborts"]) == (kernel, aborts), (label, st["relax_kernel"], st["resident_aborts"])
+        assert_flat_identical(got, can, label)
+
+    solve("first", 2, 0)
+    monkeypatch.setenv("WFST_SSSP_RES_TLIM_US", "0")
+    monkeypatch.setenv("WFST_SSSP_RES_RETRY_MS", "0")
+    solve("aborts, no pause", 1, 1)
+    solve("aborts again at once", 1, 2)
+    monkeypatch.delenv("WFST_SSSP_RES_TLIM_US")
+    solve("resident again", 2, 2)
+    monkeypatch.setenv("WFST_SSSP_RES_TLIM_US", "0")
+    monkeypatch.setenv("WFST_SSSP_RES_RETRY_MS", "600000")
+    solve("aborts, long pause", 1, 3)
+    monkeypatch.delenv("WFST_SSSP_RES_TLIM_US")
+    solve("inside the pause: one launch per level, no attempt", 1, 3)
+
+
+def test_resident_solve_next_to_a_batch_that_fills_the_compute_units(oracle, monkeypatch):
+    """shortest_path(T) (1M states: a resident grid of 245 workgroups, one per compute unit) issued while a 4096-acceptor
+    fused batch holds the compute units on another context: bit-identical to the canonical oracle every time, at most one
+    abort per solve, and the solve after the batch is a resident one again."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("WFST_SSSP_RES_RETRY_MS", "0")
+    t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
+    accs = synth.make_acceptors(t, 4096, 200, seed0=1000)
+    ctx = rustfst_amd.Context(0)
+    s2 = torch.cuda.Stream()
+    ctx2 = rustfst_amd.Context(0, stream=s2.cuda_stream)
+    dt = to_device(t, ctx)
+    daccs = rustfst_amd.DeviceFst.upload_many(accs, ctx2)
+    can = to_oracle(oracle, t).shortest_path_canonical().to_flat()
+    for _ in range(3):
+        assert_flat_identical(dt.shortest_path().to_flat(), can, "alone")
+    assert ctx.stats()["relax_kernel"] == 2 and ctx.stats()["resident_aborts"] == 0
+    first = None
+    reps = 5
+    for rep in range(reps):
+        job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
+        sp = dt.shortest_path()
+        outs, n_arcs = job.finish()
+        assert_flat_identical(sp.to_flat(), can, f"next to the batch, rep {rep}")
+        flat = [o.to_flat() for o in outs[:8]]
+        if first is None:
+            first = flat
+        for a, b in zip(flat, first):
+            assert_flat_identical(a, b, f"batch results, rep {rep}")
+    assert ctx.stats()["resident_aborts"] <= reps
+    assert_flat_identical(dt.shortest_path().to_flat(), can, "after the batches")
+    assert ctx.stats()["relax_kernel"] == 2
+
+
+def test_two_processes_solving_on_one_gpu():
+    """Two PROCESSES query the same kind of FST on one GPU at the same time.  A resident launch needs every workgroup on a
+    compute unit of its own, so only one process at a time may run one: the lease is an advisory file lock per device
+    (ResidentLease), whoever does not get it takes one launch per level for that solve.  Both processes: every result equal
+    to their first, no resident launch ever gives up, and each of them ran resident launches."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "two_process_resident.py"), "600000", "150"]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and so.strip().splitlines()[-1].startswith("OK"), so[-1500:] + se[-1500:]
+        fields = dict(kv.split("=") for kv in so.strip().splitlines()[-1].split()[1:])
+        assert int(fields["aborts"]) == 0 and int(fields["resident"]) > 0, so[-500:]
 
 
 def test_reference_tie_order_on_acyclic_inputs(oracle):
@@ -591,11 +759,13 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
     shortest_path.rs:214-232) — bit-identical to the oracle's reference-order mode on tied inputs (weights on a 1/2 grid
     and integer weights: ties everywhere), on random DAGs in arbitrary state numbering (random permutations), on composed
     lattices with unit-spaced weights, and with the TOP_SORTED / ACYCLIC property bits set.  Inputs on which the
-    reference uses another queue (a cycle; all weights zero / one -> LIFO) keep the canonical rule."""
+    reference uses another queue (a cycle -> SCC queue; all weights zero / one -> LIFO) have no rule to follow: there the
+    call returns the path only when the optimum is UNIQUE (it is then the reference's path AND the canonical one,
+    wfst_stats.tied_choices == 0) and is KO "ambiguous optimum" when the canonical oracle counts a tied choice."""
     ctx = rustfst_amd.Context(0)
     ctx.set_tie_order(True)
     rng = np.random.default_rng(8080)
-    n_ref = n_tied = n_diff = 0
+    n_ref = n_tied = n_diff = n_other_unique = n_other_tied = 0
     for k in range(90):
         n = int(rng.integers(2, 120))
         f = random_fst_flat(rng, n, 4, 3, p_eps_i=0.1, p_final=0.25, acyclic=(k % 6 != 5), min_fanout=1,
@@ -616,18 +786,27 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
             f = dict(f, props=f["props"] | synth.ACYCLIC)
         o = to_oracle(oracle, f)
         ref = o.shortest_path()  # the reference's order (AutoQueue restatement, approximate ==)
-        got = to_device(f, ctx).shortest_path().to_flat()
+        can = o.shortest_path_canonical()
         if ref.queue_kind in ("top_order", "top_order_scc", "state_order"):
+            got = to_device(f, ctx).shortest_path().to_flat()
             n_ref += 1
-            can = o.shortest_path_canonical()
             n_tied += can.n_tied_choices > 0
             rf, cf = ref.to_flat(), can.to_flat()
             n_diff += not (rf["n_states"] == cf["n_states"] and np.array_equal(rf["arcs"], cf["arcs"]))
             assert_flat_identical(got, rf, f"reference tie order, case {k} ({ref.queue_kind})")
+        elif can.n_tied_choices > 0:
+            n_other_tied += 1
+            with pytest.raises(rustfst_amd.WfstError, match="ambiguous optimum"):
+                to_device(f, ctx).shortest_path()
         else:
-            assert_flat_identical(got, o.shortest_path_canonical().to_flat(), f"canonical fallback, case {k} ({ref.queue_kind})")
+            n_other_unique += 1
+            got = to_device(f, ctx).shortest_path().to_flat()
+            assert ctx.stats()["tied_choices"] == 0
+            assert_flat_identical(got, can.to_flat(), f"unique optimum, canonical, case {k} ({ref.queue_kind})")
+            assert_flat_identical(got, ref.to_flat(), f"unique optimum, the reference's path, case {k} ({ref.queue_kind})")
     # (the cases are not vacuous: optima tie, and the reference's choice differs from the canonical one on some of them)
     assert n_ref >= 45 and n_tied >= 8 and n_diff >= 3, (n_ref, n_tied, n_diff)
+    assert n_other_unique >= 3 and n_other_tied >= 3, (n_other_unique, n_other_tied)
     # composed lattices with integer weights (ties along the lattice)
     t = synth.make_transducer(3000, 6, 4, 0.0, seed=12)  # (no input epsilons: the lattices are acyclic)
     t["arcs"]["weight"] = np.round(t["arcs"]["weight"])
@@ -640,6 +819,51 @@ def test_reference_tie_order_on_acyclic_inputs(oracle):
         assert ref.queue_kind in ("top_order", "top_order_scc", "state_order")
         assert_flat_identical(lat.shortest_path().to_flat(), ref.to_flat(), "reference tie order on a composed lattice")
     ctx.set_tie_order(False)
+
+
+def test_tied_choices_are_reported_and_tie_order_1_is_total_on_cyclic_inputs(oracle):
+    """SURVEY F6 / shortest_path.rs:214-232: on a cyclic input rustfst's choice among tied optima depends on its dequeue
+    history.  The library tells the caller whether that matters: wfst_stats.tied_choices = states of the returned path with
+    more than one optimal predecessor (+ 1 for tied final states), counted by the tail kernel's walk over the in-arcs —
+    equal to the canonical oracle's count.  Tie order 0 always returns the canonical path; tie order 1 returns it only when
+    the count is 0 (then rustfst's path is the same one: compared with the oracle's reference mode) and is KO otherwise.
+    Cyclic branching graphs with integer weights (ties likely) and with k/512 weights (ties rare), 70k - 300k arcs."""
+    n_unique = n_tied = n_ref_differs = 0
+    for case, (n, fan, seed, integer) in enumerate([(9000, 8, 1, True), (9000, 8, 2, False), (40000, 8, 3, True), (40000, 8, 4, False),
+                                                    (2000, 40, 5, True), (2000, 40, 6, False), (30000, 3, 7, True), (30000, 3, 8, False)]):
+        t = synth.make_transducer(n, fan, 64, 0.0, seed=seed)
+        if integer:
+            t["arcs"]["weight"] = np.round(t["arcs"]["weight"] / 4.0) + 1.0  # (1, 2, 3, 4: optima tie)
+            t["finals"] = np.where(np.isfinite(t["finals"]), np.round(t["finals"]), np.inf).astype(np.float32)
+        o = to_oracle(oracle, t)
+        can = o.shortest_path_canonical()
+        ref = o.shortest_path()
+        assert ref.queue_kind not in ("top_order", "top_order_scc", "state_order")  # (a ring backbone: cyclic)
+        ctx = rustfst_amd.Context(0)
+        d = to_device(t, ctx)
+        for q in range(3):  # tie order 0: the canonical path, and from the second query on (transpose cached) the count
+            got = d.shortest_path().to_flat()
+            assert_flat_identical(got, can.to_flat(), f"case {case} q {q}")
+            ties = ctx.stats()["tied_choices"]
+            if t["arcs"].shape[0] >= 1 << 18 and q >= 1:
+                assert ties == can.n_tied_choices, (case, q, ties, can.n_tied_choices)
+            else:
+                assert ties in (can.n_tied_choices, rustfst_amd._lib.TIES_UNKNOWN)
+        ctx.set_tie_order(True)
+        if can.n_tied_choices == 0:
+            n_unique += 1
+            got = d.shortest_path().to_flat()
+            assert ctx.stats()["tied_choices"] == 0
+            assert_flat_identical(got, ref.to_flat(), f"case {case}: unique optimum = the reference's path")
+        else:
+            n_tied += 1
+            rf, cf = ref.to_flat(), can.to_flat()
+            n_ref_differs += not (rf["n_states"] == cf["n_states"] and np.array_equal(rf["arcs"], cf["arcs"]))
+            with pytest.raises(rustfst_amd.WfstError, match="ambiguous optimum"):
+                d.shortest_path()
+            assert ctx.stats()["tied_choices"] == can.n_tied_choices
+        ctx.set_tie_order(False)
+    assert n_unique >= 2 and n_tied >= 2, (n_unique, n_tied, n_ref_differs)
 
 
 def test_handles_outlive_their_context():

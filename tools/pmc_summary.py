@@ -12,7 +12,10 @@ for db in sorted(glob.glob(os.path.join(out, "*_results.db"))):
     n_solves = max(1, n_solves[0] if n_solves else 1)
     for name, cname, n, tot in c.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
         short = name.replace("wfst::(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0]
-        if short not in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel"):
+        if os.environ.get("PMC_KERNELS") == "all":
+            if not short.startswith("sssp_") or "setup" in short:
+                continue
+        elif short not in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel"):
             continue
         rows.setdefault(short, {})[cname] = (n / n_solves, tot / n_solves)
 for k, cs in rows.items():
