@@ -106,6 +106,7 @@ constexpr uint32_t CUR_SHARDS = 64;  // reservation cursors: one per 128-B line 
 constexpr uint32_t CUR_STRIDE = 32;  // 300 k states of one level on ONE cursor were 3.6 ms, the whole la_emit of that level)
 constexpr uint32_t LVL_RING = 64;    // level ranges live on the device: the host queues several levels per look
 constexpr uint32_t WIDE_MAX_BLOCKS = 4096;
+constexpr uint32_t WIDE_STAGE_MAX = 16;  // arcs of a state's searched side staged in LDS by la_emit
 struct WideCtl {
   uint32_t status;
   uint32_t k_done;  // levels finished so far; lvl[k_done % LVL_RING] is the next one (lo == hi: the search is over)
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(256) la_patch_range(WideArena ar, uint32_t q_l
 template <class P, uint32_t G>
 __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar, uint32_t level, WideCtl* ctl) {
   constexpr uint32_t SPW = 64 / G;
+  __shared__ uint4 s_stage[(256 / G) * WIDE_STAGE_MAX];  // the searched side's arcs of the states the block works on
   const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
   if (lo >= hi) return;
   const uint32_t lane = lane_id(), sub = lane % G, grp = lane / G;
@@ -233,7 +235,17 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
     const uint32_t q = q0 + grp;
     const bool valid = q < hi;
     const uint32_t qc = valid ? q : hi - 1;
-    const typename P::Expand x = pol.make_expand(ar.t_lo[qc], ar.t_hi[qc]);
+    typename P::Expand x = pol.make_expand(ar.t_lo[qc], ar.t_hi[qc]);
+    // The searched side's arcs go to LDS, one trip for the group: every item is matched against them by binary searches
+    // (equal_range: ~8 dependent probes per item), and a probe of a 16-byte arc in memory is a round trip of its own — a
+    // composed state of the look-ahead recipe (10 arcs searched, 2 items) walked ~20 of them one after the other, which was
+    // most of this kernel (profiles/r05c_wide_lookahead.md).  From LDS the searches cost what their instructions cost.
+    if (x.n_se <= WIDE_STAGE_MAX) {
+      uint4* const stg = s_stage + (threadIdx.x / G) * WIDE_STAGE_MAX;
+      for (uint32_t t = sub; t < x.n_se; t += G) stg[t] = *reinterpret_cast<const uint4*>(x.se_arcs + t);
+      x.se_arcs = reinterpret_cast<const wfst_tr*>(stg);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a group's slot is private to it: the wave's LDS accesses are ordered)
     const uint32_t n_items = valid ? x.n_it + 1 : 0u;
     // size of the segment
     uint32_t cnt0 = 0, seg_total = 0;
@@ -329,6 +341,7 @@ __global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar,
         ar.arcs[seg + k].nextstate = slot;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the staged arcs are read before the next states' overwrite them)
   }
 }
 

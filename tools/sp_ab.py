@@ -1,6 +1,6 @@
 """A/B of shortest_path(T) under several environment settings in ONE process (the relaxation reads its knobs per solve).
 
-usage: r4_quick.py STATES REPS cfg [cfg ...]      cfg = "name:VAR=val,VAR=val" or "name:" (defaults)
+usage: sp_ab.py STATES REPS cfg [cfg ...]      cfg = "name:VAR=val,VAR=val" or "name:" (defaults)
 Prints, per configuration: best / median host ms of shortest_path(T), the relaxation chain's device time (HIP events around
 the pre-queued launches, profiling mode 2), launches, the kernel that ran, and whether the distances are bit-identical to
 the first configuration's."""

@@ -13,3 +13,17 @@ best = 1e9
 for _ in range(reps):
     t0 = time.perf_counter(); d.shortest_path(); best = min(best, time.perf_counter() - t0)
 print(f"best of {reps}: {best*1e3:.3f} ms, sweeps {ctx.stats()['sweeps']}")
+# the same solves with the relaxation chain bracketed by HIP events (profiling mode 2): under `rocprofv3 --kernel-trace` this
+# process then holds BOTH clocks for the same launches — the events' chain time and the trace's per-kernel durations
+import statistics
+ctx.set_profiling(2)
+chain = []
+for _ in range(max(5, reps // 2)):
+    d.shortest_path()
+    st = ctx.stats()
+    if st["relax_launches"]:
+        chain.append(st["relax_ms"] * 1e3)
+ctx.set_profiling(0)
+if chain:
+    print(f"relaxation chain by HIP events (this process): median {statistics.median(chain):.1f} us, min {min(chain):.1f} us "
+          f"over {len(chain)} solves, {int(ctx.stats()['relax_launches'])} launches, kernel {int(ctx.stats()['relax_kernel'])}")
