@@ -858,9 +858,13 @@ def main():
             "cold_query_ms": None if cold is None else {
                 "first_in_process": cold[0], "second": cold[1], "third": cold[2], "fourth": cold[3],
                 "fresh_handle_warm_process": {"first": cold2[0], "second": cold2[1], "third": cold2[2]},
-                "note": "shortest_path(T) on a fresh HBM-resident handle: the 1st query builds the mailbox region plan and takes "
-                        "the parent pass, the 2nd builds the transpose; `first_in_process` also pays the process's first "
-                        "launches (code objects, the pool's first large allocations), `fresh_handle_warm_process` does not"},
+                "fresh_handle_frac_of_hbm_roofline": {k: round((20.0 * e_t + 12.0 * args.states) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                                      for k, v in (("first", cold2[0]), ("second", cold2[1]), ("third", cold2[2]))},
+                "note": "shortest_path(T) on a fresh HBM-resident handle: the 1st query builds the mailbox region plan, takes the parent "
+                                    "pass AND has the transpose for the backtrace built beside it on an auxiliary stream (its resident launch "
+                                    "waits for the compute units the build holds: the ~1 ms that used to sit in the 2nd query); from the 2nd "
+                                    "on the solve is one predicted batch with the one-launch tail; `first_in_process` also pays the process's first "
+                                    "launches (code objects, the pool's first large allocations), `fresh_handle_warm_process` does not"},
             "config5": config5, "batch_sweep": batch_sweep, "step_512_acceptors": step_512,
             "config2_single_string": config2,
             "reference_harness_split": harness,

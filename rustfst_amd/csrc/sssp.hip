@@ -1896,38 +1896,80 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
-// Transpose of f (in-arcs as {source, position}); built the SECOND time shortest_path sees the same large FST —
-// a one-shot query keeps the parent pass, a resident transducer that is queried again pays ~1 ms once.
+// Transpose of f (in-arcs as {source, position}) for the backtrace of repeated queries.  It is built BEHIND the first
+// shortest_path query of a large FST, on the context's auxiliary stream, while that query's relaxation runs (the first
+// query takes the parent pass either way): the second query finds it ready, or makes its stream wait for the rest of the
+// build — a one-shot query pays nothing it waits for, a resident transducer that is queried again no longer pays ~1 ms
+// inside its second query (bench.py cold_query_ms).  `force`: the caller needs the in-arcs now (tie order 1).
+namespace {
+void reverse_csr_build(wfst_ctx* ctx, const wfst_fst* f, RevCsr& r, hipStream_t st, bool async) {
+  const uint32_t n = f->n_states;
+  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
+  r.off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
+  r.arc = DBuf<uint4>(owner_pool, f->n_arcs);
+  // (scratch: from the owner's pool too and kept in the object until the build is known to be over — released at once they
+  // could be handed to a launch of another stream)
+  r.tmp_indeg = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
+  r.tmp_cursor = DBuf<uint32_t>(owner_pool, n);
+  HIP_CHECK(hipMemsetAsync(r.tmp_indeg.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
+  rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, r.tmp_indeg.p);
+  // rev_off = exclusive scan of the in-degrees (n + 1 outputs: the extra zero input makes rev_off[n] the total)
+  size_t temp_bytes = 0;
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, r.tmp_indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+  r.tmp_scan = DBuf<uint8_t>(owner_pool, temp_bytes);
+  HIP_CHECK(rocprim::exclusive_scan(r.tmp_scan.p, temp_bytes, r.tmp_indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+  HIP_CHECK(hipMemcpyAsync(r.tmp_cursor.p, r.off.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  const uint32_t fblocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
+  rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, r.tmp_cursor.p, r.arc.p);
+  HIP_CHECK(hipGetLastError());
+  if (async) {
+    HIP_CHECK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(r.ready, st));
+    r.settled.store(false);
+  } else {
+    HIP_CHECK(hipStreamSynchronize(st));
+    r.tmp_indeg.reset();
+    r.tmp_cursor.reset();
+    r.tmp_scan.reset();
+  }
+}
+bool transpose_wanted(const wfst_fst* f) {
+  if (f->n_arcs >= 0xFFFFFFFFull || f->n_arcs == 0) return false;
+  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return false;
+  return true;
+}
+}  // namespace
+
 const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f, bool force = false) {
   std::lock_guard<std::mutex> lk(f->cache_mu);
-  if (f->rev_dev) return f->rev_dev.get();
-  if (f->n_arcs >= 0xFFFFFFFFull || f->n_arcs == 0) return nullptr;
-  // (`force`: the caller needs the in-arcs of the path's states now — the uniqueness check of tie order 1 on a cyclic input)
-  if (!force && (f->sp_queries.fetch_add(1) + 1 < 2 || f->n_arcs < (1u << 18))) return nullptr;
-  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0 && !force) return nullptr;
-  const uint32_t n = f->n_states;
-  hipStream_t st = ctx->stream;
-  auto r = std::make_shared<RevCsr>();
-  DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
-  r->off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
-  r->arc = DBuf<uint4>(owner_pool, f->n_arcs);
-  DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
-  HIP_CHECK(hipMemsetAsync(indeg.p, 0, (size_t)n * sizeof(uint32_t), st));
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
-  rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, indeg.p);
-  {  // rev_off = exclusive scan of the in-degrees (n + 1 outputs: the extra zero input makes rev_off[n] the total)
-    HIP_CHECK(hipMemsetAsync(indeg.p + n, 0, sizeof(uint32_t), st));
-    size_t temp_bytes = 0;
-    HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, indeg.p, r->off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
-    DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
-    HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, indeg.p, r->off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
-    HIP_CHECK(hipMemcpyAsync(cursor.p, r->off.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));  // temp is released here
+  if (RevCsr* r = f->rev_dev.get()) {
+    if (!r->settled.load()) {  // built behind an earlier query: over by now, or this stream waits for the rest of it
+      if (hipEventQuery(r->ready) == hipSuccess) {
+        r->tmp_indeg.reset();
+        r->tmp_cursor.reset();
+        r->tmp_scan.reset();
+        r->settled.store(true);
+      } else {
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream, r->ready, 0));
+      }
+    }
+    return r;
   }
-  const uint32_t fblocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
-  rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, cursor.p, r->arc.p);
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(st));  // indeg / cursor are released here
+  if (!(force ? f->n_arcs < 0xFFFFFFFFull && f->n_arcs != 0 : transpose_wanted(f))) return nullptr;
+  const uint32_t seen = f->sp_queries.fetch_add(1) + 1;
+  if (!force && f->n_arcs < (1u << 18)) return nullptr;  // (small FSTs: the parent pass over all arcs is as cheap as the walk)
+  const bool async_ok = !force && !ctx->profiling && !(std::getenv("WFST_SSSP_ASYNC_TRANSPOSE") && std::atoi(std::getenv("WFST_SSSP_ASYNC_TRANSPOSE")) == 0);
+  auto r = std::make_shared<RevCsr>();
+  if (seen < 2 && async_ok) {  // first query: start the build beside it, answer this query without
+    if (!ctx->aux_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    reverse_csr_build(ctx, f, *r, ctx->aux_stream, true);
+    f->rev_dev = r;
+    return nullptr;
+  }
+  if (seen < 2 && !force) return nullptr;
+  reverse_csr_build(ctx, f, *r, ctx->stream, false);
   f->rev_dev = r;
   return r.get();
 }
