@@ -221,8 +221,13 @@ __global__ void __launch_bounds__(256) la_patch_range(WideArena ar, uint32_t q_l
 // parallelism — idle); loops run to the longest trip count among the wave's groups so that shuffles stay wave-uniform.
 // Policy P supplies the composition itself: P::Expand, make_expand(tuple words) and eval_item(expand, item, write, position,
 // arrays, first emitted) -> number of arcs the item emits (see compose_lookahead.hip / compose_wide.hip).
+#ifdef WFST_WIDE_WAVES_PER_EU  // experiments: cap the registers of la_emit for more waves per SIMD
+#define WFST_WIDE_EMIT_ATTR __attribute__((amdgpu_waves_per_eu(WFST_WIDE_WAVES_PER_EU, WFST_WIDE_WAVES_PER_EU)))
+#else
+#define WFST_WIDE_EMIT_ATTR
+#endif
 template <class P, uint32_t G>
-__global__ void __launch_bounds__(256) la_emit(P pol, LaCaps caps, WideArena ar, uint32_t level, WideCtl* ctl) {
+__global__ void __launch_bounds__(256) WFST_WIDE_EMIT_ATTR la_emit(P pol, LaCaps caps, WideArena ar, uint32_t level, WideCtl* ctl) {
   constexpr uint32_t SPW = 64 / G;
   __shared__ uint4 s_stage[(256 / G) * WIDE_STAGE_MAX];  // the searched side's arcs of the states the block works on
   const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
