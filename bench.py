@@ -38,7 +38,7 @@ def kernel_sources_sha256():
     state of the kernel is flagged stale in the bench line"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_resident.h"):
+    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_resident.h", "sssp_binned.h"):
         with open(os.path.join(ROOT, "rustfst_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

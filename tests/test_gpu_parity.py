@@ -458,6 +458,32 @@ def test_config5_lookahead_compose_and_nbest_at_scale_invariants_only():
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_config5_lookahead_full_size_sample_vs_oracle(oracle):
+    """BASELINE configs[4] at its FULL operand size against the oracle on a sample: the 5M-state / 50M-arc HCLG-shaped FST (5 %
+    output epsilons) as the look-ahead operand, two of the 200-label acceptors — the look-ahead composition (label
+    reachability over 5M states, relabelling, the filter stack) bit-identical to the oracle's: states, arc order, labels,
+    weight bits, finals; and the n = 10 shortest paths of the first result identical to the oracle's on ITS result.  (The
+    oracle redoes MatcherFst::new per composition, as rustfst-cli does: ~9 s each on one core.)"""
+    n = 5_000_000
+    t = synth.make_transducer(n, 10, 256, 0.05, seed=9)
+    accs = synth.make_acceptors(t, 2, 200, seed0=77)
+    arcs = t["arcs"].copy()
+    arcs["ilabel"], arcs["olabel"] = t["arcs"]["olabel"].copy(), t["arcs"]["ilabel"].copy()
+    t1 = dict(t, arcs=arcs, props=synth.O_LABEL_SORTED)
+    ctx = rustfst_amd.Context(0)
+    la = rustfst_amd.LookAhead(to_device(t1, ctx))
+    o1 = to_oracle(oracle, t1)
+    for i, a in enumerate(accs):
+        got = la.compose(la.relabel(to_device(a, ctx)))
+        exp = o1.compose_lookahead(to_oracle(oracle, a))
+        g, e = got.to_flat(), exp.to_flat()
+        assert g["n_states"] == e["n_states"] and g["n_states"] > 100, (i, g["n_states"], e["n_states"])
+        assert_flat_identical(g, e, f"look-ahead composition at 5M states, acceptor {i}")
+        if i == 0:
+            assert_flat_identical(got.shortest_path(ShortestPathConfig(nshortest=10)).to_flat(), exp.shortest_path_n(10).to_flat(),
+                                  "n = 10 shortest paths of the 5M-state look-ahead composition")
+
+
 @pytest.mark.parametrize("delta", ["0", "0.7", "3", "1000"])
 def test_near_far_schedule_does_not_change_results(oracle, delta, monkeypatch):
     """The near-far threshold schedule only reorders relaxations: distances, hops and the path are the
