@@ -626,21 +626,26 @@ def main():
         # 512 acceptors here — the one-GPU form of configs[3])
         step_512 = None
         if rank == 0 and world == 1 and not args.no_extras and args.overlap:
-            daccs_keep = daccs
+            daccs_keep, order_keep = daccs, args.order
             daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(sweep_accs[:512], ctx2))
-            for _ in range(20):
-                step()
-            torch.cuda.synchronize(device)
-            c0 = time.perf_counter()
-            a512, n512 = 0, 200
-            for _ in range(n512):
-                a512 += step()
-            torch.cuda.synchronize(device)
-            el512 = time.perf_counter() - c0
             step_512 = {"workload": f"the timed step with ALL 512 acceptors (len {args.acc_len}) of configs[3] on this one GPU: "
-                                    "shortest_path(T) + fused compose->shortest_path of 512, overlapped on two contexts",
-                        "steps": n512, "ms_per_step": round(1e3 * el512 / n512, 4), "arcs_per_s": round(a512 / el512, 1),
-                        "acceptors_per_s": round(512 * n512 / el512, 1)}
+                                    "shortest_path(T) + fused compose->shortest_path of 512, overlapped on two contexts; both enqueue orders "
+                                    "(a 512-string batch holds 64 compute units for ~0.3 ms: the relaxation's resident launch, which wants one "
+                                    "workgroup on each of 245, waits for them)", "steps": 200}
+            for order in ("s1-first", "s2-first"):
+                args.order = order
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize(device)
+                c0 = time.perf_counter()
+                a512, n512 = 0, 200
+                for _ in range(n512):
+                    a512 += step()
+                torch.cuda.synchronize(device)
+                el512 = time.perf_counter() - c0
+                step_512[order] = {"ms_per_step": round(1e3 * el512 / n512, 4), "arcs_per_s": round(a512 / el512, 1),
+                                   "acceptors_per_s": round(512 * n512 / el512, 1)}
+            args.order = order_keep
             daccs = daccs_keep
 
         # ------------------------------------------------------------------ configs[4]: HCLG-shaped operand under look-ahead
@@ -860,11 +865,10 @@ def main():
                 "fresh_handle_warm_process": {"first": cold2[0], "second": cold2[1], "third": cold2[2]},
                 "fresh_handle_frac_of_hbm_roofline": {k: round((20.0 * e_t + 12.0 * args.states) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                                                       for k, v in (("first", cold2[0]), ("second", cold2[1]), ("third", cold2[2]))},
-                "note": "shortest_path(T) on a fresh HBM-resident handle: the 1st query builds the mailbox region plan, takes the parent "
-                                    "pass AND has the transpose for the backtrace built beside it on an auxiliary stream (its resident launch "
-                                    "waits for the compute units the build holds: the ~1 ms that used to sit in the 2nd query); from the 2nd "
-                                    "on the solve is one predicted batch with the one-launch tail; `first_in_process` also pays the process's first "
-                                    "launches (code objects, the pool's first large allocations), `fresh_handle_warm_process` does not"},
+                "note": "shortest_path(T) on a fresh HBM-resident handle: the 1st query builds the mailbox region plan and takes the parent "
+                        "pass; the 2nd builds the transpose for the backtrace (through the plan's regions: ~0.3 ms); from the 3rd on the solve "
+                        "is one predicted batch with the one-launch tail; `first_in_process` also pays the process's first launches (code "
+                        "objects, the pool's first large allocations), `fresh_handle_warm_process` does not"},
             "config5": config5, "batch_sweep": batch_sweep, "step_512_acceptors": step_512,
             "config2_single_string": config2,
             "reference_harness_split": harness,

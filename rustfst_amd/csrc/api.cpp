@@ -212,10 +212,6 @@ wfst_status wfst_ctx_destroy(wfst_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->ev_chain)
       if (e) (void)hipEventDestroy(e);
-    if (ctx->aux_stream) {
-      (void)hipStreamSynchronize(ctx->aux_stream);
-      (void)hipStreamDestroy(ctx->aux_stream);
-    }
     ctx->pool.reset();
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

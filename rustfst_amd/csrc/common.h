@@ -135,7 +135,6 @@ struct wfst_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
-  hipStream_t aux_stream = nullptr;  // created on first use: work that should overlap the queries of `stream` (transpose builds)
   // shared with every FST handle created on this context (and its arenas): the device memory of a handle that outlives
   // its context (interpreter shutdown destroys in any order) is still released to a live pool, which goes with the last owner
   std::shared_ptr<wfst::DevicePool> pool;
@@ -214,19 +213,6 @@ struct RevFst {
 struct RevCsr {
   DBuf<uint32_t> off;  // [n+1]
   DBuf<uint4> arc;     // [E] {source state, position of the arc in the source's arc list, weight bits, 0}
-  // Built asynchronously behind the FIRST shortest_path query of the FST, on the context's auxiliary stream: `ready` is
-  // recorded behind the last build kernel; a consumer makes its stream wait for it until somebody has seen it complete
-  // (`settled`), which is also when the build's scratch buffers go back to the pool.  null: built synchronously.
-  hipEvent_t ready = nullptr;
-  std::atomic<bool> settled{true};
-  DBuf<uint32_t> tmp_indeg, tmp_cursor;
-  DBuf<uint8_t> tmp_scan;
-  ~RevCsr() {
-    if (ready) {
-      (void)hipEventSynchronize(ready);  // (the build may still be writing into the buffers released below)
-      (void)hipEventDestroy(ready);
-    }
-  }
 };
 // Message-region plan of the mailbox relaxation sweeps (sssp_mailbox.h): offsets of the region reserved for every
 // (source block, destination block) pair, sized by the number of arcs between the two blocks.

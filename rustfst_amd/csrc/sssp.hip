@@ -584,6 +584,75 @@ __global__ void __launch_bounds__(256) rev_fill_kernel(const uint32_t* __restric
   }
 }
 
+// ---- the same transpose WITHOUT a global atomic, for FSTs that have a mailbox plan (sssp_mailbox.h): region (i -> j) of the
+// plan holds one slot per arc from block i to block j, destination-major — so the regions of destination block j, taken
+// together, ARE the in-arcs of block j's states, already contiguous and already at their final place in rev_arc; what is
+// left is the order inside the block.  rev_bucket_kernel: workgroup i writes a record {source, position, weight, target mod B}
+// per arc of block i into its slot (one LDS atomicAdd on the region's cursor; the records of a region fill its lines front to
+// back); rev_place_kernel: workgroup j counts its records per target state in LDS, scans, writes rev_off, and moves every
+// record to its target's run.  10 M arcs: ~0.2 ms against ~1.2 ms for the two atomic passes above.
+template <uint32_t LOG>
+__global__ void __launch_bounds__(1024) rev_bucket_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn, uint32_t n,
+                                                          uint32_t nb, const uint32_t* __restrict__ roff_t, uint4* __restrict__ rec) {
+  constexpr uint32_t B = 1u << LOG;
+  extern __shared__ uint32_t l_cur[];  // [nb] next slot of region (i -> j)
+  const uint32_t i = blockIdx.x, s0 = i << LOG, s1 = min(n, s0 + B);
+  for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) l_cur[j] = roff_t[(size_t)i * nb + j];
+  __syncthreads();
+  const uint32_t sub = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+  for (uint32_t s = s0 + grp; s < s1; s += blockDim.x / 16) {
+    const uint32_t b = offsets[s], e = offsets[s + 1];
+    for (uint32_t k = b + sub; k < e; k += 16) {
+      const uint2 a = wn[k];
+      const uint32_t slot = atomicAdd(&l_cur[a.y >> LOG], 1u);
+      rec[slot] = make_uint4(s, k - b, a.x, a.y & (B - 1u));
+    }
+  }
+}
+template <uint32_t LOG>
+__global__ void __launch_bounds__(1024) rev_place_kernel(const uint32_t* __restrict__ roff, uint32_t nb, uint32_t n,
+                                                         const uint4* __restrict__ rec, uint32_t* __restrict__ rev_off,
+                                                         uint4* __restrict__ rev_arc) {
+  constexpr uint32_t B = 1u << LOG, R = B / 1024;
+  __shared__ uint32_t l_cnt[B];
+  __shared__ uint32_t s_wsum[16];
+  const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t lo = roff[(size_t)j * nb], hi = roff[(size_t)(j + 1) * nb];  // all the in-arcs of block j
+  for (uint32_t t = tid; t < B; t += 1024) l_cnt[t] = 0;
+  __syncthreads();
+  for (uint32_t k = lo + tid; k < hi; k += 1024) atomicAdd(&l_cnt[rec[k].w], 1u);
+  __syncthreads();
+  // exclusive scan of the B counts: R consecutive counts per thread, a wave scan of the thread sums, the wave totals
+  uint32_t c[R], mine = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    c[r] = l_cnt[tid * R + r];
+    mine += c[r];
+  }
+  uint32_t x = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  if (lane == 63) s_wsum[wv] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wv; ++w) base += s_wsum[w];
+  uint32_t run = base + x - mine;
+  const uint32_t s0 = j << LOG;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t tl = tid * R + r;
+    l_cnt[tl] = run;  // from here on: the next free position of the target's run
+    if (s0 + tl < n) rev_off[s0 + tl] = lo + run;
+    run += c[r];
+  }
+  if (j == gridDim.x - 1 && tid == 0) rev_off[n] = hi;
+  __syncthreads();
+  for (uint32_t k = lo + tid; k < hi; k += 1024) {
+    const uint4 r = rec[k];
+    rev_arc[lo + atomicAdd(&l_cnt[r.w], 1u)] = make_uint4(r.x, r.y, r.z, 0u);
+  }
+}
+
 // single_shortest_path_backtrace (shortest_path.rs:241-282) over the transpose, by ONE wave: at every step the lanes test
 // the in-arcs of the current state for tightness, (d[s] (x) w, hops[s] + 1) == (d[t], hops[t]), and the smallest
 // (class, s, pos) wins — the same predecessor sssp_parent_kernel selects.  A step is TWO dependent trips: the in-arc
@@ -1896,80 +1965,60 @@ void shortest_distance(wfst_ctx* ctx, const wfst_fst* f, float* distance, uint32
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
-// Transpose of f (in-arcs as {source, position}) for the backtrace of repeated queries.  It is built BEHIND the first
-// shortest_path query of a large FST, on the context's auxiliary stream, while that query's relaxation runs (the first
-// query takes the parent pass either way): the second query finds it ready, or makes its stream wait for the rest of the
-// build — a one-shot query pays nothing it waits for, a resident transducer that is queried again no longer pays ~1 ms
-// inside its second query (bench.py cold_query_ms).  `force`: the caller needs the in-arcs now (tie order 1).
+// Transpose of f (in-arcs as {source, position}); built the SECOND time shortest_path sees the same large FST — a one-shot
+// query keeps the parent pass, a resident transducer that is queried again pays the build once, inside its second query:
+// ~0.3 ms for 10 M arcs through the mailbox plan (rev_bucket_kernel / rev_place_kernel), ~1.2 ms by the two atomic passes for
+// FSTs without a plan.  (Building it on a second stream beside the FIRST query was measured: that query's resident launch
+// waits for the compute units the build holds — 0.65 -> 1.8 ms, and a one-shot query pays for a transpose it never uses.)
+// `force`: the caller needs the in-arcs of the path's states now (tie order 1 on a cyclic input).
 namespace {
-void reverse_csr_build(wfst_ctx* ctx, const wfst_fst* f, RevCsr& r, hipStream_t st, bool async) {
+void reverse_csr_build(wfst_ctx* ctx, const wfst_fst* f, RevCsr& r) {
   const uint32_t n = f->n_states;
+  hipStream_t st = ctx->stream;
   DevicePool& owner_pool = f->owner_pool ? *f->owner_pool : *ctx->pool;  // cached with the handle: the owner's pool outlives it
   r.off = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
   r.arc = DBuf<uint4>(owner_pool, f->n_arcs);
-  // (scratch: from the owner's pool too and kept in the object until the build is known to be over — released at once they
-  // could be handed to a launch of another stream)
-  r.tmp_indeg = DBuf<uint32_t>(owner_pool, (size_t)n + 1);
-  r.tmp_cursor = DBuf<uint32_t>(owner_pool, n);
-  HIP_CHECK(hipMemsetAsync(r.tmp_indeg.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
+  const MboxPlan* plan = f->mbox ? f->mbox.get() : f->mbox13.get();  // (cache_mu is held by the caller)
+  if (plan && !(std::getenv("WFST_SSSP_TRANSPOSE_PLAN") && std::atoi(std::getenv("WFST_SSSP_TRANSPOSE_PLAN")) == 0)) {
+    DBuf<uint4> rec(*ctx->pool, f->n_arcs);  // one record per arc, bucketed by destination block
+    if (plan->log == 13) {
+      rev_bucket_kernel<13><<<plan->nb, 1024, plan->nb * sizeof(uint32_t), st>>>(f->dev.offsets, f->dev.wn, n, plan->nb, plan->roff_t.p, rec.p);
+      rev_place_kernel<13><<<plan->nb, 1024, 0, st>>>(plan->roff.p, plan->nb, n, rec.p, r.off.p, r.arc.p);
+    } else {
+      rev_bucket_kernel<12><<<plan->nb, 1024, plan->nb * sizeof(uint32_t), st>>>(f->dev.offsets, f->dev.wn, n, plan->nb, plan->roff_t.p, rec.p);
+      rev_place_kernel<12><<<plan->nb, 1024, 0, st>>>(plan->roff.p, plan->nb, n, rec.p, r.off.p, r.arc.p);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));  // rec is released here
+    return;
+  }
+  DBuf<uint32_t> indeg(*ctx->pool, (size_t)n + 1), cursor(*ctx->pool, n);
+  HIP_CHECK(hipMemsetAsync(indeg.p, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((f->n_arcs + 255) / 256, (uint64_t)ctx->n_cus * 8);
-  rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, r.tmp_indeg.p);
+  rev_count_kernel<<<blocks, 256, 0, st>>>(f->dev.wn, f->n_arcs, indeg.p);
   // rev_off = exclusive scan of the in-degrees (n + 1 outputs: the extra zero input makes rev_off[n] the total)
   size_t temp_bytes = 0;
-  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, r.tmp_indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
-  r.tmp_scan = DBuf<uint8_t>(owner_pool, temp_bytes);
-  HIP_CHECK(rocprim::exclusive_scan(r.tmp_scan.p, temp_bytes, r.tmp_indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
-  HIP_CHECK(hipMemcpyAsync(r.tmp_cursor.p, r.off.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+  DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
+  HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, indeg.p, r.off.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+  HIP_CHECK(hipMemcpyAsync(cursor.p, r.off.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   const uint32_t fblocks = std::min<uint32_t>((uint32_t)ctx->n_cus * 8, (uint32_t)(((uint64_t)n * GROUP + 255) / 256));
-  rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, r.tmp_cursor.p, r.arc.p);
+  rev_fill_kernel<<<fblocks, 256, 0, st>>>(f->dev.offsets, f->dev.wn, n, cursor.p, r.arc.p);
   HIP_CHECK(hipGetLastError());
-  if (async) {
-    HIP_CHECK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(r.ready, st));
-    r.settled.store(false);
-  } else {
-    HIP_CHECK(hipStreamSynchronize(st));
-    r.tmp_indeg.reset();
-    r.tmp_cursor.reset();
-    r.tmp_scan.reset();
-  }
-}
-bool transpose_wanted(const wfst_fst* f) {
-  if (f->n_arcs >= 0xFFFFFFFFull || f->n_arcs == 0) return false;
-  if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return false;
-  return true;
+  HIP_CHECK(hipStreamSynchronize(st));  // indeg / cursor / temp are released here
 }
 }  // namespace
 
 const RevCsr* reverse_csr(wfst_ctx* ctx, const wfst_fst* f, bool force = false) {
   std::lock_guard<std::mutex> lk(f->cache_mu);
-  if (RevCsr* r = f->rev_dev.get()) {
-    if (!r->settled.load()) {  // built behind an earlier query: over by now, or this stream waits for the rest of it
-      if (hipEventQuery(r->ready) == hipSuccess) {
-        r->tmp_indeg.reset();
-        r->tmp_cursor.reset();
-        r->tmp_scan.reset();
-        r->settled.store(true);
-      } else {
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        HIP_CHECK(hipStreamWaitEvent(ctx->stream, r->ready, 0));
-      }
-    }
-    return r;
+  if (f->rev_dev) return f->rev_dev.get();
+  if (f->n_arcs >= 0xFFFFFFFFull || f->n_arcs == 0) return nullptr;
+  if (!force) {
+    if (f->sp_queries.fetch_add(1) + 1 < 2 || f->n_arcs < (1u << 18)) return nullptr;
+    if (const char* e = std::getenv("WFST_SSSP_TRANSPOSE")) if (std::atoi(e) == 0) return nullptr;
   }
-  if (!(force ? f->n_arcs < 0xFFFFFFFFull && f->n_arcs != 0 : transpose_wanted(f))) return nullptr;
-  const uint32_t seen = f->sp_queries.fetch_add(1) + 1;
-  if (!force && f->n_arcs < (1u << 18)) return nullptr;  // (small FSTs: the parent pass over all arcs is as cheap as the walk)
-  const bool async_ok = !force && !ctx->profiling && !(std::getenv("WFST_SSSP_ASYNC_TRANSPOSE") && std::atoi(std::getenv("WFST_SSSP_ASYNC_TRANSPOSE")) == 0);
   auto r = std::make_shared<RevCsr>();
-  if (seen < 2 && async_ok) {  // first query: start the build beside it, answer this query without
-    if (!ctx->aux_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    reverse_csr_build(ctx, f, *r, ctx->aux_stream, true);
-    f->rev_dev = r;
-    return nullptr;
-  }
-  if (seen < 2 && !force) return nullptr;
-  reverse_csr_build(ctx, f, *r, ctx->stream, false);
+  reverse_csr_build(ctx, f, *r);
   f->rev_dev = r;
   return r.get();
 }

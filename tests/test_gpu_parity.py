@@ -1313,14 +1313,13 @@ def test_shortest_path_repeated_queries_use_transpose(gpu_ctx, oracle, seed):
         assert_flat_identical(d.shortest_path().to_flat(), ref2, f"after tr_sort, query {q}")
 
 
-@pytest.mark.parametrize("async_build", ["1", "0"], ids=["built_behind_the_first_query", "built_in_the_second_query"])
-def test_transpose_is_there_for_the_second_query(oracle, monkeypatch, async_build):
-    """The transpose for the backtrace is built on the context's auxiliary stream while the FIRST query of a large FST
-    runs (sssp.hip: reverse_csr): the second query — right behind the first, or from another context — already walks it (the
-    one-launch tail ran: it counted the tied choices), a tr_sort in between drops it while it may still be under
-    construction, and an abandoned handle with a build in flight is released cleanly.  Every path bit-identical to the
-    canonical oracle; WFST_SSSP_ASYNC_TRANSPOSE=0 builds it inside the second query as before."""
-    monkeypatch.setenv("WFST_SSSP_ASYNC_TRANSPOSE", async_build)
+@pytest.mark.parametrize("plan", ["1", "0"], ids=["through_the_mailbox_plan", "two_atomic_passes"])
+def test_transpose_is_built_in_the_second_query(oracle, monkeypatch, plan):
+    """The transpose for the backtrace is built inside the SECOND shortest_path query of a large FST (sssp.hip: reverse_csr):
+    through the mailbox plan's regions (rev_bucket_kernel / rev_place_kernel: no global atomic) or, without a plan, by the two
+    atomic passes — the same walks either way: every path bit-identical to the canonical oracle, the tied choices counted
+    from the second query on; a second context, a tr_sort in between, an abandoned handle."""
+    monkeypatch.setenv("WFST_SSSP_TRANSPOSE_PLAN", plan)
     unknown = rustfst_amd._lib.TIES_UNKNOWN
     ctx = rustfst_amd.Context(0)
     t = synth.make_transducer(300_000, 8, 64, 0.0, seed=41)
@@ -1332,7 +1331,7 @@ def test_transpose_is_there_for_the_second_query(oracle, monkeypatch, async_buil
     for q in range(3):
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"query {q + 2}")
         assert ctx.stats()["tied_choices"] == can.n_tied_choices
-    # a second context right behind a fresh handle's first query: its stream waits for the build if it is still running
+    # a second context right behind a fresh handle's first query
     d2 = to_device(t, ctx)
     ctx_b = rustfst_amd.Context(0)
     import ctypes as C
@@ -1344,15 +1343,17 @@ def test_transpose_is_there_for_the_second_query(oracle, monkeypatch, async_buil
     assert_flat_identical(first, can.to_flat(), "fresh handle, first query")
     assert_flat_identical(got, can.to_flat(), "fresh handle, second query from another context")
     assert ctx_b.stats()["tied_choices"] == can.n_tied_choices
-    # tr_sort right behind a first query: the transpose under construction is dropped, the next one is built for the new order
+    # tr_sort after the transpose exists: it is dropped, the next one is built for the new order
     d3 = to_device(t, ctx)
+    d3.shortest_path()
     d3.shortest_path()
     d3.tr_sort(False)
     o.tr_sort(by_olabel=True)
     ref3 = o.shortest_path_canonical().to_flat()
     for q in range(3):
         assert_flat_identical(d3.shortest_path().to_flat(), ref3, f"after tr_sort, query {q}")
-    d4 = to_device(t, ctx)  # a handle dropped with its build in flight
+    d4 = to_device(t, ctx)  # a handle dropped right after the query that built its transpose
+    d4.shortest_path()
     d4.shortest_path()
     del d4
 
