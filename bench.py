@@ -38,7 +38,7 @@ def kernel_sources_sha256():
     state of the kernel is flagged stale in the bench line"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_resident.h", "sssp_binned.h"):
+    for name in ("sssp.hip", "sssp_mailbox.h", "sssp_resident.h", "sssp_binned.h", "api.cpp"):  # (api.cpp: the device pool — block reuse decides what a solve finds in the Infinity Cache)
         with open(os.path.join(ROOT, "rustfst_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -429,6 +429,24 @@ def main():
         os.remove(f_out)
 
     last = {}
+    chain_probe = {}
+
+    def chain_us(label, n=15):
+        """the relaxation chain of a repeated shortest_path(T) on the bench's handle by HIP events (profiling mode 2), median of n;
+        recorded under `label` (roofline.chain_us_by_point: the same bracket at several points of the run)"""
+        if rank != 0:
+            return None
+        ctx.set_profiling(2)
+        v = []
+        for _ in range(n):
+            dt.shortest_path()
+            cs = ctx.stats()
+            if cs["relax_launches"]:
+                v.append(1e3 * cs["relax_ms"])
+        ctx.set_profiling(0)
+        v.sort()
+        chain_probe[label] = round(v[len(v) // 2], 1) if v else None
+        return chain_probe[label]
     batch_arcs = [0]  # composed + relaxed arcs of the batch legs only (what scales with the number of GPUs)
     phases = [0.0, 0.0, 0.0, 0.0, 0]  # host seconds in: first begin, second begin, batch finish, shortest_path finish; steps
 
@@ -543,6 +561,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t_start
         step_phases_us = None
+        chain_us("after_timed_steps")
         if args.overlap and phases[4]:
             # (the counters include the warm-up steps: same code path)
             step_phases_us = {k: round(1e6 * phases[i] / phases[4], 1) for i, k in
@@ -575,6 +594,7 @@ def main():
 
         # ------------------------------------------------------------------ configs[1]: ONE 1000-arc string against a
         # 100k-state T (the case a lone dependent chain makes the GPU lose to one CPU core; reported, not timed above)
+        chain_us("after_alone_passes")
         config2 = None
         if rank == 0 and not args.no_extras:
             t2 = synth.make_transducer(100_000, args.fanout, args.sigma, 0.0, seed=2)
@@ -593,6 +613,7 @@ def main():
                        "gpu_ms": round(1e3 * best, 4), "composed_arcs": int(n2), "_t2": t2, "_a2": a2}
 
         # ------------------------------------------------------------------ batch_sweep: where the fused batch saturates
+        chain_us("after_config2")
         batch_sweep = None
         if rank == 0 and not args.no_extras:
             batch_sweep = []
@@ -624,6 +645,7 @@ def main():
         # ------------------------------------------------------------------ the whole 512-acceptor batch of configs[3] on ONE GPU
         # (the timed step above holds this GPU's share of it, 512 / 8: weak scaling; this is the same overlapped step with all
         # 512 acceptors here — the one-GPU form of configs[3])
+        chain_us("after_batch_sweep")
         step_512 = None
         if rank == 0 and world == 1 and not args.no_extras and args.overlap:
             daccs_keep, order_keep = daccs, args.order
@@ -650,14 +672,17 @@ def main():
 
         # ------------------------------------------------------------------ configs[4]: HCLG-shaped operand under look-ahead
         # composition + n = 10 shortest paths (rustfst-cli/src/cmds/compose.rs:77-181 wires the look-ahead recipe)
+        chain_us("after_step_512")
         config5 = None
         if rank == 0 and not args.no_extras and args.config5_states > 0:
             config5 = config5_extra(args.config5_states, ctx, device)
+        chain_us("after_config5")
 
         # ------------------------------------------------------------------ the same roofline figure at other sizes
         rvs = None
         if rank == 0 and not args.no_extras and args.roofline_sizes:
             rvs = roofline_vs_size(ctx, [int(x) for x in args.roofline_sizes.split(",") if x], args.fanout, args.sigma)
+        chain_us("after_roofline_vs_size")
 
         # ------------------------------------------------------------------ roofline of the relaxation kernel
         # HIP events bracket every sssp_relax_kernel launch on ctx's stream (wfst_ctx_set_profiling);
@@ -703,6 +728,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(solve_bytes / max(1, st["relax_launches"]), 1),
                     "solve_algorithmic_bytes": 20 * e_t + 12 * args.states,
                     "solve_relax_kernel_ms": round(st["relax_ms"], 4),
+                    "chain_us_by_point": dict(chain_probe),
                     "solve_frac": round(achieved / HBM_PEAK_GBS, 5),
                     "arcs_relaxed": int(st["relax_arcs"]), "frontier_states": int(st["relax_states"]),
                     "relax_arcs_per_s": round(st["relax_arcs"] / (st["relax_ms"] * 1e-3), 1),

@@ -27,8 +27,14 @@ size_t DevicePool::bucket(size_t bytes) {
 void* DevicePool::alloc(size_t bytes) {
   std::lock_guard<std::mutex> lk(mu_);
   size_t b = bucket(bytes);
-  auto it = free_.find(b);
-  if (it != free_.end()) {
+  // LIFO inside a bucket: the block freed LAST is handed out first.  A solve frees its buffers in the reverse order of their
+  // allocation, so every buffer of the next solve gets the block it had in the last one — two buffers of one bucket (the
+  // mailbox kernels' two message arrays are both 160 MB for the benched T) otherwise SWAP blocks from solve to solve, and a
+  // resident launch whose region headers sit where the other array was last time finds none of them in the Infinity Cache:
+  // 280 -> 265 us per solve of C3 (LAB_NOTEBOOK.md, round 5).
+  auto range = free_.equal_range(b);
+  if (range.first != range.second) {
+    auto it = std::prev(range.second);
     void* p = it->second;
     free_.erase(it);
     live_[p] = b;
