@@ -1,4 +1,4 @@
-"""Randomised differential soak of the relaxation kernels (atomic sweeps, mailbox sweeps with their NARROW launches)
+"""Randomised differential soak of the relaxation kernels (atomic sweeps with and without binned levels, mailbox sweeps with their NARROW launches)
 against the canonical CPU oracle: python tools/soak_sssp.py [seconds] [seed0].  Every case draws a kernel, a band width
 and, for the mailbox kernel, a hand-over threshold and a gating mode."""
 import os, sys, time
@@ -22,6 +22,14 @@ while time.time() < t_end:
     os.environ["WFST_SSSP_NARROW"] = str(int(rng.choice([0, 8, 64, 8192, 1_000_000_000])))  # hand-over threshold of the NARROW launches
     os.environ["WFST_SSSP_BIG"] = str(int(rng.integers(0, 2)))  # the many-blocks variant of the kernel
     os.environ["WFST_SSSP_STG"] = str(int(rng.choice([1, 2, 7, 24])))  # staging slots per destination
+    # the binned levels behind the atomic sweeps (mode 0 only): per-level choice / every level / off, 8192- or 16384-state bins,
+    # a hop limit of the message format low enough that deep states relax through the atomic path of the expand kernel
+    os.environ["WFST_SSSP_BINNED"] = str(int(rng.integers(0, 2)))
+    os.environ["WFST_SSSP_DENSE_LOW"] = str(int(rng.choice([0, 50, 3000, 4_000_000_000])))
+    os.environ["WFST_SSSP_BIN_LOG"] = str(int(rng.choice([13, 14])))
+    os.environ["WFST_SSSP_BIN_HOPCAP"] = str(int(rng.choice([2, 5, 1 << 18])))
+    os.environ["WFST_SSSP_RES_RETRY_MS"] = "0"
+    os.environ["WFST_SSSP_TRANSPOSE_PLAN"] = str(int(rng.integers(0, 2)))
     hint = rng.choice(["", "0", "1"])
     if hint:
         os.environ["WFST_SSSP_HINT"] = str(hint)
