@@ -453,14 +453,18 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       const uint32_t sub = tid & 15u, grp = tid >> 4;
       unsigned long long* __restrict__ msgs_out = (unsigned long long*)rv.msgs[ps ^ 1u];
       const __amdgpu_buffer_rsrc_t rs_out = ps ? rs0 : rs1;
-      constexpr uint32_t G = MB_THREADS / 16, ROUND = G * 8u;
+#ifndef WFST_RS_UMAX
+#define WFST_RS_UMAX 5
+#endif
+      constexpr uint32_t G = MB_THREADS / 16, UMAX = WFST_RS_UMAX, ROUND = G * UMAX;  // (UMAX: states a 16-lane group relaxes at once in a wide level)
       static_assert(MB_THREADS == 1024, "a resident workgroup is sixteen waves");
+      static_assert(UMAX >= 4u && UMAX <= 8u, "the one-round ladder below is 1 / 2 / 4 / UMAX states per group");
       const uint32_t an_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)an);
       uint32_t sent = 0;
 #define RS_EXPAND(U_, r0_) rs_expand_round<LOG, U_>(r0_, an_u, grp, sub, wn, a_state, lkey, l_pend, l_off, j, l_cur, l_base, l_stage, stg, l_roff_out, msgs_out, &ctl->pad)
       if (an_u <= ROUND) {
         // one round (every level but a band's widest): the staged runs start at the regions' first slots
-        if (an_u > 4u * G) sent = RS_EXPAND(8, 0u);
+        if (UMAX > 4u && an_u > 4u * G) sent = RS_EXPAND(UMAX, 0u);
         else if (an_u > 2u * G) sent = RS_EXPAND(4, 0u);
         else if (an_u > G) sent = RS_EXPAND(2, 0u);
         else if (an_u) sent = RS_EXPAND(1, 0u);
@@ -484,7 +488,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       } else {
         // several rounds: after each, the staged runs go out behind what the earlier rounds wrote (l_base) and the counts start again
         for (uint32_t r0 = 0; r0 < an_u; r0 += ROUND) {
-          sent |= RS_EXPAND(8, r0);
+          sent |= RS_EXPAND(UMAX, r0);
           __syncthreads();
           if (reg < nb) {
             const uint32_t first = l_base[reg], cnt = l_cur[reg], last = first + min(cnt, stg), ro = l_roff_out[reg];
