@@ -599,13 +599,33 @@ __global__ void __launch_bounds__(1024) rev_bucket_kernel(const uint32_t* __rest
   const uint32_t i = blockIdx.x, s0 = i << LOG, s1 = min(n, s0 + B);
   for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) l_cur[j] = roff_t[(size_t)i * nb + j];
   __syncthreads();
+  // 16 lanes per state, four states of a group in flight (their row bounds, then their first 16 arcs, are requested together:
+  // one workgroup per compute unit, so the loads in flight per thread are the bandwidth)
   const uint32_t sub = threadIdx.x & 15u, grp = threadIdx.x >> 4;
-  for (uint32_t s = s0 + grp; s < s1; s += blockDim.x / 16) {
-    const uint32_t b = offsets[s], e = offsets[s + 1];
-    for (uint32_t k = b + sub; k < e; k += 16) {
-      const uint2 a = wn[k];
-      const uint32_t slot = atomicAdd(&l_cur[a.y >> LOG], 1u);
-      rec[slot] = make_uint4(s, k - b, a.x, a.y & (B - 1u));
+  constexpr uint32_t U = 4, G = 1024 / 16;
+  for (uint32_t sb = s0 + grp; sb < s1; sb += U * G) {
+    uint32_t b[U], e[U];
+    uint2 a[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t s = sb + u * G;
+      b[u] = s < s1 ? offsets[s] : 0u;
+      e[u] = s < s1 ? offsets[s + 1] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) a[u] = b[u] + sub < e[u] ? wn[b[u] + sub] : make_uint2(0u, 0u);
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t s = sb + u * G;
+      if (b[u] + sub < e[u]) {
+        const uint32_t slot = atomicAdd(&l_cur[a[u].y >> LOG], 1u);
+        rec[slot] = make_uint4(s, sub, a[u].x, a[u].y & (B - 1u));
+      }
+      for (uint32_t k = b[u] + sub + 16u; k < e[u]; k += 16u) {  // (rows beyond 16 arcs)
+        const uint2 x = wn[k];
+        const uint32_t slot = atomicAdd(&l_cur[x.y >> LOG], 1u);
+        rec[slot] = make_uint4(s, k - b[u], x.x, x.y & (B - 1u));
+      }
     }
   }
 }
@@ -620,7 +640,18 @@ __global__ void __launch_bounds__(1024) rev_place_kernel(const uint32_t* __restr
   const uint32_t lo = roff[(size_t)j * nb], hi = roff[(size_t)(j + 1) * nb];  // all the in-arcs of block j
   for (uint32_t t = tid; t < B; t += 1024) l_cnt[t] = 0;
   __syncthreads();
-  for (uint32_t k = lo + tid; k < hi; k += 1024) atomicAdd(&l_cnt[rec[k].w], 1u);
+  // (four records per thread in flight: one workgroup per compute unit is all the parallelism there is here)
+  {
+    uint32_t k = lo + tid;
+    for (; k + 3u * 1024u < hi; k += 4u * 1024u) {
+      const uint32_t t0 = rec[k].w, t1 = rec[k + 1024u].w, t2 = rec[k + 2048u].w, t3 = rec[k + 3072u].w;
+      atomicAdd(&l_cnt[t0], 1u);
+      atomicAdd(&l_cnt[t1], 1u);
+      atomicAdd(&l_cnt[t2], 1u);
+      atomicAdd(&l_cnt[t3], 1u);
+    }
+    for (; k < hi; k += 1024u) atomicAdd(&l_cnt[rec[k].w], 1u);
+  }
   __syncthreads();
   // exclusive scan of the B counts: R consecutive counts per thread, a wave scan of the thread sums, the wave totals
   uint32_t c[R], mine = 0;
@@ -647,9 +678,21 @@ __global__ void __launch_bounds__(1024) rev_place_kernel(const uint32_t* __restr
   }
   if (j == gridDim.x - 1 && tid == 0) rev_off[n] = hi;
   __syncthreads();
-  for (uint32_t k = lo + tid; k < hi; k += 1024) {
-    const uint4 r = rec[k];
-    rev_arc[lo + atomicAdd(&l_cnt[r.w], 1u)] = make_uint4(r.x, r.y, r.z, 0u);
+  {
+    uint32_t k = lo + tid;
+    for (; k + 3u * 1024u < hi; k += 4u * 1024u) {
+      const uint4 r0 = rec[k], r1 = rec[k + 1024u], r2 = rec[k + 2048u], r3 = rec[k + 3072u];
+      const uint32_t p0 = atomicAdd(&l_cnt[r0.w], 1u), p1 = atomicAdd(&l_cnt[r1.w], 1u);
+      const uint32_t p2 = atomicAdd(&l_cnt[r2.w], 1u), p3 = atomicAdd(&l_cnt[r3.w], 1u);
+      rev_arc[lo + p0] = make_uint4(r0.x, r0.y, r0.z, 0u);
+      rev_arc[lo + p1] = make_uint4(r1.x, r1.y, r1.z, 0u);
+      rev_arc[lo + p2] = make_uint4(r2.x, r2.y, r2.z, 0u);
+      rev_arc[lo + p3] = make_uint4(r3.x, r3.y, r3.z, 0u);
+    }
+    for (; k < hi; k += 1024u) {
+      const uint4 r = rec[k];
+      rev_arc[lo + atomicAdd(&l_cnt[r.w], 1u)] = make_uint4(r.x, r.y, r.z, 0u);
+    }
   }
 }
 
