@@ -1313,6 +1313,55 @@ def test_shortest_path_repeated_queries_use_transpose(gpu_ctx, oracle, seed):
         assert_flat_identical(d.shortest_path().to_flat(), ref2, f"after tr_sort, query {q}")
 
 
+def _ragged_transducer(n, max_deg, seed):
+    """synth.make_transducer's arcs with a random out-degree per state in [0, max_deg]: rows of no arcs, of fewer than 16, of
+    more than 16 and of more than 32 (the 16-lane groups of the transpose kernels take a row 16 arcs at a time)."""
+    t = synth.make_transducer(n, max_deg, 64, 0.0, seed=seed)
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, max_deg + 1, n).astype(np.uint32)
+    deg[0] = max_deg
+    keep = np.tile(np.arange(max_deg, dtype=np.uint32), n) < np.repeat(deg, max_deg)
+    offsets = np.zeros(n + 1, np.uint32)
+    offsets[1:] = np.cumsum(deg, dtype=np.uint64).astype(np.uint32)
+    props = int(t["props"]) & ~(synth.ACCESSIBLE | synth.INITIAL_CYCLIC)  # (no longer known)
+    arcs = np.ascontiguousarray(t["arcs"][keep])
+    arcs["weight"] = np.floor(arcs["weight"] / np.float32(2.5)) + np.float32(1.0)  # 1..4: many in-arcs of a state are tight at once
+    return dict(n_states=n, start=0, offsets=offsets, arcs=arcs, finals=t["finals"], props=props)
+
+
+@pytest.mark.parametrize("n,max_deg,picks", [(40_000, 40, 6), (1_010_000, 18, 2)], ids=["4096_state_blocks", "8192_state_blocks"])
+def test_transpose_through_the_plan_on_ragged_rows(oracle, monkeypatch, n, max_deg, picks):
+    """rev_bucket_kernel / rev_place_kernel (sssp.hip) on rows of every length, with both block sizes of the mailbox plan:
+    handles with ONE final state each (a different walk through the transpose per handle), the second and third query of
+    each — the ones that walk the in-arcs — bit-identical to the canonical oracle, with its count of tied choices: with weights
+    1..4 most states have several tight in-arcs, so both the predecessor chosen (the smallest (source, position) among them)
+    and the count depend on every in-arc record of the states on the walk."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "1")
+    monkeypatch.setenv("WFST_SSSP_TRANSPOSE_PLAN", "1")
+    ctx = rustfst_amd.Context(0)
+    t = _ragged_transducer(n, max_deg, seed=77)
+    assert len(t["arcs"]) >= 1 << 18 and int(np.diff(t["offsets"].astype(np.int64)).max()) > 16
+    dist = to_device(t, ctx).shortest_distance()
+    reach = np.flatnonzero(np.isfinite(dist))
+    assert len(reach) > n // 2
+    far = reach[np.argsort(dist[reach], kind="stable")[-(len(reach) // 50):]]  # the farthest 2 %: the longest walks, most ties
+    rng = np.random.default_rng(n)
+    tied = 0
+    for pick in rng.choice(far, size=picks, replace=False):
+        finals = np.full(n, np.inf, np.float32)
+        finals[pick] = np.float32(0.25)
+        tp = dict(t, finals=finals)
+        can = to_oracle(oracle, tp).shortest_path_canonical()
+        assert can.to_flat()["n_states"] > 1
+        d = to_device(tp, ctx)
+        for q in range(3):  # parent pass; the query that builds the transpose; the predicted batch with the one-launch tail
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"final state {pick}, query {q + 1}")
+            if q:
+                assert ctx.stats()["tied_choices"] == can.n_tied_choices
+        tied += can.n_tied_choices
+    assert tied > 0
+
+
 @pytest.mark.parametrize("plan", ["1", "0"], ids=["through_the_mailbox_plan", "two_atomic_passes"])
 def test_transpose_is_built_in_the_second_query(oracle, monkeypatch, plan):
     """The transpose for the backtrace is built inside the SECOND shortest_path query of a large FST (sssp.hip: reverse_csr):
