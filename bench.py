@@ -86,6 +86,44 @@ def parse_args():
     return args
 
 
+def host_cpu_info():
+    """which CPU the single-threaded baseline ran on (core count AND model): /proc/cpuinfo model name, the
+    scaling governor, the CPU this thread is on right now and that CPU's clock, the number of NUMA nodes"""
+    info = {"cpu_model": None, "governor": None, "cpu_of_thread": None, "mhz": None, "numa_nodes": None}
+    try:
+        cpu = None
+        if hasattr(os, "sched_getcpu"):
+            cpu = os.sched_getcpu()
+        else:
+            with open("/proc/self/stat") as fh:
+                cpu = int(fh.read().rsplit(")", 1)[1].split()[36])
+        info["cpu_of_thread"] = cpu
+        cur, model, mhz = None, None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    cur = int(v)
+                elif k == "model name" and (model is None or cur == cpu):
+                    model = v
+                elif k == "cpu MHz" and cur == cpu:
+                    mhz = float(v)
+        info["cpu_model"], info["mhz"] = model, mhz
+    except Exception:  # noqa: BLE001  (a container without /proc/cpuinfo: the fields stay null)
+        pass
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{info['cpu_of_thread'] or 0}/cpufreq/scaling_governor") as fh:
+            info["governor"] = fh.read().strip()
+    except Exception:  # noqa: BLE001
+        info["governor"] = "unavailable"
+    try:
+        info["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except Exception:  # noqa: BLE001
+        pass
+    return info
+
+
 def _flush_c_stdio():
     import ctypes
     try:
@@ -560,6 +598,9 @@ def main():
         drain()
         barrier()
         elapsed = time.perf_counter() - t_start
+        # what the TIMED steps returned: the untimed extras below run step() again on other batches (step_512_acceptors) and
+        # must not change what the CPU leg's parity guards compare with
+        timed_last = {k: last[k] for k in ("sp", "outs", "n_arcs")}
         step_phases_us = None
         chain_us("after_timed_steps")
         if args.overlap and phases[4]:
@@ -750,6 +791,8 @@ def main():
                     with open(tp) as fh:
                         pmc = json.load(fh)
                     roofline["traffic"] = round(pmc["traffic_bytes_per_solve"] / max(1, st["relax_launches"]))
+                    roofline["traffic_unit"] = "bytes per launch (per solve / launches, like `achieved`'s algorithmic_bytes_per_launch)"
+                    roofline["traffic_bytes_per_solve"] = round(pmc["traffic_bytes_per_solve"])
                     roofline["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / algo_bytes, 2)
                     roofline["traffic_over_solve_algorithmic"] = round(pmc["traffic_bytes_per_solve"] / (20.0 * e_t + 12.0 * args.states), 2)
                     roofline["traffic_source"] = pmc["source"] + "; " + pmc["correction"]
@@ -825,8 +868,21 @@ def main():
             oa2 = [oracle_py.OracleFst.from_flat(*(a[k] for k in ("n_states", "start", "offsets", "arcs", "finals", "props"))) for a in config2["_a2"]]
             config2["cpu_ms"] = round(1e3 * min(oracle_py.compose_shortest_path_batch(oa2, ot2, n_threads=1)[2] for _ in range(10)), 4)
             config2["cpu_cores"] = 1
-        # parity spot-check of what was just timed (cheap): total weights agree
-        gw = last["sp"].to_flat()
+        host = host_cpu_info()
+        # parity guards of what was just timed.  (1) the composed arc count of the timed batch == the oracle's; (2) the paths
+        # of two of its acceptors, bit for bit, against the oracle's own compose (connect) -> canonical shortest path;
+        # (3) the total weight of shortest_path(T).  A guard that fails ends the run: a line must not carry a false one.
+        assert o_arcs == timed_last["n_arcs"], \
+            f"composed arcs of the timed batch ({timed_last['n_arcs']}) differ from the oracle's ({o_arcs})"
+        paths_checked = []
+        for i in sorted({0, len(oaccs) - 1}):
+            can = oaccs[i].compose(ot, connect=True).shortest_path_canonical().to_flat()
+            got = timed_last["outs"][i].to_flat()
+            same = (got["n_states"] == can["n_states"] and got["start"] == can["start"] and np.array_equal(got["offsets"], can["offsets"])
+                    and np.array_equal(got["arcs"], can["arcs"]) and np.array_equal(got["finals"].view(np.uint32), can["finals"].view(np.uint32)))
+            assert same, f"path of acceptor {i} of the timed batch differs from the oracle's"
+            paths_checked.append(int(mine[i]))
+        gw = timed_last["sp"].to_flat()
         gpu_total = float(np.float32(np.add.reduce(gw["arcs"]["weight"][::-1].astype(np.float32), dtype=np.float32) + gw["finals"][0])) if gw["n_states"] else float("inf")
         cpu_baseline = {
             "value": round(cpu_arcs / cpu_s, 1), "unit": "arcs/s", "cores": args.cpu_threads, "kind": "port",
@@ -836,7 +892,10 @@ def main():
             "seconds": round(cpu_s, 3), "steps": cpu_steps, "ms_shortest_path_T": round(1e3 * t_sp / cpu_steps, 2),
             "ms_batch": round(1e3 * t_batch / cpu_steps, 2), "queue_kind": osp.queue_kind,
             "shortest_path_T_weight_cpu": osp.total_weight, "shortest_path_T_weight_gpu": gpu_total,
-            "composed_arcs_match": bool(o_arcs == last["n_arcs"]),
+            "composed_arcs_match": bool(o_arcs == timed_last["n_arcs"]),
+            "paths_checked_bit_exact": paths_checked,
+            "cpu_model": host["cpu_model"], "cpu_governor": host["governor"], "cpu_of_thread": host["cpu_of_thread"],
+            "cpu_mhz_of_thread": host["mhz"], "numa_nodes": host["numa_nodes"],
             "all_cores": all_cores,
         }
 
@@ -884,7 +943,7 @@ def main():
             },
             "ms_shortest_path_T": round(ms_sp_t, 4), "ms_compose_shortest_path_batch": round(ms_batch, 4),
             "ms_per_compose_shortest_path": round(ms_batch / max(1, len(mine)), 5),
-            "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(last["n_arcs"]),
+            "relaxation_sweeps": int(sweeps), "composed_arcs_per_batch": int(timed_last["n_arcs"]),
             "setup_seconds": round(gen_s, 2), "priming_steps": 3,
             "cold_query_ms": None if cold is None else {
                 "first_in_process": cold[0], "second": cold[1], "third": cold[2], "fourth": cold[3],

@@ -30,19 +30,26 @@ def trace(path, alg_bytes=212e6):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{short(name)}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / 1e3 / a[0]:.2f} | {a[2] / 1e3:.2f} | "
               f"{a[3] / 1e3:.2f} | {100 * a[1] / tot:.1f} |")
-    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel"):
+    # the relaxation launches of a solve: time per kernel, and ONE roofline fraction over their SUM (20 E + 12 N bytes belong to
+    # the whole solve: dividing them by one kernel's share of the time means nothing)
+    n_solves = sum(1 for name, _, _ in rows if "setup_kernel" in name) or 1
+    chain = 0.0
+    for kname in ("sssp_relax_kernel", "sssp_mbox_kernel", "sssp_mbox_resident_kernel", "sssp_bin_expand_kernel", "sssp_bin_apply_kernel"):
         rel = [(e - s) for name, s, e in rows if kname + "(" in name or kname + "<" in name]
         if not rel:
             continue
-        n_solves = sum(1 for name, _, _ in rows if "setup_kernel" in name) or 1
         work = [d for d in rel if d >= 5500]  # launches after convergence inside a batch only find an empty frontier
         per_solve = sum(rel) / n_solves / 1e3
+        chain += per_solve
         print()
         print(f"{kname}: {len(rel)} launches in {n_solves} solves ({len(rel) / n_solves:.1f} per solve); "
               f"avg over all launches {sum(rel) / len(rel) / 1e3:.2f} us; "
               f"{len(work)} launches >= 5.5 us avg {sum(work) / max(1, len(work)) / 1e3:.2f} us; "
-              f"kernel time per solve {per_solve:.1f} us -> {alg_bytes / 1e6:.0f} MB (20 E + 12 N) / that = {alg_bytes / per_solve / 1e3:.1f} GB/s "
-              f"= {alg_bytes / per_solve / 1e3 / 8000:.4f} of the 8 TB/s peak")
+              f"kernel time per solve {per_solve:.1f} us")
+    if chain > 0:
+        print()
+        print(f"relaxation kernels per solve (sum of the above): {chain:.1f} us -> {alg_bytes / 1e6:.0f} MB (20 E + 12 N) / that = "
+              f"{alg_bytes / chain / 1e3:.1f} GB/s = {alg_bytes / chain / 1e3 / 8000:.4f} of the 8 TB/s peak")
 
 
 def pmc(fetch_db, write_db):
