@@ -1347,6 +1347,7 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     uint32_t log = 0;
     if (nb12 <= cus) log = 12;
     else if (nb13 <= cus && !std::getenv("WFST_SSSP_LOG12")) log = 13;
+    if (log == 12 && nb13 <= cus && std::getenv("WFST_SSSP_LOG13") && std::atoi(std::getenv("WFST_SSSP_LOG13")) != 0) log = 13;  // experiments: half the workgroups
     if (want && log && !ctx->profiling && ctx->resident_allowed() && !big_env && sv.lease.acquire(ctx->device)) {
       want_res = true;
       sv.log = log;
