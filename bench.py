@@ -383,8 +383,12 @@ def main():
             flats = [t] + synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
             if not args.no_extras:  # (before T leaves rank 0: their end states are final states of T everywhere)
                 sweep_accs = synth.make_acceptors(t, SWEEP_MAX, args.acc_len, seed0=50_000)
+            if not args.no_extras:  # (every rank takes its share of them in the multi-GPU extras: batch_strong / batch_weak_4096)
+                flats = flats + sweep_accs
         flats = wdist.broadcast_flat_fsts(flats, 0, device)
-        t, accs_all = flats[0], flats[1:]
+        t, accs_all = flats[0], flats[1:1 + n_total]
+        if not args.no_extras:
+            sweep_accs = flats[1 + n_total:]
     else:
         t = synth.make_transducer(args.states, args.fanout, args.sigma, 0.0, seed=3)
         accs_all = synth.make_acceptors(t, n_total, args.acc_len, seed0=1000)
@@ -507,6 +511,8 @@ def main():
             comm.gather_paths_begin(outs, args.acc_len + 8)
             last["pending"] = True
 
+    exchange_on = [True]  # (the multi-GPU extras time the same steps without the result exchange: what it costs per step)
+
     def step():
         if not args.overlap:
             sp = dt.shortest_path()
@@ -528,18 +534,18 @@ def main():
                 p1 = time.perf_counter()
                 job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt2, ctx=ctx2)
             p2 = time.perf_counter()
-            if (world > 1 or force_dist) and last.get("to_send") is not None:
+            if (world > 1 or force_dist) and exchange_on[0] and last.get("to_send") is not None:
                 exchange(last["to_send"])  # the previous step's results (both requests of this step are running)
                 last["to_send"] = None
             outs, n_arcs = job.finish()
             p3 = time.perf_counter()
-            if world > 1 or force_dist:
+            if (world > 1 or force_dist) and exchange_on[0]:
                 last["to_send"] = outs
             sp = sp_job.finish()
             p4 = time.perf_counter()
             phases[:] = [phases[0] + p1 - p0, phases[1] + p2 - p1, phases[2] + p3 - p2, phases[3] + p4 - p3, phases[4] + 1]
         last["sp"], last["outs"], last["n_arcs"] = sp, outs, n_arcs
-        if (world > 1 or force_dist) and not args.overlap:
+        if (world > 1 or force_dist) and not args.overlap and exchange_on[0]:
             exchange(outs)
         batch_arcs[0] += 2 * n_arcs
         return e_t + 2 * n_arcs
@@ -616,6 +622,77 @@ def main():
             ta = torch.tensor([arcs, batch_arcs[0]], dtype=torch.int64, device=device)
             dist.all_reduce(ta, op=dist.ReduceOp.SUM)
             arcs, batch_arcs[0] = int(ta[0].item()), int(ta[1].item())
+
+        # ------------------------------------------------------------------ multi-GPU extras (untimed; every rank takes part)
+        # What the headline cannot show at N > 1 (`value` holds N replicated shortest_path(T) queries and a weak-scaled batch):
+        #  * exchange_exposed: the same overlapped steps with and without the result all-gather — what the exchange costs a step;
+        #  * batch_strong: configs[3] AS WRITTEN — its 512 acceptors split N ways (i mod N), fused batch only, results
+        #    all-gathered — against the 512 on ONE GPU (rank 0's batch_sweep[512], same run): the strong-scaling figure;
+        #  * batch_weak_4096: 4096 acceptors PER GPU (every rank the same 4096: throughput only), where the batch kernel has
+        #    enough waves in flight for the per-acceptor time to be flat (0.23 us): the weak-scaling figure of the sharded leg.
+        dist_extras = None
+        if (world > 1 or force_dist) and not args.no_extras and args.overlap:
+            import torch.distributed as dist
+
+            def timed_all(fn, reps):
+                """max over ranks of the host clock around `reps` calls of fn, between two barriers"""
+                barrier()
+                c0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                drain_local()
+                barrier()
+                tt_ = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                return float(tt_.item()) / reps
+
+            def drain_local():
+                if exchange_on[0]:
+                    drain()
+            n_x = 200
+            for _ in range(10):
+                step()
+            s_with = timed_all(step, n_x)
+            exchange_on[0] = False
+            for _ in range(10):
+                step()
+            s_without = timed_all(step, n_x)
+            exchange_on[0] = True
+            # strong: the 512 split N ways, records gathered (packed form: what a decoder reads), no S1 beside it
+            idx512 = wdist.shard_indices(512, rank, world)
+            d512 = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([sweep_accs[i] for i in idx512], ctx2))
+            tab = [None]
+
+            def strong():
+                tab[0], _ = rustfst_amd.compose_shortest_path_batch_packed(d512, dt2, args.acc_len + 8, ctx=ctx2, out=tab[0])
+                comm.gather_records_begin(tab[0], args.acc_len + 8)
+                comm.gather_paths_end()
+            for _ in range(5):
+                strong()
+            s_strong = timed_all(strong, 50)
+            d4096 = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(sweep_accs[:SWEEP_MAX], ctx2))
+            tab4 = [None]
+
+            def weak():
+                tab4[0], _ = rustfst_amd.compose_shortest_path_batch_packed(d4096, dt2, args.acc_len + 8, ctx=ctx2, out=tab4[0])
+            for _ in range(3):
+                weak()
+            s_weak = timed_all(weak, 20)
+            dist_extras = {
+                "value_note": f"`value` = {world} replicated shortest_path(T) queries (one per rank, distinct sources) + the weak-scaled "
+                              f"batch ({args.batch_per_gpu} acceptors per GPU): it scales with N by construction; the figures below are "
+                              "the ones that can fail to",
+                "exchange_exposed": {"ms_per_step_with_exchange": round(1e3 * s_with, 4), "ms_per_step_without": round(1e3 * s_without, 4),
+                                     "exposed_us_per_step": round(1e6 * (s_with - s_without), 2), "steps_each": n_x},
+                "batch_strong": {"workload": "configs[3] as written: 512 acceptors split over the ranks (i mod N), fused compose->shortest_path, "
+                                             "records all-gathered every call; no shortest_path(T) beside it",
+                                 "acceptors_per_rank": len(idx512), "ms": round(1e3 * s_strong, 4),
+                                 "acceptors_per_s": round(512 / s_strong, 1)},
+                "batch_weak_4096": {"workload": f"{SWEEP_MAX} acceptors per GPU (every rank the same {SWEEP_MAX}: throughput only), records, no exchange",
+                                    "ms": round(1e3 * s_weak, 4), "us_per_acceptor": round(1e6 * s_weak / SWEEP_MAX, 4),
+                                    "acceptors_per_s_all_ranks": round(world * SWEEP_MAX / s_weak, 1)},
+            }
+            del d512, d4096
 
         # ------------------------------------------------------------------ per-part times (untimed extra pass)
         # each request ALONE on its own context, host clock around the synchronous call (3 repetitions, best)
@@ -917,6 +994,13 @@ def main():
                     "of a step is one single-source query per rank (rank r: start state (start + 104729 r) mod N): distinct work, "
                     "counted in `value`, not in these",
         }
+        if dist_extras is not None and batch_sweep is not None:
+            one = next((pt for pt in batch_sweep["points"] if pt["batch"] == 512), None)
+            if one is not None:
+                dist_extras["batch_strong"]["one_gpu_ms"] = one["packed_ms"]
+                dist_extras["batch_strong"]["speedup_vs_one_gpu"] = round(one["packed_ms"] / dist_extras["batch_strong"]["ms"], 3)
+                dist_extras["batch_strong"]["note"] = ("one_gpu_ms = rank 0's batch_sweep[512].packed_ms of this run (no exchange); "
+                                                       "the batch kernel is latency-bound at one wave per acceptor, so N GPUs buy less than N")
         ms = 1e3 * step_s
         out = {
             "metric": "arcs relaxed/sec (compose -> shortest_path, 1M-state / 10M-arc FST)",
@@ -927,7 +1011,7 @@ def main():
                                   "timed_seconds": round(elapsed, 3), "clock": "host perf_counter per step on rank 0"},
             "step_host_phases_us": step_phases_us,
             "rccl_world_size": rccl_world, "rccl_used": bool(world > 1 or force_dist), "gather_check": gather_check,
-            "batch_only": batch_only,
+            "batch_only": batch_only, "multi_gpu": dist_extras,
             "s1_start_states": "T's own" if world == 1 else f"rank r: ({int(t['start'])} + 104729 r) mod {int(t['n_states'])}",
             "step_schedule": "serial (one stream)" if (not args.overlap) else ("S1 (shortest_path(T)) enqueued async on stream 1, then the S2 batch on stream 2" if args.order == "s1-first" else "S2 batch enqueued async on stream 2, then S1 on stream 1") + ", S2 collected, S1 collected (two contexts, one host thread); "
                              + (f"batch context on {args.batch_cus} reserved CUs" if args.batch_cus > 0 else "no CU partitioning"),

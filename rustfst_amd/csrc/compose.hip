@@ -1465,7 +1465,9 @@ void launch_end(wfst_ctx* ctx, BatchRun& run) {
     }
   }
   if (!seen) HIP_CHECK(hipStreamSynchronize(st));
-  else HIP_CHECK(hipGetLastError());  // (no stream wait on this path: a fault of the chain is still reported here)
+  else HIP_CHECK(hipPeekAtLastError());  // (no stream wait on this path.  Reports launch-configuration / sticky API errors the runtime has already
+                                              // seen — NOT an asynchronous kernel fault: a chain that faults never writes its ticket, and the spin above then
+                                              // ends in the stream wait, which reports it.  Peek, not Get: the error may belong to another thread's launch)
   if (ctx->profiling) {
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

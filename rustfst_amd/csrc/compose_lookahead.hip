@@ -581,18 +581,33 @@ wfst_fst* compose_lookahead_wide(wfst_ctx* ctx, const wfst_lookahead* la, const 
   const LaPolicy pol{view_of(f1), view_of(fst2), Reach{la->d_iv_off->p, la->d_iv->p, la->data.final_label}};
   WideOutput w;
   const double d1 = (double)f1->n_arcs / std::max<uint32_t>(f1->n_states, 1), d2 = (double)fst2->n_arcs / std::max<uint32_t>(fst2->n_states, 1);
-  // (a serving loop composes many inputs of one kind against the operand: the last result sizes the arena, + 1/8)
+  // A serving loop composes many inputs of one kind against the operand: the last result sizes the arena, + 1/8.  The hint
+  // is best effort: it only applies to an input of about the size of the one it came from (within a factor of two in
+  // arcs — one 90M-state result must not make every later small composition ask for gigabytes), and when the pool cannot
+  // supply the hinted arena the composition runs from the unhinted estimate instead of failing.
+  const uint64_t est_s0 = est_s, est_a0 = est_a;
+  bool hinted = false;
   if (!std::getenv("WFST_WIDE_EST_STATES")) {
     const uint64_t ls = la->last_wide_states.load(std::memory_order_relaxed), lw = la->last_wide_arcs.load(std::memory_order_relaxed);
-    if (ls + ls / 8 + 1024 < 0x7FFFFFF0ull && lw + lw / 4 + 65536 < 0x7FFFFFF0ull) {
+    const uint64_t li = la->last_wide_input_arcs.load(std::memory_order_relaxed), in = fst2->n_arcs;
+    if (ls != 0 && in <= 2 * li + 16 && li <= 2 * in + 16 && ls + ls / 8 + 1024 < 0x7FFFFFF0ull && lw + lw / 4 + 65536 < 0x7FFFFFF0ull) {
       est_s = std::max<uint64_t>(est_s, ls + ls / 8 + 1024);
       est_a = std::max<uint64_t>(est_a, lw + lw / 4 + 65536);  // (the arc arena is cut into 64 slices: room for their skew)
+      hinted = est_s != est_s0 || est_a != est_a0;
     }
   }
-  run_wide(ctx, pol, ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)fst2->start, pack_hi(FState{0u, 0.0f, NO_LABEL}), est_s,
-           est_a, 1.0 + std::min(d1, d2), w);
+  const uint64_t t0 = ((uint64_t)(uint32_t)f1->start << 32) | (uint32_t)fst2->start;
+  try {
+    run_wide(ctx, pol, t0, pack_hi(FState{0u, 0.0f, NO_LABEL}), est_s, est_a, 1.0 + std::min(d1, d2), w);
+  } catch (const Error&) {
+    if (!hinted) throw;
+    (void)hipGetLastError();  // (a refused allocation must not surface at the next launch check)
+    w = WideOutput{};
+    run_wide(ctx, pol, t0, pack_hi(FState{0u, 0.0f, NO_LABEL}), est_s0, est_a0, 1.0 + std::min(d1, d2), w);
+  }
   la->last_wide_states.store(w.n_states, std::memory_order_relaxed);
   la->last_wide_arcs.store(w.n_arcs, std::memory_order_relaxed);
+  la->last_wide_input_arcs.store(fst2->n_arcs, std::memory_order_relaxed);
   ctx->stats.compose_states = w.n_states;
   ctx->stats.compose_arcs = w.n_arcs;
   return adopt_device(ctx, w.n_states, w.n_arcs, 0, out_props, w.off, w.arcs, w.fin);

@@ -49,7 +49,7 @@ struct wfst_lookahead {
   std::unique_ptr<wfst::DBuf<uint32_t>> d_iv_off, d_iv;
   // what the last composition on the wide driver came to (states, arcs before the gather): the next one against this
   // operand starts with an arena of that size instead of growing into it (eight growths, a quarter of a 90 M-state run)
-  mutable std::atomic<uint64_t> last_wide_states{0}, last_wide_arcs{0};
+  mutable std::atomic<uint64_t> last_wide_states{0}, last_wide_arcs{0}, last_wide_input_arcs{0};  // arena hint of the wide driver (best effort)
   ~wfst_lookahead();
 };
 

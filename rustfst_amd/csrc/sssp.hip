@@ -13,6 +13,10 @@
 // No MFMA: this is sparse DP; the bound is HBM / L2-atomic traffic (20 B per arc relaxed by the
 // SURVEY §8(d) accounting; this layout actually streams 8 B of arc + one 8-B atomic).
 #include <cstdlib>
+#include <cerrno>
+#include <cstdio>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <cstddef>
 #include <chrono>
 #include <cstring>
@@ -1043,21 +1047,41 @@ struct ResidentLease {
   ResidentLease() = default;
   ResidentLease(const ResidentLease&) = delete;
   ResidentLease& operator=(const ResidentLease&) = delete;
-  static int device_lock_fd(int device) {  // one descriptor per device and process, opened once (-1: no lock file, in-process lease only)
-    static std::atomic<int> fds[64];
-    static std::once_flag once[64];
+  // One descriptor per device and process (-1: no lock file, in-process lease only).  Opened read-only (flock works on a
+  // read-only descriptor, so a file another user created is still lockable), never through a symbolic link, made world-readable
+  // by whoever creates it whatever the umask; reopened after a fork (a child shares its parent's open file description, and
+  // flock locks belong to the description: parent and child would both "hold" it).  Without a lock file two processes can
+  // both start resident grids; the launch's wait limit is what then protects them, and that is said once on stderr.
+  static int device_lock_fd(int device) {
+    struct Slot { std::mutex mu; int fd = -1; pid_t pid = 0; bool tried = false; };
+    static Slot slots[64];
     const unsigned d = (unsigned)device & 63u;
-    std::call_once(once[d], [d] {
-      int fd = -1;
-      if (!std::getenv("WFST_SSSP_NO_LOCKFILE")) {
-        const char* dir = std::getenv("WFST_LOCK_DIR");
-        char path[512];
-        std::snprintf(path, sizeof(path), "%s/.wfst_amd_resident_gpu%u.lock", dir ? dir : "/tmp", d);
-        fd = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-      }
-      fds[d].store(fd);
-    });
-    return fds[d].load();
+    Slot& sl = slots[d];
+    std::lock_guard<std::mutex> lk(sl.mu);
+    const pid_t me = ::getpid();
+    if (sl.tried && sl.pid == me) return sl.fd;
+    if (sl.tried && sl.fd >= 0) ::close(sl.fd);  // (the parent's description)
+    sl.tried = true;
+    sl.pid = me;
+    sl.fd = -1;
+    if (std::getenv("WFST_SSSP_NO_LOCKFILE")) return -1;
+    const char* dir = std::getenv("WFST_LOCK_DIR");
+    char path[512];
+    std::snprintf(path, sizeof(path), "%s/.wfst_amd_resident_gpu%u.lock", dir ? dir : "/tmp", d);
+    int fd = ::open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0 && errno == ENOENT) {
+      fd = ::open(path, O_CREAT | O_EXCL | O_RDONLY | O_NOFOLLOW | O_CLOEXEC, 0644);
+      if (fd >= 0) (void)::fchmod(fd, 0644);
+      else if (errno == EEXIST) fd = ::open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);  // (somebody else created it meanwhile)
+    }
+    if (fd < 0) {
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true))
+        std::fprintf(stderr, "libwfst_amd: no per-device lock file (%s: %s); resident launches of several processes on one GPU are only "
+                             "protected by their wait limit (WFST_LOCK_DIR selects another directory)\n", path, std::strerror(errno));
+    }
+    sl.fd = fd;
+    return fd;
   }
   bool acquire(int device) {
     static std::atomic<int> busy[64];
@@ -2218,7 +2242,9 @@ wfst_fst* shortest_path_n1_end(wfst_sp_job* job) {
   if (!j->tail_queued) queue_tail(j.get());
   // (the ticket of the fused tail was the last thing this job had on the stream: nothing to wait for)
   if (!(j->tail_queued && j->fused_tail && j->drv.done_seen && !j->drv.extended) || ctx->chain_timing) HIP_CHECK(hipStreamSynchronize(st));
-  else HIP_CHECK(hipGetLastError());  // (no stream wait on this path: a fault of the chain is still reported here)
+  else HIP_CHECK(hipPeekAtLastError());  // (no stream wait on this path.  Reports launch-configuration / sticky API errors the runtime has already
+                                              // seen — NOT an asynchronous kernel fault: a chain that faults never writes its ticket, and the spin above then
+                                              // ends in the stream wait, which reports it.  Peek, not Get: the error may belong to another thread's launch)
   if (ctx->chain_timing && !ctx->profiling) {  // the sweeps of this query as one chain (wfst_ctx_set_profiling(ctx, 2))
     ctx->stats.relax_ms = 0.0;
     ctx->stats.relax_launches = 0;

@@ -84,71 +84,114 @@ constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
          (size_t)nb * stg * 8 + 3 * (size_t)nb * 4;
 }
 
-// One round of a level's expansion: 16 lanes per listed state, U states per 16-lane group (U = 1, 2, 4, 8 by the length
-// of the level's list: a thin level runs the short instances).  No arrays of flags, no branch around a load, one LDS
-// read per state for the row's bounds: the body is a third of the instructions of sssp_mbox_kernel's.  Candidate per
-// arc -> LDS (a state of the same block: its key is lowered at once and it waits for the next level) or the destination's
-// staging slots.  l_cur[d] counts the round's messages for destination d; one that finds the slots full is stored directly at
-// its place in the region.  Returns nonzero if this lane sent anything.
+// One round of a level's expansion: 16 lanes per listed state, U states per 16-lane group (U = 1, 2, 4, 6 by the length of the
+// level's list: a thin level runs the short instances).  No arrays of flags, no branch around a load (a lane without an arc
+// reads arc 0 and drops it — its row's last arc instead, a line the neighbours fetch anyway, was measured 10 us per solve
+// slower), one LDS read per state for the row's bounds.  What a lane keeps per state while its U loads are in flight is the
+// arc, the distance and the hop word: whether it has an arc at all is one bit of a mask, the row's bounds are not kept (a row
+// of more than 16 arcs — none in a fan-out-10 transducer — is finished afterwards, one state at a time, from the bounds in
+// LDS), and the candidates are worked off WFST_RS_BATCH at a time (their LDS atomics issued together), so that only that
+// many slot numbers and encoded distances are alive at once.  The first version (bounds, encoded distance and slot number
+// of all U states alive across the round) spilled from U = 6 on and was 2.5 % (1M states) / 3.8 % (2M) slower at its best
+// U = 5 (profiles/r06c_expand_round.md: U x batch table, same box).  Candidate per arc -> LDS (a state of the same block:
+// its key is lowered at once and it waits for the next level) or the destination's staging slots.  l_cur[d] counts the
+// round's messages for destination d; one that finds the slots full is stored directly at its place in the region.
+// Returns nonzero if this lane sent anything.
 template <uint32_t LOG, uint32_t U>
 __device__ __forceinline__ uint32_t rs_expand_round(uint32_t r0, uint32_t an, uint32_t grp, uint32_t sub, const uint2* __restrict__ wn,
                                                     const uint16_t* a_state, unsigned long long* lkey, uint32_t* l_pend, const uint32_t* l_off,
                                                     uint32_t j, uint32_t* l_cur, const uint32_t* l_base, uint2* l_stage, uint32_t stg,
                                                     const uint32_t* l_roff_out, unsigned long long* __restrict__ msgs_out,
                                                     uint32_t* __restrict__ pad) {
-  constexpr uint32_t B = 1u << LOG, HOP_BITS = 32 - LOG, G = MB_THREADS / 16;
+  constexpr uint32_t HOP_BITS = 32 - LOG, G = MB_THREADS / 16;
   if (!__any(r0 + grp < an)) return 0u;  // (a lane's first state is its lowest: none there, none at all)
-  uint32_t tl[U];
+  uint2 a[U];
+  float d[U];
+  uint32_t hs[U], vmask = 0, lmask = 0, ovf = 0;
   for (uint32_t u = 0; u < U; ++u) {
     const uint32_t e = r0 + grp + G * u;
-    tl[u] = a_state[e < an ? e : r0];
-  }
-  uint32_t i[U], end[U], hs[U], ovf = 0;
-  float d[U];
-  for (uint32_t u = 0; u < U; ++u) {
-    const bool has = r0 + grp + G * u < an;
-    const unsigned long long k = lkey[tl[u]];
-    const uint32_t b = l_off[tl[u]], en = l_off[tl[u] + 1];
+    const bool has = e < an;
+    const uint32_t tl = a_state[has ? e : r0];
+    const unsigned long long k = lkey[tl];
+    const uint32_t b = l_off[tl], en = l_off[tl + 1];
     const uint32_t h1 = (uint32_t)k + 1u;
     d[u] = dec_f32((uint32_t)(k >> 32));
     hs[u] = h1 << LOG;
-    i[u] = has ? b + sub : 0u;
-    end[u] = has ? en : 0u;
-    ovf |= has && i[u] < end[u] ? h1 >> HOP_BITS : 0u;
+    const bool valid = has && b + sub < en;
+    vmask |= (valid ? 1u : 0u) << u;
+    lmask |= (has && en - b > 16u ? 1u : 0u) << u;
+    ovf |= valid ? h1 >> HOP_BITS : 0u;
+    a[u] = wn[valid ? b + sub : 0u];
   }
   if (ovf) *pad = 1u;  // hop count beyond the message format: the host refuses the result
-  uint2 a[U];
-  // (a lane without an arc reads arc 0 and drops it.  Its row's last arc instead — a line the neighbours fetch anyway — was
-  // measured 10 us per solve slower.)
-  for (uint32_t u = 0; u < U; ++u) a[u] = wn[i[u] < end[u] ? i[u] : 0u];
   uint32_t sent = 0;
-  for (;;) {
-    uint32_t enc[U], slot[U];
-    for (uint32_t u = 0; u < U; ++u) {
-      const float c = (d[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-      enc[u] = enc_f32(c);
-      slot[u] = 0xFFFFFFFFu;
-      if (i[u] < end[u] && c < INF && (a[u].y >> LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
-        const uint32_t tl_ = a[u].y & (B - 1u);
-        const unsigned long long c_ = ((unsigned long long)enc[u] << 32) | (hs[u] >> LOG);
-        if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
-      } else
-      if (i[u] < end[u] && c < INF) slot[u] = atomicAdd(&l_cur[a[u].y >> LOG], 1u);  // +inf never improves (shortest_path.rs:226)
+  // the candidates, in two halves (only H slot numbers and encoded distances alive at once); inside a half the LDS atomics
+  // are issued together and waited for once
+#ifndef WFST_RS_BATCH
+#define WFST_RS_BATCH 2
+#endif
+  constexpr uint32_t B = 1u << LOG, H = U < WFST_RS_BATCH ? U : WFST_RS_BATCH;
+  for (uint32_t u0 = 0; u0 < U; u0 += H) {
+    uint32_t enc[H], slot[H];
+    for (uint32_t h = 0; h < H; ++h) {
+      const uint32_t u = u0 + h;
+      slot[h] = 0xFFFFFFFFu;
+      enc[h] = 0;
+      if (u < U) {
+        const float c = (d[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+        enc[h] = enc_f32(c);
+        const bool valid = ((vmask >> u) & 1u) != 0u && c < INF;   // +inf never improves (shortest_path.rs:226)
+        if (valid && (a[u].y >> LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
+          const uint32_t tl_ = a[u].y & (B - 1u);
+          const unsigned long long c_ = ((unsigned long long)enc[h] << 32) | (hs[u] >> LOG);
+          if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
+        } else if (valid) {
+          slot[h] = atomicAdd(&l_cur[a[u].y >> LOG], 1u);
+        }
+      }
     }
-    uint32_t more = 0;
-    for (uint32_t u = 0; u < U; ++u) {
-      const uint32_t db = a[u].y >> LOG;
-      const uint2 msg = make_uint2(hs[u] | (a[u].y & (B - 1u)), enc[u]);
-      if (slot[u] < stg) l_stage[db * stg + slot[u]] = msg;
-      else if (slot[u] != 0xFFFFFFFFu)
-        __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + slot[u]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      sent |= ~slot[u];
-      i[u] += 16;
-      more |= i[u] < end[u] ? 1u : 0u;
+    for (uint32_t h = 0; h < H; ++h) {
+      const uint32_t u = u0 + h;
+      if (u < U) {
+        const uint32_t db = a[u].y >> LOG;
+        const uint2 msg = make_uint2(hs[u] | (a[u].y & (B - 1u)), enc[h]);
+        if (slot[h] < stg) l_stage[db * stg + slot[h]] = msg;
+        else if (slot[h] != 0xFFFFFFFFu)
+          __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + slot[h]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        sent |= ~slot[h];
+      }
     }
-    if (!__any(more)) break;
-    for (uint32_t u = 0; u < U; ++u) a[u] = wn[i[u] < end[u] ? i[u] : 0u];
+  }
+  // rows of more than 16 arcs: the rest of each, state by state (uniform per 16-lane group; the wave stays together)
+  if (__any(lmask != 0u)) {
+    for (uint32_t u = 0; u < U; ++u) {
+      if (!__any(((lmask >> u) & 1u) != 0u)) continue;
+      const bool lng = ((lmask >> u) & 1u) != 0u;
+      const uint32_t e = r0 + grp + G * u;
+      const uint32_t tl = a_state[lng ? e : r0];
+      const uint32_t en = lng ? l_off[tl + 1] : 0u;
+      uint32_t i = lng ? l_off[tl] + 16u + sub : 0u;
+      while (__any(i < en)) {
+        const uint2 ar = wn[i < en ? i : 0u];
+        const float c = (d[u] + __uint_as_float(ar.x)) + 0.0f;
+        if (i < en && c < INF) {
+          const uint32_t enc1 = enc_f32(c), db = ar.y >> LOG, tl_ = ar.y & (B - 1u);
+          if (db == j) {
+            const unsigned long long c_ = ((unsigned long long)enc1 << 32) | (hs[u] >> LOG);
+            if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
+          } else {
+            const uint32_t sl = atomicAdd(&l_cur[db], 1u);
+            const uint2 msg = make_uint2(hs[u] | tl_, enc1);
+            if (sl < stg) l_stage[db * stg + sl] = msg;
+            else __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + sl], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+            sent |= 1u;
+          }
+        }
+        i += 16u;
+      }
+    }
   }
   return sent;
 }
@@ -454,11 +497,12 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       unsigned long long* __restrict__ msgs_out = (unsigned long long*)rv.msgs[ps ^ 1u];
       const __amdgpu_buffer_rsrc_t rs_out = ps ? rs0 : rs1;
 #ifndef WFST_RS_UMAX
-#define WFST_RS_UMAX 5
+#define WFST_RS_UMAX 6
 #endif
       constexpr uint32_t G = MB_THREADS / 16, UMAX = WFST_RS_UMAX, ROUND = G * UMAX;  // (UMAX: states a 16-lane group relaxes at once in a wide level)
       static_assert(MB_THREADS == 1024, "a resident workgroup is sixteen waves");
       static_assert(UMAX >= 4u && UMAX <= 8u, "the one-round ladder below is 1 / 2 / 4 / UMAX states per group");
+      static_assert(UMAX <= 32u, "one bit per state in the masks of rs_expand_round");
       const uint32_t an_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)an);
       uint32_t sent = 0;
 #define RS_EXPAND(U_, r0_) rs_expand_round<LOG, U_>(r0_, an_u, grp, sub, wn, a_state, lkey, l_pend, l_off, j, l_cur, l_base, l_stage, stg, l_roff_out, msgs_out, &ctl->pad)

@@ -463,10 +463,11 @@ def test_config5_lookahead_full_size_sample_vs_oracle(oracle):
     output epsilons) as the look-ahead operand, two of the 200-label acceptors — the look-ahead composition (label
     reachability over 5M states, relabelling, the filter stack) bit-identical to the oracle's: states, arc order, labels,
     weight bits, finals; and the n = 10 shortest paths of the first result identical to the oracle's on ITS result.  (The
-    oracle redoes MatcherFst::new per composition, as rustfst-cli does: ~9 s each on one core.)"""
+    oracle redoes MatcherFst::new per composition, as rustfst-cli does: ~9 s each on one core.)  WFST_TEST_CONFIG5_SAMPLE=k
+    takes k acceptors of the batch instead of 2 (the long run: 8 of 64 is ~80 s of oracle time)."""
     n = 5_000_000
     t = synth.make_transducer(n, 10, 256, 0.05, seed=9)
-    accs = synth.make_acceptors(t, 2, 200, seed0=77)
+    accs = synth.make_acceptors(t, max(2, min(64, int(os.environ.get("WFST_TEST_CONFIG5_SAMPLE", "2")))), 200, seed0=77)
     arcs = t["arcs"].copy()
     arcs["ilabel"], arcs["olabel"] = t["arcs"]["olabel"].copy(), t["arcs"]["ilabel"].copy()
     t1 = dict(t, arcs=arcs, props=synth.O_LABEL_SORTED)
@@ -571,6 +572,72 @@ def test_mailbox_sweeps_do_not_change_results(oracle, monkeypatch, mailbox, delt
         f = random_fst_flat(rng, int(rng.integers(2, 300)), 5, 3, p_eps_i=0.1, p_eps_o=0.1, p_final=0.2, weight_grid=1, max_w=4)
         ref = to_oracle(oracle, f).shortest_path_canonical().to_flat()
         assert_flat_identical(to_device(f, ctx).shortest_path().to_flat(), ref, f"mailbox small {k}")
+
+
+def _reweighted(t, family, seed):
+    """T with its arc weights replaced by an arbitrary-f32 family (the fixtures and benchmarks all use k/512: there the exact ==
+    of this engine and the reference's approximate one cannot differ, and neither can an ordering bug of the encoded keys hide)"""
+    rng = np.random.default_rng(seed)
+    t = dict(t)
+    arcs = t["arcs"].copy()
+    e = arcs.shape[0]
+    if family == "uniform_1e-3":
+        w = rng.random(e, dtype=np.float32) * np.float32(1e-3)
+    elif family == "lognormal_12_decades":
+        w = np.power(10.0, rng.uniform(-6.0, 6.0, e)).astype(np.float32)
+    elif family == "subnormal":  # k x 2^-149, and a few ordinary tiny values among them: sums cross the subnormal boundary
+        w = (rng.integers(0, 1 << 22, e).astype(np.uint32)).view(np.float32).copy()
+        pick = rng.random(e) < 0.05
+        w[pick] = (rng.random(int(pick.sum()), dtype=np.float32) * np.float32(1e-37)).astype(np.float32)
+    elif family == "huge":  # sums overflow to +inf (which never improves, shortest_path.rs:226) on most two-arc paths
+        w = (rng.random(e, dtype=np.float32) * np.float32(3.0e38)).astype(np.float32)
+        w[rng.random(e) < 0.3] = np.float32(1.0)
+    elif family == "negative_dag":  # arcs forward only (window 40 000 states: crosses blocks), weights in [-5, 5)
+        n = t["n_states"]
+        src = np.repeat(np.arange(n, dtype=np.int64), np.diff(t["offsets"].astype(np.int64)))
+        room = np.maximum(1, np.minimum(40_000, n - 1 - src))
+        ns = src + 1 + (arcs["nextstate"].astype(np.int64) % room)
+        keep = src < n - 1
+        arcs, src, ns = arcs[keep], src[keep], ns[keep]
+        arcs["nextstate"] = ns.astype(np.uint32)
+        t["offsets"] = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))]).astype(np.uint32)
+        w = (rng.random(arcs.shape[0], dtype=np.float32) * np.float32(10.0) - np.float32(5.0)).astype(np.float32)
+        t["props"] = int(synth.I_LABEL_SORTED | synth.ACYCLIC | synth.INITIAL_ACYCLIC | synth.TOP_SORTED)
+        t["finals"] = t["finals"].copy()
+        t["finals"][n - 1] = np.float32(0.25)
+    else:
+        raise ValueError(family)
+    arcs["weight"] = w
+    t["arcs"] = arcs
+    return t
+
+
+@pytest.mark.parametrize("kernel", ["resident", "mailbox_one_level", "atomic"])
+@pytest.mark.parametrize("family", ["uniform_1e-3", "lognormal_12_decades", "subnormal", "huge", "negative_dag"])
+def test_arbitrary_f32_weights_bit_exact_vs_canonical_oracle(oracle, monkeypatch, family, kernel):
+    """Distances, hop counts and the path on weights that are NOT on a coarse grid — uniform [0, 1e-3), twelve decades,
+    subnormals, values whose sums overflow, negative weights on a DAG — bit-identical to the canonical oracle (the exact (min,+)
+    fixed point of left-folded f32 sums) under the resident launches, the one-level mailbox launches and the atomic
+    sweeps (negative weights always take the atomic sweeps).  What this pins: the order-preserving u32 encoding of f32 distances
+    inside the 64-bit keys (enc_f32 / dec_f32, incl. negative values and subnormals), `+ 0.0f` normalisation, +inf candidates
+    dropped, and that no kernel flushes subnormals.  semirings/semiring.rs:159-168 is the reference's approximate compare this
+    engine does not use."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "0" if kernel == "atomic" else "1")
+    if kernel == "mailbox_one_level":
+        monkeypatch.setenv("WFST_SSSP_RESIDENT", "0")
+    ctx = rustfst_amd.Context(0)
+    t = _reweighted(synth.make_transducer(150_000, 8, 64, 0.0, seed=11), family, seed=5)
+    d = to_device(t, ctx)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    assert np.isfinite(can.distance).sum() > 1000  # (the search is not trivial under any family)
+    for q in range(2):
+        dist, hops = d.shortest_distance(want_hops=True)
+        if family != "negative_dag":
+            assert ctx.stats()["relax_kernel"] == {"atomic": 0, "mailbox_one_level": 1, "resident": 2}[kernel]
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"{family}, {kernel}, query {q}")
+    assert ctx.stats()["resident_aborts"] == 0
 
 
 @pytest.mark.parametrize("narrow", [None, "0", "1000000000"])

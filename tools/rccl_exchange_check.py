@@ -81,6 +81,38 @@ blobs = [o.to_bytes() for o in outs[:1 + rank % 3]]
 a, b = comm.gather_fsts(blobs), hcomm.gather_fsts(blobs)
 ok &= a == b and a[rank] == blobs and len(a) == world
 ok &= comm.gather_fsts([] if rank == 0 else [b"x" * 9]) == [[]] + [[b"x" * 9] for _ in range(world - 1)]
+# 4. the bench's overlapped step under world = N: shortest_path(T) from this rank's own start state on one context, the fused
+#    batch of this rank's shard on a second one, the previous step's results all-gathered over RCCL meanwhile (queued behind
+#    what the first context holds: wfst_comm_order_after) — three steps in a row; what every exchange delivers must be the
+#    host transport's and the one-GPU run's records, and the solve beside it must not change (its path is compared with a
+#    solve that ran alone)
+ctx2 = rustfst_amd.Context(local)
+daccs2 = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([accs[i] for i in mine], ctx2))
+s1 = int((int(t["start"]) + rank * 104729) % int(t["n_states"]))
+dts = rustfst_amd.DeviceFst.from_arrays(t["n_states"], s1, t["offsets"], t["arcs"], t["finals"], t["props"], ctx)
+alone = dts.shortest_path().to_flat()
+pending, prev_outs = False, None
+for it in range(4):
+    sp_job = dts.shortest_path_begin()
+    job = rustfst_amd.compose_shortest_path_batch_begin(daccs2, dt, ctx=ctx2)
+    if prev_outs is not None:
+        if pending:
+            g = comm.gather_paths_end()
+            pending = False
+            ok &= np.array_equal(g, g_rccl)
+        comm.order_after(ctx)
+        if len(prev_outs) == n_local:
+            comm.gather_paths_begin(prev_outs, max_arcs)
+        else:
+            comm.gather_records_begin(packed, max_arcs)
+        pending = True
+    prev_outs, _ = job.finish()
+    spf = sp_job.finish().to_flat()
+    ok &= np.array_equal(spf["arcs"], alone["arcs"]) and np.array_equal(spf["finals"], alone["finals"])
+    ok &= np.array_equal(wdist.pack_device_paths(prev_outs, max_arcs), packed[:len(prev_outs)])
+if pending:
+    ok &= np.array_equal(comm.gather_paths_end(), g_rccl)
+del daccs2, dts
 flag = torch.tensor([1 if ok else 0], device=dev)
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 del comm, hcomm
