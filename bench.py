@@ -772,20 +772,28 @@ def main():
                                     "shortest_path(T) + fused compose->shortest_path of 512, overlapped on two contexts; both enqueue orders "
                                     "(a 512-string batch holds 64 compute units for ~0.3 ms: the relaxation's resident launch, which wants one "
                                     "workgroup on each of 245, waits for them)", "steps": 200}
-            for order in ("s1-first", "s2-first"):
-                args.order = order
-                for _ in range(20):
-                    step()
-                torch.cuda.synchronize(device)
-                c0 = time.perf_counter()
-                a512, n512 = 0, 200
-                for _ in range(n512):
-                    a512 += step()
-                torch.cuda.synchronize(device)
-                el512 = time.perf_counter() - c0
-                step_512[order] = {"ms_per_step": round(1e3 * el512 / n512, 4), "arcs_per_s": round(a512 / el512, 1),
-                                   "acceptors_per_s": round(512 * n512 / el512, 1)}
+            for share, tag in ((0, ""), (1, "_half_share")):
+                # (half share: wfst_ctx_set_resident_share(ctx, 1) on the query's context — 123 resident workgroups of 8192 states
+                # instead of 245 of 4096: the solve alone is slower, and runs BESIDE the batch's 64 compute units instead of behind them)
+                ctx.set_resident_share(share)
+                for order in ("s1-first", "s2-first"):
+                    args.order = order
+                    for _ in range(20):
+                        step()
+                    torch.cuda.synchronize(device)
+                    c0 = time.perf_counter()
+                    a512, n512 = 0, 200
+                    for _ in range(n512):
+                        a512 += step()
+                    torch.cuda.synchronize(device)
+                    el512 = time.perf_counter() - c0
+                    step_512[order + tag] = {"ms_per_step": round(1e3 * el512 / n512, 4), "arcs_per_s": round(a512 / el512, 1),
+                                             "acceptors_per_s": round(512 * n512 / el512, 1)}
+            ctx.set_resident_share(0)
+            step_512["resident_aborts"] = int(ctx.stats()["resident_aborts"])
             args.order = order_keep
+            for _ in range(3):  # (the handle's launch hints are those of the 4096-state plan again)
+                dt.shortest_path()
             daccs = daccs_keep
 
         # ------------------------------------------------------------------ configs[4]: HCLG-shaped operand under look-ahead

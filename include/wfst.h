@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 5 /* 5: wfst_ctx_get_sweep_modes, relax_kernel may be 3, wfst_stats gained tied_choices;
+#define WFST_ABI_VERSION 6 /* 6: wfst_ctx_set_resident_share; 5: wfst_ctx_get_sweep_modes, relax_kernel may be 3, wfst_stats gained tied_choices;
                              * 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
                              * 4: wfst_stats gained resident_aborts, relax_kernel may be 2; wfst_comm_create_host, wfst_gather_records_begin */
 
@@ -359,6 +359,19 @@ wfst_status wfst_comm_allgatherv(wfst_comm* comm, const void* send, size_t bytes
  * that needs rustfst's structure falls back to rustfst (the convention for unsupported cases).  Tie order 0 never fails
  * and reports the same count in wfst_stats.tied_choices. */
 wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order);
+
+/* Share of the device a RESIDENT relaxation launch of this context may occupy (shortest_path on branching FSTs of <= 2M
+ * states: sssp_mbox_resident_kernel keeps one 1024-thread workgroup on a compute unit of its own for every block of states,
+ * for the whole wide phase of the solve — DESIGN.md §3.2 / §3.3).  0 (default) = the whole device: blocks of 4096 states, up to
+ * 245 workgroups for a 1M-state FST — the fastest solve, and nothing else of any size fits beside it: a kernel that holds
+ * more than a dozen compute units when the launch arrives makes it WAIT (a 512-string fused batch holds 64 of them for
+ * ~0.3 ms).  1 = half the device: blocks of 8192 states where that brings the workgroup count to at most half the compute
+ * units (1M states: 123), one launch per level where it does not — the solve alone is ~1.6 x slower (1M states: 0.41 vs
+ * 0.25 ms of kernels) and runs BESIDE a batch of that size instead of behind it.  The request class decides: a server
+ * whose shortest_path queries share the GPU with large fused batches sets 1 on the context that runs the queries.
+ * Same results either way (the keys are the fixed point whatever the block size).  The reference has no counterpart: its
+ * algorithms run on one host thread (shortest_path.rs:173-239). */
+wfst_status wfst_ctx_set_resident_share(wfst_ctx* ctx, uint32_t share);
 
 /* ---- measurement hooks (bench.py / tests; not part of the reference surface) ---- */
 typedef struct {

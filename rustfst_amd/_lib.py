@@ -73,6 +73,7 @@ SYMBOLS = [
     ("wfst_lookahead_download", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("wfst_label_reachable_compute", C.c_int, [_u32, _vp, _vp, _vp, C.c_int, _P(_vp)]),
     ("wfst_ctx_set_tie_order", C.c_int, [_vp, C.c_int]),
+    ("wfst_ctx_set_resident_share", C.c_int, [_vp, _u32]),
     ("wfst_shortest_path_batch", C.c_int, [_vp, _P(_vp), _sz, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_path_begin", C.c_int, [_vp, _vp, _P(ShortestPathConfig), _P(_vp)]),
     ("wfst_shortest_path_end", C.c_int, [_vp, _P(_vp)]),

@@ -654,6 +654,13 @@ wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order) {
     ctx->tie_reference = reference_order != 0;
   });
 }
+wfst_status wfst_ctx_set_resident_share(wfst_ctx* ctx, uint32_t share) {
+  return wrap([&] {
+    if (!ctx) throw Error("null ctx");
+    if (share > 1) throw Error("wfst_ctx_set_resident_share: 0 (whole device) or 1 (half)");
+    ctx->resident_share = share;
+  });
+}
 wfst_status wfst_ctx_set_profiling(wfst_ctx* ctx, int on) {
   return wrap([&] {
     if (!ctx) throw Error("null ctx");

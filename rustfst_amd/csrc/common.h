@@ -142,6 +142,7 @@ struct wfst_ctx {
   wfst::PinnedBuf pinned_big;  // batch descriptors / results
   bool profiling = false;
   bool tie_reference = false;  // wfst_ctx_set_tie_order: the reference's predecessor choice on acyclic inputs
+  uint32_t resident_share = 0; // wfst_ctx_set_resident_share: 0 = resident launches may fill the device, 1 = at most half of it
   // A resident relaxation launch of this context gave up waiting (its grid was not resident as a whole: another tenant held
   // compute units): solves take one launch per level until `resident_retry_at`, then a resident launch is tried again;
   // the pause doubles with every abort in a row (50 ms .. 3.2 s) and is forgotten by the first resident solve that completes.

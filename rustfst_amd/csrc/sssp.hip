@@ -1372,6 +1372,15 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     if (nb12 <= cus) log = 12;
     else if (nb13 <= cus && !std::getenv("WFST_SSSP_LOG12")) log = 13;
     if (log == 12 && nb13 <= cus && std::getenv("WFST_SSSP_LOG13") && std::atoi(std::getenv("WFST_SSSP_LOG13")) != 0) log = 13;  // experiments: half the workgroups
+    // wfst_ctx_set_resident_share(ctx, 1): the resident grid may hold at most half of the compute units, so that a large batch
+    // kernel of another context runs BESIDE it (a resident workgroup needs a compute unit of its own; a grid that wants 245 of
+    // 256 waits for whatever holds more than 11 of them).  8192-state blocks where that is enough, one launch per level otherwise.
+    if (ctx->resident_share == 1u) {
+      const uint32_t half = cus / 2u;
+      if (nb12 <= half) log = 12;
+      else if (nb13 <= half && !std::getenv("WFST_SSSP_LOG12")) log = 13;
+      else log = 0;
+    }
     if (want && log && !ctx->profiling && ctx->resident_allowed() && !big_env && sv.lease.acquire(ctx->device)) {
       want_res = true;
       sv.log = log;

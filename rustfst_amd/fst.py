@@ -71,6 +71,11 @@ class Context:
     def synchronize(self):
         check(_lib.lib().wfst_ctx_synchronize(self._h), "wfst_ctx_synchronize")
 
+    def set_resident_share(self, share: int):
+        """0 (default): a resident relaxation launch may fill the device (fastest alone); 1: at most half of it, so that it runs
+        beside a large fused batch instead of behind it (wfst_ctx_set_resident_share)."""
+        check(_lib.lib().wfst_ctx_set_resident_share(self._h, int(share)), "wfst_ctx_set_resident_share")
+
     def set_tie_order(self, reference_order: bool):
         """shortest_path(nshortest = 1): False = the canonical tie rule (default); True = the reference's own choice among
         tied optima on ACYCLIC inputs (wfst_ctx_set_tie_order)."""

@@ -842,6 +842,50 @@ def test_resident_solve_next_to_a_batch_that_fills_the_compute_units(oracle, mon
     assert ctx.stats()["relax_kernel"] == 2
 
 
+@pytest.mark.parametrize("order", ["s1-first", "s2-first"])
+def test_resident_share_half_runs_beside_a_512_string_batch(oracle, order):
+    """configs[3] on ONE GPU: shortest_path(T) (1M states) and the fused batch of all 512 acceptors, overlapped on two contexts,
+    in both enqueue orders, with the query's context set to HALF the device (wfst_ctx_set_resident_share(ctx, 1): 123
+    workgroups of 8192 states instead of 245 of 4096, so that the batch's 64 compute units and the solve's 123 fit side by
+    side).  Every repetition: the path and all distances bit-identical to the canonical oracle, a sample of the batch
+    bit-identical to the oracle's compose -> shortest path, no resident launch gives up; and the default share still takes
+    4096-state blocks afterwards."""
+    torch = pytest.importorskip("torch")
+    t = synth.make_transducer(1_000_000, 10, 256, 0.0, seed=3)
+    accs = synth.make_acceptors(t, 512, 200, seed0=50_000)
+    ctx = rustfst_amd.Context(0)
+    s2 = torch.cuda.Stream()
+    ctx2 = rustfst_amd.Context(0, stream=s2.cuda_stream)
+    ctx.set_resident_share(1)
+    dt = to_device(t, ctx)
+    daccs = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many(accs, ctx2))
+    ot = to_oracle(oracle, t)
+    can = ot.shortest_path_canonical()
+    can_flat = can.to_flat()
+    exp = {i: to_oracle(oracle, accs[i]).compose(ot, connect=True).shortest_path_canonical().to_flat() for i in (0, 255, 511)}
+    dist, hops = dt.shortest_distance(want_hops=True)
+    np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+    np.testing.assert_array_equal(hops, can.hops)
+    assert ctx.stats()["relax_kernel"] == 2
+    for rep in range(6):
+        if order == "s1-first":
+            sp_job = dt.shortest_path_begin()
+            job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
+        else:
+            job = rustfst_amd.compose_shortest_path_batch_begin(daccs, dt, ctx=ctx2)
+            sp_job = dt.shortest_path_begin()
+        outs, n_arcs = job.finish()
+        sp = sp_job.finish()
+        assert_flat_identical(sp.to_flat(), can_flat, f"{order}, rep {rep}: the query")
+        for i, e in exp.items():
+            assert_flat_identical(outs[i].to_flat(), e, f"{order}, rep {rep}: batch item {i}")
+    st = ctx.stats()
+    assert st["resident_aborts"] == 0 and st["relax_kernel"] == 2
+    ctx.set_resident_share(0)
+    assert_flat_identical(dt.shortest_path().to_flat(), can_flat, "whole-device share again")
+    assert ctx.stats()["relax_kernel"] == 2
+
+
 def test_two_processes_solving_on_one_gpu():
     """Two PROCESSES query the same kind of FST on one GPU at the same time.  A resident launch needs every workgroup on a
     compute unit of its own, so only one process at a time may run one: the lease is an advisory file lock per device
