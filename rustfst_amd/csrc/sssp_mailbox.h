@@ -315,7 +315,9 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     const uint32_t n_lv = min(s_n[cur], NW_CAP);
     const uint32_t far_seen = s_n[2];
     if (n_lv == 0) break;
-    if (n_lv > (sweep == 0 ? NW_GROW : NW_GROW_MANY)) {
+    // (8192-state blocks: a workgroup's share of the hand-over is twice as long — with the 4096-state limit the tail of a 1M-state
+    // solve on half the device bounced back to the WIDE levels twice: 385 -> 350 us, 5 -> 3 launches; 2M states unchanged)
+    if (n_lv > (sweep == 0 ? NW_GROW : (LOG == 13 ? 2u * NW_GROW_MANY : NW_GROW_MANY))) {
       grew = true;
       break;
     }

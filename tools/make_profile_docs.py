@@ -1,13 +1,15 @@
-"""Assembles profiles/<tag>_*.md from the scratch output of tools/profile_round2.sh (gpurun_out/prof_<tag>/ and
-gpurun_out/pmc_<tag>_*): python tools/make_profile_docs.py <tag> [atomic_pmc_dir]"""
-import io, json, os, subprocess, sys, contextlib
+"""Assembles profiles/<tag>_end_of_round.md, <tag>_counters.md and <tag>_bench_line.json from the scratch output of
+tools/profile_round.sh (gpurun_out/prof_<tag>/, gpurun_out/pmc_<tag>/) and a default bench line:
+python tools/make_profile_docs.py <tag> <bench_line.json> [suite summary]     (run after tools/pmc_to_json.py)"""
+import contextlib, io, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import rocpd_summary
 
-tag = sys.argv[1]
-atomic_pmc = sys.argv[2] if len(sys.argv) > 2 else None
+tag, bench_path = sys.argv[1], sys.argv[2]
+suite = sys.argv[3] if len(sys.argv) > 3 else ""
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+pmc_dir = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
 dst = os.path.join(ROOT, "profiles")
 head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT).decode().strip()
 
@@ -15,71 +17,59 @@ head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT
 def cap(fn, *a):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        fn(*a)
+        try:
+            fn(*a)
+        except Exception as e:
+            print(f"(not available: {e})")
     return buf.getvalue()
 
 
-def read(name):
-    p = os.path.join(src, name)
+def read(name, base=src):
+    p = os.path.join(base, name)
     return open(p).read() if os.path.exists(p) else f"(missing: {name})\n"
 
 
-line = read("bench_line.json").strip().splitlines()[-1]
-open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(line + "\n")
+def clean(text):
+    return "\n".join(l for l in text.splitlines() if "amdgpu.ids" not in l and "simple_timer" not in l and "rocprofv3" not in l
+                     and "generateRocpd" not in l and "tool.cpp" not in l) + "\n"
+
+
+raw = [l for l in open(bench_path).read().strip().splitlines() if l.startswith("{")]
+line = raw[-1]
 d = json.loads(line)
-md = [f"# {tag} — end of round 2: rocprofv3 evidence (MI355X, commit {head})\n",
-      "All of it collected by `tools/profile_round2.sh` in one `gpurun` call; raw rocpd databases stay in `gpurun_out/` (scratch).\n",
+open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(line + "\n")
+rf = d.get("roofline", {})
+c5 = (d.get("config5") or {}).get("wide_lookahead", {})
+md = [f"# {tag} — end of round: rocprofv3 evidence (MI355X, commit {head})\n",
+      "Collected by `tools/profile_round.sh` + the default `python bench.py` in one `gpurun` call" + (f" ({suite})" if suite else "") +
+      "; raw rocpd databases stay in `gpurun_out/` (scratch).\n",
       "## default bench line (`python bench.py`)\n```\n" + line + "\n```\n",
-      f"Headline: {d['value']/1e9:.2f} G arcs/s, {d['ms_per_step']} ms per step (mean {d['ms_per_step_stats']['mean']} ± {d['ms_per_step_stats']['std']} ms over {d['steps']} steps); "
-      f"`shortest_path(T)` alone {d['ms_shortest_path_T']} ms, fused batch alone {d['ms_compose_shortest_path_batch']} ms.\n",
-      "## kernel table: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras` (both requests overlapped)\n",
+      f"Headline: **{d['value'] / 1e9:.2f} G arcs/s, {d['ms_per_step']} ms per step**; `shortest_path(T)` alone {d.get('ms_shortest_path_T')} ms, fused batch "
+      f"alone {d.get('ms_compose_shortest_path_batch')} ms.  `roofline`: {rf.get('launches')} launches, {rf.get('solve_relax_kernel_ms')} ms of relaxation "
+      f"kernels per solve (HIP events, un-profiled) -> 212 MB / that = {rf.get('achieved')} GB/s = **{rf.get('frac')}** of 8 TB/s; traffic "
+      f"{rf.get('traffic_over_algorithmic')} x algorithmic (stale: {rf.get('traffic_stale')}).  `roofline_vs_size`: "
+      + " / ".join(f"{p.get('frac')}" for p in (d.get('roofline_vs_size') or {}).get('points', [])) + " at "
+      + " / ".join(f"{p['states'] // 1000000}M" for p in (d.get('roofline_vs_size') or {}).get('points', [])) + " states.  "
+      f"`step_512_acceptors`: {json.dumps(d.get('step_512_acceptors'))}.  `cold_query_ms`: {json.dumps((d.get('cold_query_ms') or {}).get('fresh_handle_warm_process'))}.  "
+      f"`config5.wide_lookahead`: first {c5.get('first_call_ms')} ms, second {c5.get('second_call_ms')}, then {c5.get('repeated_calls_ms')} "
+      f"(spread {c5.get('spread')}), `roofline_compose.frac` {(c5.get('roofline_compose') or {}).get('frac')}.\n",
+      "## The two clocks of the relaxation: HIP events and the profiler, SAME process\n",
+      "`tools/sp_repeat.py 1000000 12` under `rocprofv3 --kernel-trace` (first block) and without the profiler (second): the tool prints the HIP-event "
+      "bracket around the pre-queued launch chain of its own solves.\n```\n" + clean(read("sp_alone.log")) + "---- without the profiler\n" +
+      clean(read("sp_alone_unprofiled.log")) + "```\n",
+      "Kernel durations of the profiled process (sum per solve below) against its own event bracket: the profiler's per-dispatch completion handling "
+      "stretches a chain of back-to-back launches; the bench line's figure is the un-profiled bracket.\n",
+      "## kernel table: the bench step (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras`)\n",
       cap(rocpd_summary.trace, os.path.join(src, "trace_results.db")),
-      "\n## the relaxation alone: `rocprofv3 --kernel-trace -- python tools/sp_repeat.py 1000000 12` (un-profiled solves, nothing else on the GPU)\n",
-      cap(rocpd_summary.trace, os.path.join(src, "sp_alone_results.db")).split("\n\n")[-1] if True else "",
-      "\n### timeline of one of those solves (launch order; duration and idle gap before each kernel)\n",
-      cap(rocpd_summary.timeline, os.path.join(src, "sp_alone_results.db"), -3),
-      "\n## where a sweep's time goes: phase stamps of `sssp_mbox_kernel` (`WFST_SSSP_MBOX_TRACE`, `tools/mbox_phases.py`)\n",
-      "Per sweep: blocks that did something / slept, states expanded, messages sent, then for every phase boundary the time since the "
-      "first block of the sweep started at which the LAST (median) busy block passed it: `trip1` = counts + keys + offsets + threshold "
-      "have arrived, `applied` = inbox messages applied (LDS atomicMin), `scanned` = changed states written back and listed, `staged` = arc "
-      "rows read and candidates staged, `expanded` = staged messages flushed, `end` = counts / waiting set published.  The kernel's "
-      "duration in the timeline above adds ≈ 1.5 µs (tiny sweeps) to ≈ 3 µs (write-back of ≈ 10 MB of dirty lines) of launch / teardown.\n```\n",
-      read("mbox_phases.txt"), "```\n",
-      "\n## atomic sweeps vs mailbox sweeps, per-launch (profiled solves: one launch at a time, events around it)\n```\n", read("sweep_compare.txt"), "```\n"]
-open(os.path.join(dst, f"{tag}_end_of_round.md"), "w").write("\n".join(md))
-
-# counters
-md = [f"# {tag} — PMC counters (rocprofv3 --pmc, one counter group per pass; commit {head})\n",
-      "`tools/pmc_relax.sh`: every pass runs `tools/sp_repeat.py 1000000 6` (six un-profiled `shortest_path(T)` solves on the C3 graph); "
-      "sums are PER SOLVE.  SQ_* counters are per shader engine instance summed over instances; SQ_WAVE_CYCLES / SQ_WAIT_* / "
-      "SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md).  FETCH_SIZE / WRITE_SIZE are KB.\n",
-      "## `sssp_mbox_kernel` (mailbox sweeps, the default on this graph)\n```\n", read("pmc_mbox.txt"), "```\n"]
-if atomic_pmc:
-    md += ["## `sssp_relax_kernel` (atomic sweeps, `WFST_SSSP_MAILBOX=0`), same passes\n```\n",
-           subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), atomic_pmc]).decode(), "```\n"]
-md += ["## `string_compose_sp_kernel` (fused batch: 64 linear acceptors of 200 labels against the 1M-state T; `tools/pmc_batch.sh`)\n```\n",
-       read("pmc_string.txt"), "```\n",
-       "Reading (per wave and BFS level): the kernel is one dependent chain per problem — per level ≈ 62 VALU + 80 SALU + 2 VMEM + 4 LDS "
-       "instructions of a lone wave (≈ 5 cycles each) and ONE dependent miss (TCC_MISS ≫ TCC_HIT: the arc block and its `anext` words come "
-       "from beyond the L2 in one trip); SQ_WAIT_ANY against SQ_ACTIVE_INST_ANY gives the split (≈ 63 % / 36 % when it was measured with one "
-       "wave per workgroup, `profiles/r02k`).  Since then a workgroup holds 8 problems (DESIGN.md §3.1): the SQ rows are per shader-engine "
-       f"instance and now cover several waves each.  Kernel time per BFS level in the bench line of this set: {d.get('batch_kernel', {}).get('us_per_bfs_level')} µs.\n"]
-open(os.path.join(dst, f"{tag}_counters.md"), "w").write("\n".join(md))
-
-# wide compose
-md = [f"# {tag} — the wide composition driver (commit {head})\n",
-      "`rocprofv3 --kernel-trace -- python tools/lookahead_timing.py 10000,100,3,16,16`: the look-ahead composition (1.22 M states / "
-      "4.27 M arcs), the plain composition without connect (1.11 M states / 3.9 M arcs) and the default `compose()` (with connect) of the "
-      "same pair, each once as warm-up and three times timed.  The driver as of this set (DESIGN.md §3.7): 8 lanes per composed state, "
-      "three launches per level (`la_emit`, `la_first`, `la_assign`) that read the level's id range from the control block, up to 8 "
-      "levels queued per host look, the arena grown in place and ahead of the level that would not fit.\n",
+      "\n## the relaxation alone at 1M states (`tools/sp_repeat.py 1000000 12`)\n", cap(rocpd_summary.trace, os.path.join(src, "sp_alone_results.db")),
+      "\n## 2M states (8192-state blocks, every launch resident)\n", cap(rocpd_summary.trace, os.path.join(src, "sp_2m_results.db"), 424e6),
+      "\n## 5M states (atomic sweeps: the default there)\n", clean(read("sp_5m.log")), cap(rocpd_summary.trace, os.path.join(src, "sp_5m_results.db"), 1060e6),
+      "\n## the wide look-ahead driver (`tools/wide_lookahead_run.py 5000000 4`)\n```\n" + clean(read("wide.log")) + "```\n",
       cap(rocpd_summary.trace, os.path.join(src, "wide_results.db")),
-      "\n## end-to-end times of the tool (warm), oracle-identical where the oracle was run\n```\n", read("wide_timing.txt"), "```\n",
-      "(gpu_ms = look-ahead composition on the GPU, cpu_ms = the oracle's, plain_gpu_ms = `compose(connect=False)` of the same pair, the last "
-      "column the default `compose()` with connect; states in parentheses; best of three.)  Round 1: 4.2 / 5.4 / 8.5 / 27.8 ms for the four "
-      "plain compositions, 1.7 / 4.4 / 11.4 / 39.7 ms with look-ahead.\n"]
-open(os.path.join(dst, f"{tag}_wide_compose.md"), "w").write("\n".join(md))
-for name in ("kdelta_gap.txt", "rm_epsilon_timing.txt", "step_breakdown.txt"):  # (optional parts of the set)
-    if os.path.exists(os.path.join(src, name)):
-        open(os.path.join(dst, f"{tag}_{name}"), "w").write(read(name))
-print("written")
+      "\n## level stamps of the resident launch (`WFST_SSSP_RES_TRACE`, `tools/res_levels.py`: microseconds from the launch's start)\n```\n" + read("res_levels.txt") + "```\n"]
+open(os.path.join(dst, f"{tag}_end_of_round.md"), "w").write("\n".join(md))
+cm = [f"# {tag} — PMC passes of the relaxation at 1M states (commit {head})\n",
+      "`tools/profile_round.sh`: every pass runs `tools/sp_repeat.py 1000000 12` under `rocprofv3 --pmc <one group> --kernel-trace`; sums are PER SOLVE.  "
+      "`profiles/pmc_relax_traffic.json` (read by bench.py) is written from the same databases by `tools/pmc_to_json.py`.\n```\n" + read("pmc_summary.txt") + "```\n"]
+open(os.path.join(dst, f"{tag}_counters.md"), "w").write("\n".join(cm))
+print("wrote", f"{tag}_end_of_round.md", f"{tag}_counters.md", f"{tag}_bench_line.json")

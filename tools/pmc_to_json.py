@@ -29,7 +29,7 @@ per_kernel = {k: {c: round(v[1]) for c, v in d.items()} for k, d in per.items()}
 fetch, write = cs["FETCH_SIZE"][1] * 1024, cs["WRITE_SIZE"][1] * 1024
 res = {
     "kernel": kernel,
-    "source": f"rocprofv3 --pmc passes of tools/profile_round5.sh {tag} (or tools/pmc_relax.sh; each pass runs tools/sp_repeat.py: un-profiled shortest_path(T) solves), one counter group per pass",
+    "source": f"rocprofv3 --pmc passes of tools/profile_round.sh {tag} (or tools/pmc_relax.sh; each pass runs tools/sp_repeat.py: un-profiled shortest_path(T) solves), one counter group per pass",
     "workload": "T 1M states / 10M arcs, fan-out 10, seed 3 (bench.py default)",
     "commit": subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT).decode().strip(),
     "kernel_sources_sha256": kernel_sources_sha256(),
