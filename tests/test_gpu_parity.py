@@ -2119,7 +2119,7 @@ def _lookahead_pair(rng, n1, n2, acyclic=False, sigma=3, p_oeps=0.45, p_ieps=0.3
 
 @pytest.mark.parametrize("path", ["wave", "wide"])
 def test_k13_lookahead_hand_traced_known_answers(gpu_ctx, monkeypatch, path):
-    """Look-ahead composition against the three answers traced by hand through the reference's source
+    """Look-ahead composition against the six answers traced by hand through the reference's source
     (tests/golden/K13_DERIVATION.md section 2, tests/golden/k13_lookahead.json): the relabelled second operand, the pruned
     dead end, pushed weights and labels, state numbering and arc order — on the single-wave kernel and on the wide driver,
     and through the batch entry point."""

@@ -89,7 +89,7 @@ def test_k13_nshortest_known_answers(oracle):
 
 
 def test_k13_lookahead_known_answers(oracle):
-    """Look-ahead composition (rustfst-cli compose --compose-type lookahead) on five pairs traced by hand through the
+    """Look-ahead composition (rustfst-cli compose --compose-type lookahead) on six pairs traced by hand through the
     reference's source (tests/golden/K13_DERIVATION.md section 2): label reachability and relabelling, pruning of a dead end,
     weight pushing (and its division at the following arcs), label pushing through a multi-epsilon, an unseen label, an
     epsilon CYCLE on fst1's output side (condensation: state_reachable.rs:36-67) and the linear-scan branch of
