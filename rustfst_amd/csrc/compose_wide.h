@@ -392,6 +392,7 @@ __global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t level, Wi
 template <uint32_t G>
 __global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint32_t level, WideCtl* ctl) {
   constexpr uint32_t SPW = 64 / G;
+  static_assert(4u * (64u / G) <= 64u, "la_assign numbers a tile of (waves per block) x (states per wave) states with one 64-lane scan: G >= 4");
   __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[64], s_status;
   const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
   if (lo >= hi) {  // the search ended before this level: the levels queued behind it must see an empty range too
