@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(256) la_first(WideArena ar, uint32_t level, Wi
 template <uint32_t G>
 __global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint32_t level, WideCtl* ctl) {
   constexpr uint32_t SPW = 64 / G;
-  static_assert(4u * (64u / G) <= 64u, "la_assign numbers a tile of (waves per block) x (states per wave) states with one 64-lane scan: G >= 4");
-  __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[64], s_status;
+  static_assert(4u * (64u / G) <= 128u, "la_assign numbers a tile of (waves per block) x (states per wave) states with two 64-lane scans: G >= 2");
+  __shared__ uint32_t s_pre[4], s_tot[4], s_cnt[128], s_status;
   const uint32_t lo = ctl->lvl[level % LVL_RING][0], hi = ctl->lvl[level % LVL_RING][1];
   if (lo >= hi) {  // the search ended before this level: the levels queued behind it must see an empty range too
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -443,10 +443,14 @@ __global__ void __launch_bounds__(256) la_assign(WideArena ar, LaCaps caps, uint
     c = group_sum<G>(c);
     if (sub == 0) s_cnt[me] = c;
     __syncthreads();
-    const uint32_t v = lane < T ? s_cnt[lane] : 0u;
-    uint32_t tile_total;
+    // (a tile is at most 128 states: two 64-lane scans)
+    const uint32_t v = lane < T ? s_cnt[lane] : 0u, v2 = 64u + lane < T ? s_cnt[64u + lane] : 0u;
+    uint32_t tile_total, total2;
     const uint32_t excl = group_excl_scan<64>(v, lane, &tile_total);
-    uint32_t next = running + __shfl(excl, me);
+    const uint32_t excl2 = tile_total + group_excl_scan<64>(v2, lane, &total2);
+    tile_total += total2;
+    const uint32_t e_lo = __shfl(excl, me & 63u), e_hi = __shfl(excl2, me & 63u);
+    uint32_t next = running + (me < 64u ? e_lo : e_hi);
     __syncthreads();
     // same predicate as the count: only the one arc whose order the table kept can pass it for a new tuple, and only its
     // lane writes that tuple's id, so the ids written by other waves meanwhile do not disturb it
@@ -707,12 +711,14 @@ void run_wide_g(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_
 template <class P>
 void run_wide(wfst_ctx* ctx, const P& pol, uint64_t lo0, uint64_t hi0, uint64_t est_s, uint64_t est_a, double items_hint,
               WideOutput& out) {
-  // (4 lanes per state where a state has a handful of items — a linear acceptor against a transducer: 2 — : the kernels are
-  // chains of dependent trips per composed state, and 16 states per wave instead of 8 is twice the memory-level parallelism
-  // for the same registers: the 90 M-state look-ahead composition 107.8 -> 87.0 ms, profiles/r06d_wide_lookahead.md)
-  uint32_t g = items_hint <= 4.0 ? 4u : (items_hint <= 8.0 ? 8u : (items_hint <= 16.0 ? 16u : 64u));
-  if (const char* e = std::getenv("WFST_WIDE_GROUP")) g = (uint32_t)std::atoi(e);  // tests: 4, 8, 16 or 64 lanes per state
-  if (g == 4) run_wide_g<P, 4>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  // (2 / 4 lanes per state where a state has a handful of items — a linear acceptor against a transducer: 2 — : the kernels move
+  // a few sectors per composed state through a chain of dependent trips, and 32 / 16 states per wave instead of 8 is that many
+  // more loads in flight for the same registers: the 90 M-state look-ahead composition 107.8 (8 lanes) -> 87.0 (4) -> 77.1 ms
+  // (2), profiles/r06d_wide_lookahead.md)
+  uint32_t g = items_hint <= 2.5 ? 2u : (items_hint <= 4.0 ? 4u : (items_hint <= 8.0 ? 8u : (items_hint <= 16.0 ? 16u : 64u)));
+  if (const char* e = std::getenv("WFST_WIDE_GROUP")) g = (uint32_t)std::atoi(e);  // tests: 2, 4, 8, 16 or 64 lanes per state
+  if (g == 2) run_wide_g<P, 2>(ctx, pol, lo0, hi0, est_s, est_a, out);
+  else if (g == 4) run_wide_g<P, 4>(ctx, pol, lo0, hi0, est_s, est_a, out);
   else if (g == 8) run_wide_g<P, 8>(ctx, pol, lo0, hi0, est_s, est_a, out);
   else if (g == 16) run_wide_g<P, 16>(ctx, pol, lo0, hi0, est_s, est_a, out);
   else run_wide_g<P, 64>(ctx, pol, lo0, hi0, est_s, est_a, out);

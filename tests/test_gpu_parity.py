@@ -2382,9 +2382,10 @@ def test_wide_driver_grows_its_arena(gpu_ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("group,batch,est", [("8", "1", "256"), ("8", "5", "0"), ("16", "2", "256"), ("16", "8", "0"), ("64", "3", "256"),
-                                             ("8", "4", "-64"), ("16", "auto", "-256"), ("4", "1", "256"), ("4", "6", "0"), ("4", "auto", "-64")])
+                                             ("8", "4", "-64"), ("16", "auto", "-256"), ("4", "1", "256"), ("4", "6", "0"), ("4", "auto", "-64"),
+                                             ("2", "1", "256"), ("2", "5", "0"), ("2", "auto", "-256")])
 def test_wide_driver_lane_groups_and_level_batches(gpu_ctx, oracle, monkeypatch, group, batch, est):
-    """The wide driver with 4, 8, 16 or 64 lanes per composed state and 1..8 levels queued per look at the control block
+    """The wide driver with 2, 4, 8, 16 or 64 lanes per composed state and 1..8 levels queued per look at the control block
     (level ranges, overflow status and finished-level count live on the device), from a small arena that has to grow in
     the middle of a batch (before the level that is not going to fit, or — foresight off — after it has overflowed) and
     from the default one: plain and look-ahead composition equal the oracle — also with states
