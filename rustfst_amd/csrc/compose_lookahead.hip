@@ -367,6 +367,9 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
   LaResult res{LA_OK, 0, 0, 0};
   uint32_t n_states = 0, n_arcs = 0, n_levels = 0;
   bool ok = true;
+#ifdef WFST_LA_PHASE
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, pt = 0;  // tuning: wall-clock per phase of a level (printed by problem 0)
+#endif
   if (f1.start >= 0 && f2.start >= 0) {  // compute_start, compose_fst_op.rs:389-404
     for (uint32_t i = lane; i < caps.H; i += 64) {
       ar.klo[i] = K_EMPTY;
@@ -386,6 +389,12 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
     __syncthreads();
     n_states = 1;
     uint32_t lo = 0, hi = 1;
+#ifdef WFST_LA_PHASE
+    pt = wall_clock64();
+#define LA_PH(i) do { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define LA_PH(i) do { } while (0)
+#endif
     while (lo < hi && ok) {  // LazyFst::compute, lazy_fst.rs:235-259: level = ids [lo, hi)
       n_levels++;
       const uint32_t level_begin = n_arcs;
@@ -393,14 +402,24 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
         if (lane == 0) ar.off[q] = n_arcs;
         const Expand x = make_expand(f1, f2, ld_l2(&ar.t_lo[q]), ld_l2(&ar.t_hi[q]));
         if (lane == 0) ar.fin[q] = x.final_weight;
+#ifdef WFST_LA_PHASE
+        if (x.n_it == 0xFFFFFFFFu) ar.fin[q] = 0.0f;  // (consume x before the stamp)
+#endif
+        LA_PH(0);
         const uint32_t n_items = x.n_it + 1;
         for (uint32_t base = 0; base < n_items; base += 64) {
           const uint32_t j = base + lane;
           const bool have = j < n_items;
           Emitted em;
           const uint32_t cnt = have ? eval_item(reach, f2, x, j, false, 0, nullptr, nullptr, nullptr, &em) : 0u;
-          uint32_t total;
-          const uint32_t pos = wave_excl_scan(cnt, lane, &total);
+          uint32_t total, pos;
+          if (!__any(cnt > 1u)) {  // (the usual case — every item emits at most one arc: positions from one ballot, no shuffles)
+            const uint64_t m1 = __ballot(cnt == 1u);
+            pos = lanes_below(m1);
+            total = (uint32_t)__popcll(m1);
+          } else {
+            pos = wave_excl_scan(cnt, lane, &total);
+          }
           if (total == 0) continue;
           if ((uint64_t)n_arcs + total > caps.A) {
             res.status = LA_OVERFLOW_ARCS;
@@ -416,10 +435,12 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
           }
           n_arcs += total;
         }
+        LA_PH(1);
       }
       if (!ok) break;
       if (lane == 0) ar.off[hi] = n_arcs;
       __syncthreads();
+      LA_PH(2);
       // StateTable::find_id (state_table.rs:49-59) for this level's destinations, in emission order
       uint32_t n_new = 0;
       for (uint32_t base = level_begin; base < n_arcs && ok; base += 64) {
@@ -431,7 +452,8 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
           khi = ld_l2(&ar.a_hi[e]);
         }
         uint32_t first = lane;  // lowest lane of the chunk holding the same tuple
-        for (uint32_t i = 0; i < 64; ++i) {
+        const uint32_t n_chunk = min(64u, n_arcs - base);  // (a decoding level emits two or three arcs: not 64 rounds of shuffles)
+        for (uint32_t i = 0; i < n_chunk; ++i) {
           const uint64_t li = shfl64(klo, i), hi_i = shfl64(khi, i);
           if (have && i < first && li == klo && hi_i == khi) first = i;
         }
@@ -478,6 +500,7 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
         __syncthreads();  // ids of this chunk are visible to the next one
       }
       if (!ok) break;
+      LA_PH(3);
       lo = hi;
       hi += n_new;
       n_states = hi;
@@ -493,6 +516,11 @@ __global__ void __launch_bounds__(64) compose_lookahead_kernel(LaView f1, const 
   res.n_states = n_states;
   res.n_arcs = n_arcs;
   res.n_levels = n_levels;
+#ifdef WFST_LA_PHASE
+  if (lane == 0 && blockIdx.x == 0)
+    printf("la phases (us per level, %u levels): expand %.2f items %.2f sync %.2f hash %.2f\n", n_levels, ph[0] / 100.0 / n_levels,
+           ph[1] / 100.0 / n_levels, ph[2] / 100.0 / n_levels, ph[3] / 100.0 / n_levels);
+#endif
   if (lane == 0) *result = res;
 }
 
