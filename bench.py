@@ -663,9 +663,18 @@ def main():
             d512 = rustfst_amd.HandleArray(rustfst_amd.DeviceFst.upload_many([sweep_accs[i] for i in idx512], ctx2))
             tab = [None]
 
+            n_loc512 = (512 + world - 1) // world  # (every rank contributes the same number of records: short shards pad with empty ones)
+            pad512 = [None]
+
             def strong():
                 tab[0], _ = rustfst_amd.compose_shortest_path_batch_packed(d512, dt2, args.acc_len + 8, ctx=ctx2, out=tab[0])
-                comm.gather_records_begin(tab[0], args.acc_len + 8)
+                send = tab[0]
+                if send.shape[0] < n_loc512:
+                    if pad512[0] is None:
+                        pad512[0] = np.zeros((n_loc512, send.shape[1]), dtype=np.uint32)
+                    pad512[0][:send.shape[0]] = send
+                    send = pad512[0]
+                comm.gather_records_begin(send, args.acc_len + 8)
                 comm.gather_paths_end()
             for _ in range(5):
                 strong()
