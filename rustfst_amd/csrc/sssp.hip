@@ -1161,6 +1161,7 @@ struct Solve {
   DBuf<unsigned long long> rs_trace;  // WFST_SSSP_RES_TRACE=<file>: per-level stamps
   ResView rv{};
   uint32_t res_max_levels = RS_LEVEL_CAP;
+  uint32_t res_lps_umax = 8u | (2u << 8);  // lanes per listed state | states per lane group of the widest round (sssp_resident.h)
   ResidentLease lease;       // at most one resident solve per device at a time (two half-resident grids would wait for each other)
   // binned levels (sssp_binned.h): the dense levels of the atomic sweeps as an owner-computes pass, chosen per level on the device
   bool binned = false;
@@ -1206,6 +1207,23 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f, uint32_t l
   DBuf<uint8_t> temp(*ctx->pool, temp_bytes);
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
   mbox_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roff.p, nb, p->roff_t.p);
+  // lanes per state of the resident kernel's expansion rounds (a lane takes two arcs): the fewest that cover all but 1/64 of
+  // the rows in one pass — a lane group without arcs is a lane group that keeps no row in flight
+  {
+    DBuf<uint32_t> over(*ctx->pool, 8);
+    uint32_t h_over[8];
+    HIP_CHECK(hipMemsetAsync(over.p, 0, sizeof(h_over), st));
+    mbox_degree_kernel<<<std::min<uint32_t>((n + 255) / 256, 1024u), 256, 0, st>>>(f->dev.offsets, n, over.p);
+    HIP_CHECK(hipMemcpyAsync(h_over, over.p, sizeof(h_over), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    p->lps = 8;
+    for (uint32_t l = 2; l < 8; ++l)
+      if (h_over[l] <= n / 64u) {
+        p->lps = l;
+        break;
+      }
+    if (const char* e = std::getenv("WFST_SSSP_LPS")) p->lps = std::max(2, std::min(8, std::atoi(e)));
+  }
   uint32_t h_units = 0;
   if (nb <= MB_NBMAX) {  // the resident kernel's regions: header + one slot per arc, 64-byte aligned
     p->roffh = DBuf<uint32_t>(owner_pool, cells + 1);
@@ -1286,11 +1304,11 @@ void launch_sweep(const wfst_fst* f, Solve& sv, uint32_t n, hipStream_t st, uint
       if (abs_sweep >= RS_MAX_SWEEP) throw Error("shortest_path: relaxation did not converge");
       sssp_mbox_resident_kernel<13><<<sv.mv.nb, MB_THREADS, sv.res_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
                                                                              sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
-                                                                             sv.narrow_t, sv.res_max_levels);
+                                                                             sv.narrow_t, sv.res_max_levels, sv.res_lps_umax);
     } else if (sv.resident && !profile && (abs_sweep & 1u) && abs_sweep < RS_MAX_SWEEP)
       sssp_mbox_resident_kernel<12><<<sv.mv.nb, MB_THREADS, sv.res_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, sv.rv, abs_sweep & 1u, n,
                                                                              sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
-                                                                             sv.narrow_t, sv.res_max_levels);
+                                                                             sv.narrow_t, sv.res_max_levels, sv.res_lps_umax);
     else if (sv.mv.nb > MB_NBMAX || sv.force_big)
       sssp_mbox_kernel<true><<<sv.mv.nb, MB_THREADS, sv.mb_dyn, st>>>(f->dev.offsets, f->dev.wn, sv.key.p, sv.mv, abs_sweep & 1u, n,
                                                                       sv.improved.p, sv.ctl.p, abs_sweep, sv.delta, sv.near_low,
@@ -1501,10 +1519,24 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       const uint64_t bytes = sv.plan->res_units * sizeof(uint2);
       constexpr size_t LDS_BYTES = 160u * 1024u;
       const size_t fixed = res_lds_bytes(sv.log, nb, 0);
-      const uint32_t stg_res = fixed + 8u * nb <= LDS_BYTES ? (uint32_t)std::min<size_t>(MB_STG_MAX, (LDS_BYTES - fixed) / (8u * nb)) : 0u;
+      // (deeper than the one-level kernel's slots where the LDS has room: a round of the resident kernel holds up to 4 x 16 x
+      // (64 / lps) states, 768 with 5 lanes per state)
+      const uint32_t stg_lim = std::min<uint32_t>(RS_STG_MAX, (MB_DYN_BUDGET - 12u * nb) / (8u * nb));  // (mb_dyn below: the one-level kernel's budget)
+      uint32_t stg_res = fixed + 8u * nb <= LDS_BYTES ? (uint32_t)std::min<size_t>(stg_lim, (LDS_BYTES - fixed) / (8u * nb)) : 0u;
+      if (const char* e = std::getenv("WFST_SSSP_STG")) stg_res = std::max<uint32_t>(1u, std::min<uint32_t>(stg_res, (uint32_t)std::atoi(e)));
       if (want_res && !sv.force_big && sv.plan->res_units != 0 && bytes < 0x7FFFFFF0ull && stg_res >= 4 && sv.rs_msgs.p) {
         sv.resident = true;
-        mv.stg = std::min(mv.stg, stg_res);
+        mv.stg = stg_res;
+        {
+          // states per lane group in the widest round: 4, unless such a round (4 x 16 x (64 / lps) states) would send more than
+          // ~0.8 of the staging slots' worth to an average destination — what overflows leaves as 8-byte stores of its own
+          // (2M states, 8192-state blocks, 21 slots: 454 us with 4, 432 with 2)
+          const uint32_t lps = sv.plan->lps, g = 16u * (64u / lps);
+          const double per_dest = 4.0 * g * ((double)f->n_arcs / (double)n) / (double)nb;
+          uint32_t umax = per_dest <= 0.8 * mv.stg ? 4u : 2u;
+          if (const char* e = std::getenv("WFST_SSSP_UMAX")) umax = std::atoi(e) >= 4 ? 4u : 2u;
+          sv.res_lps_umax = lps | (umax << 8);
+        }
         sv.mb_dyn = (size_t)nb * mv.stg * sizeof(uint2) + 3u * (size_t)nb * sizeof(uint32_t);
         sv.res_dyn = res_lds_bytes(sv.log, nb, mv.stg);
       } else {

@@ -33,6 +33,8 @@ constexpr uint32_t RS_MU = 4;       // 16-byte message loads a lane keeps in fli
 constexpr uint32_t FLAG_RES_ABORT = 0xAB0u;  // activity flag of a launch that gave up waiting
 constexpr uint32_t RS_MAX_SWEEP = 60000;     // tag = (sweep + 1) << 16 | level
 constexpr uint32_t RS_LEVEL_CAP = 65000;
+constexpr uint32_t RS_STG_MAX = 48;  // staging slots per destination of a resident launch (LDS permitting)
+constexpr uint32_t RS_DUMMY = 32;    // cursors (and 64 staging slots) that lanes without a candidate use instead of branching
 constexpr uint32_t RS_DYN_BUDGET = 100u * 1024u;  // dynamic LDS (staging + per-destination tables) next to ~57 KB static
 
 typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));
@@ -81,89 +83,98 @@ struct ResScalars {
 static_assert(sizeof(ResScalars) % 16 == 0, "the arrays behind the scalars stay 16-byte aligned");
 constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
   return sizeof(ResScalars) + ((size_t)8 << log) + ((size_t)4 << log) + 16 + ((size_t)2 << log) + ((size_t)4 << log) / 32 +
-         (size_t)nb * stg * 8 + 3 * (size_t)nb * 4;
+         ((size_t)nb * stg + 64) * 8 + (3 * (size_t)nb + RS_DUMMY) * 4;
 }
 
-// One round of a level's expansion: 16 lanes per listed state, U states per 16-lane group (U = 1, 2, 4, 6 by the length of the
-// level's list: a thin level runs the short instances).  No arrays of flags, no branch around a load (a lane without an arc
-// reads arc 0 and drops it — its row's last arc instead, a line the neighbours fetch anyway, was measured 10 us per solve
-// slower), one LDS read per state for the row's bounds.  What a lane keeps per state while its U loads are in flight is the
-// arc, the distance and the hop word: whether it has an arc at all is one bit of a mask, the row's bounds are not kept (a row
-// of more than 16 arcs — none in a fan-out-10 transducer — is finished afterwards, one state at a time, from the bounds in
-// LDS), and the candidates are worked off WFST_RS_BATCH at a time (their LDS atomics issued together), so that only that
-// many slot numbers and encoded distances are alive at once.  The first version (bounds, encoded distance and slot number
-// of all U states alive across the round) spilled from U = 6 on and was 2.5 % (1M states) / 3.8 % (2M) slower at its best
-// U = 5 (profiles/r06c_expand_round.md: U x batch table, same box).  Candidate per arc -> LDS (a state of the same block:
-// its key is lowered at once and it waits for the next level) or the destination's staging slots.  l_cur[d] counts the
-// round's messages for destination d; one that finds the slots full is stored directly at its place in the region.
-// Returns nonzero if this lane sent anything.
+// One round of a level's expansion: `lps` lanes per listed state (2 .. 8, chosen per FST from its out-degrees: MboxPlan::lps),
+// each lane fetching TWO arcs in one 16-byte load, U states per lane group in flight (U = 1, 2, 4, UMAX by the length of the
+// level's list: a thin level runs the short instances).  A wave holds 64 / lps groups (the lanes left over idle); rows of more
+// than 2 lps arcs are finished afterwards, one state at a time, from the bounds in LDS.  No arrays of flags, no branch around a
+// load (a lane without an arc reads arc 0 and drops it; a lane whose second arc lies beyond its row reads one arc too many and
+// drops it: the arrays behind `wn` in the FST's arena keep the last row's overshoot inside the allocation).  What a lane
+// keeps per state while its U loads are in flight is the two arcs, the distance and the hop word; whether it has arcs is two
+// bits of a mask.  History (profiles/r06c_expand_round.md, r06g_lanes_per_state.md): 16 lanes x one 8-byte arc, U = 6, was
+// 248 us at 1M states where 5 lanes x two arcs, U = 4 (fan-out 10: 94 % of the lanes busy instead of 62 %, 48 states in
+// flight per wave instead of 24 for fewer registers) is 236: the round is a chain of latencies, and what it is worth is the
+// number of rows in flight.  Candidate per arc -> LDS (a state of the same block: its key is lowered at once and it waits
+// for the next level) or the destination's staging slots.  l_cur[d] counts the round's messages for destination d; one
+// that finds the slots full is stored directly at its place in the region.  Returns nonzero if this lane sent anything.
 template <uint32_t LOG, uint32_t U>
-__device__ __forceinline__ uint32_t rs_expand_round(uint32_t r0, uint32_t an, uint32_t grp, uint32_t sub, const uint2* __restrict__ wn,
-                                                    const uint16_t* a_state, unsigned long long* lkey, uint32_t* l_pend, const uint32_t* l_off,
-                                                    uint32_t j, uint32_t* l_cur, const uint32_t* l_base, uint2* l_stage, uint32_t stg,
-                                                    const uint32_t* l_roff_out, unsigned long long* __restrict__ msgs_out,
-                                                    uint32_t* __restrict__ pad) {
-  constexpr uint32_t HOP_BITS = 32 - LOG, G = MB_THREADS / 16;
-  if (!__any(r0 + grp < an)) return 0u;  // (a lane's first state is its lowest: none there, none at all)
-  uint2 a[U];
+__device__ __forceinline__ uint32_t rs_expand_round(uint32_t LPS, uint32_t G, uint32_t r0, uint32_t an, uint32_t grp, uint32_t sub, const uint2* __restrict__ wn,
+                                                     const uint16_t* a_state, unsigned long long* lkey, uint32_t* l_pend, const uint32_t* l_off,
+                                                     uint32_t j, uint32_t* l_cur, const uint32_t* l_base, uint2* l_stage, uint32_t stg,
+                                                     const uint32_t* l_roff_out, unsigned long long* __restrict__ msgs_out,
+                                                     uint32_t* __restrict__ pad) {
+  constexpr uint32_t HOP_BITS = 32 - LOG, B = 1u << LOG;  // (G = groups per workgroup; the idle lanes of a wave carry a grp beyond every list)
+  if (!__any(r0 + grp < an)) return 0u;
+  struct __attribute__((packed, aligned(8))) Arc2 {
+    rs_u32x4 v;
+  };
+  rs_u32x4 a[U];
   float d[U];
   uint32_t hs[U], vmask = 0, lmask = 0, ovf = 0;
   for (uint32_t u = 0; u < U; ++u) {
     const uint32_t e = r0 + grp + G * u;
-    const bool has = e < an;
+    const bool has = e < an;  // (e wraps for an idle lane: grp = 2^31)
     const uint32_t tl = a_state[has ? e : r0];
     const unsigned long long k = lkey[tl];
     const uint32_t b = l_off[tl], en = l_off[tl + 1];
     const uint32_t h1 = (uint32_t)k + 1u;
     d[u] = dec_f32((uint32_t)(k >> 32));
     hs[u] = h1 << LOG;
-    const bool valid = has && b + sub < en;
-    vmask |= (valid ? 1u : 0u) << u;
-    lmask |= (has && en - b > 16u ? 1u : 0u) << u;
-    ovf |= valid ? h1 >> HOP_BITS : 0u;
-    a[u] = wn[valid ? b + sub : 0u];
+    const uint32_t i0 = b + 2u * sub;
+    const bool v0 = has && i0 < en, v1 = has && i0 + 1u < en;
+    vmask |= ((v0 ? 1u : 0u) | (v1 ? 2u : 0u)) << (2u * u);
+    lmask |= (has && en - b > 2u * LPS ? 1u : 0u) << u;
+    ovf |= v0 ? h1 >> HOP_BITS : 0u;
+    a[u] = ((const Arc2*)(wn + (v0 ? i0 : 0u)))->v;
   }
   if (ovf) *pad = 1u;  // hop count beyond the message format: the host refuses the result
   uint32_t sent = 0;
-  // the candidates, in two halves (only H slot numbers and encoded distances alive at once); inside a half the LDS atomics
-  // are issued together and waited for once
-#ifndef WFST_RS_BATCH
-#define WFST_RS_BATCH 2
-#endif
-  constexpr uint32_t B = 1u << LOG, H = U < WFST_RS_BATCH ? U : WFST_RS_BATCH;
-  for (uint32_t u0 = 0; u0 < U; u0 += H) {
-    uint32_t enc[H], slot[H];
-    for (uint32_t h = 0; h < H; ++h) {
-      const uint32_t u = u0 + h;
-      slot[h] = 0xFFFFFFFFu;
-      enc[h] = 0;
-      if (u < U) {
-        const float c = (d[u] + __uint_as_float(a[u].x)) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
-        enc[h] = enc_f32(c);
-        const bool valid = ((vmask >> u) & 1u) != 0u && c < INF;   // +inf never improves (shortest_path.rs:226)
-        if (valid && (a[u].y >> LOG) == j) {  // same block: never leaves LDS; the state waits for the next level
-          const uint32_t tl_ = a[u].y & (B - 1u);
-          const unsigned long long c_ = ((unsigned long long)enc[h] << 32) | (hs[u] >> LOG);
-          if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
-        } else if (valid) {
-          slot[h] = atomicAdd(&l_cur[a[u].y >> LOG], 1u);
-        }
+  // The two candidates of a state together (their LDS atomics are issued before either is waited for), and WITHOUT a branch:
+  // the round is bound by instruction issue (~56 instructions per candidate in the branchy form, a third of them exec-mask
+  // bookkeeping), so a lane without a candidate for another block counts on a dummy cursor and stages into a dummy slot of its
+  // own instead of jumping around the code; the one branch left is the candidate for a state of this very block (LDS
+  // atomicMin at once: sent to itself through region (j -> j) it was 85 us in ONE region of the dense level — arc 0 of every
+  // state of the benchmark's transducer stays in the block, and a region is read by four lanes).  Distances on this path are
+  // sums of non-negative weights: enc_f32 is "set the sign bit".
+  const uint32_t nb_ = (uint32_t)(l_base - l_cur);  // (the three per-destination tables are nb words each, + RS_DUMMY)
+  const uint32_t lane31 = threadIdx.x & (RS_DUMMY - 1u);
+  for (uint32_t u = 0; u < U; ++u) {
+    const uint32_t w_[2] = {a[u].x, a[u].z}, nx[2] = {a[u].y, a[u].w};
+    uint32_t enc[2], slot[2], vl = 0;
+    for (uint32_t h = 0; h < 2; ++h) {
+      const float c = (d[u] + __uint_as_float(w_[h])) + 0.0f;  // w1 (x) w2 = f32 add (tropical_weight.rs:60-70)
+      enc[h] = __float_as_uint(c) | 0x80000000u;
+      const bool valid = ((vmask >> (2u * u + h)) & 1u) != 0u && c < INF;  // +inf never improves (shortest_path.rs:226)
+      const bool local = valid && (nx[h] >> LOG) == j, remote = valid && !local;
+      vl |= (remote ? 1u : 0u) << h;
+      slot[h] = atomicAdd(&l_cur[remote ? nx[h] >> LOG : 2u * nb_ + lane31], 1u);
+      if (local) {  // same block: never leaves LDS; the state waits for the next level
+        const uint32_t tl_ = nx[h] & (B - 1u);
+        const unsigned long long c_ = ((unsigned long long)enc[h] << 32) | (hs[u] >> LOG);
+        if (c_ < atomicMin(&lkey[tl_], c_)) atomicOr(&l_pend[tl_ >> 5], 1u << (tl_ & 31u));
       }
     }
-    for (uint32_t h = 0; h < H; ++h) {
-      const uint32_t u = u0 + h;
-      if (u < U) {
-        const uint32_t db = a[u].y >> LOG;
-        const uint2 msg = make_uint2(hs[u] | (a[u].y & (B - 1u)), enc[h]);
-        if (slot[h] < stg) l_stage[db * stg + slot[h]] = msg;
-        else if (slot[h] != 0xFFFFFFFFu)
-          __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + slot[h]], ((unsigned long long)msg.y << 32) | msg.x, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        sent |= ~slot[h];
+    bool over = false;
+    for (uint32_t h = 0; h < 2; ++h) {
+      const bool valid = ((vl >> h) & 1u) != 0u;
+      const uint32_t db = nx[h] >> LOG;
+      const bool fits = valid && slot[h] < stg;
+      over |= valid && !fits;
+      l_stage[fits ? __umul24(db, stg) + slot[h] : __umul24(nb_, stg) + (threadIdx.x & 63u)] = make_uint2(hs[u] | (nx[h] & (B - 1u)), enc[h]);
+    }
+    sent |= vl;
+    if (__any(over)) {  // (staging slots full: stored directly at its place in the region)
+      for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t db = nx[h] >> LOG;
+        if (((vl >> h) & 1u) != 0u && slot[h] >= stg)
+          __hip_atomic_store(&msgs_out[l_roff_out[db] + l_base[db] + slot[h]], ((unsigned long long)enc[h] << 32) | hs[u] | (nx[h] & (B - 1u)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-  // rows of more than 16 arcs: the rest of each, state by state (uniform per 16-lane group; the wave stays together)
+  // rows of more than 2 LPS arcs: the rest of each, state by state (uniform per lane group; the wave stays together)
   if (__any(lmask != 0u)) {
     for (uint32_t u = 0; u < U; ++u) {
       if (!__any(((lmask >> u) & 1u) != 0u)) continue;
@@ -171,7 +182,7 @@ __device__ __forceinline__ uint32_t rs_expand_round(uint32_t r0, uint32_t an, ui
       const uint32_t e = r0 + grp + G * u;
       const uint32_t tl = a_state[lng ? e : r0];
       const uint32_t en = lng ? l_off[tl + 1] : 0u;
-      uint32_t i = lng ? l_off[tl] + 16u + sub : 0u;
+      uint32_t i = lng ? l_off[tl] + 2u * LPS + sub : 0u;
       while (__any(i < en)) {
         const uint2 ar = wn[i < en ? i : 0u];
         const float c = (d[u] + __uint_as_float(ar.x)) + 0.0f;
@@ -189,7 +200,7 @@ __device__ __forceinline__ uint32_t rs_expand_round(uint32_t r0, uint32_t an, ui
             sent |= 1u;
           }
         }
-        i += 16u;
+        i += LPS;
       }
     }
   }
@@ -201,7 +212,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
                                                                         uint64_t* __restrict__ key, MboxView mb, ResView rv, uint32_t par_in,
                                                                         uint32_t n, uint32_t* __restrict__ improved_ring, Ctl* __restrict__ ctl,
                                                                         uint32_t sweep, float delta, uint32_t near_low, uint32_t narrow_t,
-                                                                        uint32_t max_levels) {
+                                                                        uint32_t max_levels, uint32_t lps_umax) {
   constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG, MB_HOP_BITS = 32 - LOG, NW_SEG = MB_B;
   extern __shared__ __align__(16) unsigned char mb_dyn[];
   ResScalars& sc_ = *(ResScalars*)mb_dyn;
@@ -220,9 +231,9 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t j = blockIdx.x, nb = mb.nb, stg = mb.stg;
   uint2* const l_stage = (uint2*)(l_pend + PW);                  // [nb * stg]
-  uint32_t* const l_roff_out = (uint32_t*)(l_stage + nb * stg);  // [nb] first message slot of region (j -> d)
-  uint32_t* const l_cur = l_roff_out + nb;                       // [nb]
-  uint32_t* const l_base = l_cur + nb;                           // [nb]
+  uint32_t* const l_roff_out = (uint32_t*)(l_stage + nb * stg + 64);  // [nb] first message slot of region (j -> d)
+  uint32_t* const l_cur = l_roff_out + nb;                            // [nb]
+  uint32_t* const l_base = l_cur + nb;                                // [nb] (+ RS_DUMMY cursors behind it)
   const uint32_t s0 = j << MB_LOG;
   uint32_t* improved = improved_ring + (sweep % IMP_RING);
   const uint32_t reg = tid / MB_LPR, q = tid % MB_LPR;
@@ -493,23 +504,20 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
 
     // ---------------- expansion (rs_expand_round), messages into the regions of level lvl + 1 (write-through stores)
     {
-      const uint32_t sub = tid & 15u, grp = tid >> 4;
+      // lanes per listed state and states per lane group of the widest round: the host's choice per FST and launch
+      // (MboxPlan::lps; umax = 4 unless a round of 4 G states would overrun the staging slots, see sssp.hip)
+      const uint32_t LPS = lps_umax & 0xFFu, UMAX = lps_umax >> 8, GPW = 64u / LPS;  // GPW groups per wave (a group never straddles two waves)
+      const uint32_t sub = lane % LPS, grp = lane / LPS < GPW ? (tid >> 6) * GPW + lane / LPS : 0x80000000u;
       unsigned long long* __restrict__ msgs_out = (unsigned long long*)rv.msgs[ps ^ 1u];
       const __amdgpu_buffer_rsrc_t rs_out = ps ? rs0 : rs1;
-#ifndef WFST_RS_UMAX
-#define WFST_RS_UMAX 6
-#endif
-      constexpr uint32_t G = MB_THREADS / 16, UMAX = WFST_RS_UMAX, ROUND = G * UMAX;  // (UMAX: states a 16-lane group relaxes at once in a wide level)
+      const uint32_t G = (MB_THREADS / 64u) * GPW, ROUND = G * UMAX;
       static_assert(MB_THREADS == 1024, "a resident workgroup is sixteen waves");
-      static_assert(UMAX >= 4u && UMAX <= 8u, "the one-round ladder below is 1 / 2 / 4 / UMAX states per group");
-      static_assert(UMAX <= 32u, "one bit per state in the masks of rs_expand_round");
       const uint32_t an_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)an);
       uint32_t sent = 0;
-#define RS_EXPAND(U_, r0_) rs_expand_round<LOG, U_>(r0_, an_u, grp, sub, wn, a_state, lkey, l_pend, l_off, j, l_cur, l_base, l_stage, stg, l_roff_out, msgs_out, &ctl->pad)
+#define RS_EXPAND(U_, r0_) rs_expand_round<LOG, U_>(LPS, G, r0_, an_u, grp, sub, wn, a_state, lkey, l_pend, l_off, j, l_cur, l_base, l_stage, stg, l_roff_out, msgs_out, &ctl->pad)
       if (an_u <= ROUND) {
         // one round (every level but a band's widest): the staged runs start at the regions' first slots
-        if (UMAX > 4u && an_u > 4u * G) sent = RS_EXPAND(UMAX, 0u);
-        else if (an_u > 2u * G) sent = RS_EXPAND(4, 0u);
+        if (an_u > 2u * G) sent = RS_EXPAND(4, 0u);  // (only with UMAX = 4)
         else if (an_u > G) sent = RS_EXPAND(2, 0u);
         else if (an_u) sent = RS_EXPAND(1, 0u);
         __syncthreads();
@@ -532,7 +540,8 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       } else {
         // several rounds: after each, the staged runs go out behind what the earlier rounds wrote (l_base) and the counts start again
         for (uint32_t r0 = 0; r0 < an_u; r0 += ROUND) {
-          sent |= RS_EXPAND(UMAX, r0);
+          if (UMAX >= 4u) sent |= RS_EXPAND(4, r0);
+          else sent |= RS_EXPAND(2, r0);
           __syncthreads();
           if (reg < nb) {
             const uint32_t first = l_base[reg], cnt = l_cur[reg], last = first + min(cnt, stg), ro = l_roff_out[reg];
