@@ -29,7 +29,10 @@
 constexpr uint32_t RS_HDR = 2;      // 8-byte units of a region header
 constexpr uint32_t RS_FIRST = 6;    // messages sharing the header's 64-byte sector
 constexpr uint32_t RS_ALIGN = 8;    // regions start on 64-byte boundaries (units)
-constexpr uint32_t RS_MU = 4;       // 16-byte message loads a lane keeps in flight while it reads the rest of a region
+#ifndef WFST_RS_MU
+#define WFST_RS_MU 4
+#endif
+constexpr uint32_t RS_MU = WFST_RS_MU;  // 16-byte message loads a lane keeps in flight while it reads the rest of a region
 constexpr uint32_t FLAG_RES_ABORT = 0xAB0u;  // activity flag of a launch that gave up waiting
 constexpr uint32_t RS_MAX_SWEEP = 60000;     // tag = (sweep + 1) << 16 | level
 constexpr uint32_t RS_LEVEL_CAP = 65000;
@@ -359,6 +362,15 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       uint32_t t_nf = 0, t_ps = 0;
       uint32_t spins = 0;
       unsigned long long t0 = 0;
+      // Nobody's header can be here sooner than a write-through store takes to land and a load to come back (~2 us: the
+      // exchange micro-benchmark's floor), and a poll that finds nothing is nb sector reads queued in front of the other
+      // workgroups' message stores: sleep through the part of the wait that cannot end (56 x 64 clocks; 0 / 8 / 16 / 32 / 48 /
+      // 64 / 96: 236.7 / 236.6 / 236.6 / 231.4 / 228.6 / 226.8 / 233.8 us per 1M-state solve, same box; the sleep between
+      // two polls, 1 .. 16 or growing, makes no difference)
+#ifndef WFST_RS_PRESLEEP
+#define WFST_RS_PRESLEEP 56
+#endif
+      if (WFST_RS_PRESLEEP) __builtin_amdgcn_s_sleep(WFST_RS_PRESLEEP);
       for (;;) {
         rs_u32x4 v = {0u, 0u, 0u, 0u};
         if (pend) v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(hdr_b + q * 16u), 0, 16);
@@ -402,7 +414,10 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(1);
+#ifndef WFST_RS_POLLSLEEP
+#define WFST_RS_POLLSLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(WFST_RS_POLLSLEEP);
       }
       // the senders' figures: one header per 4 lanes (the other lanes hold zeros).  (245 LDS atomics on one address instead of
       // these shifts cost ~1 us per level: measured)
