@@ -285,7 +285,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
                                             uint64_t* __restrict__ key, const MboxView& mb, Ctl* __restrict__ ctl,
                                             uint32_t* __restrict__ improved, uint32_t sweep, float tau, uint32_t far_total,
                                             uint32_t near_low, uint32_t profile, uint32_t wl_n, bool waits, uint32_t bfar,
-                                            uint4* wl, uint32_t* s_n /*[4]: list sizes [0..1], found beyond the threshold [2]*/,
+                                            uint4* wl, uint32_t* s_n /*[8]: list sizes [0..2] (level mod 3), found beyond the threshold [3], left waiting [4]*/,
                                             uint32_t par_out, const uint32_t* l_roff_out, uint32_t* l_cur, uint32_t* l_cap) {
   constexpr uint32_t MB_LOG = LOG, MB_B = 1u << LOG, MB_HOP_BITS = 32 - LOG, NW_SEG = MB_B;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, j = blockIdx.x, nb = mb.nb;
@@ -309,7 +309,8 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     s_n[0] = min(wl_n, NW_CAP);
     s_n[1] = 0;
     s_n[2] = 0;
-    s_n[3] = (waits || wl_n > NW_CAP) ? 1u : 0u;  // something is left waiting after this launch
+    s_n[3] = 0;
+    s_n[4] = (waits || wl_n > NW_CAP) ? 1u : 0u;  // something is left waiting after this launch
     if (wl_n) mb.wl_cnt[j] = 0;
   }
   if (wl_n == 0) {  // (uniform) nothing to follow; whoever waits in this block's masks waits for a WIDE sweep
@@ -320,13 +321,20 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     return;
   }
   __syncthreads();
-  uint32_t cur = 0, prev_n = 0, prev2_n = 0, far_new = 0;
+  // (the two lists alternate; their COUNTERS rotate through three words, so that the one a level will fill next can be zeroed a
+  // level ahead and a level needs ONE barrier: a hop of the tail is ~2 us, two trips and this)
+  uint32_t cur = 0, cnt_i = 0, prev_n = 0, prev2_n = 0, far_new = 0;
   bool left_any = false;
   unsigned long long p_arcs = 0, p_states = 0;
   bool grew = false;
   for (uint32_t level = 0;; ++level) {
-    const uint32_t n_lv = min(s_n[cur], NW_CAP);
-    const uint32_t far_seen = s_n[2];
+    const uint32_t n_lv = min(s_n[cnt_i], NW_CAP);
+    const uint32_t far_seen = s_n[3];
+    const uint32_t cnt_o = cnt_i == 2u ? 0u : cnt_i + 1u, cnt_z = cnt_o == 2u ? 0u : cnt_o + 1u;
+    if (tid == 0) s_n[cnt_z] = 0;  // (last level's size: everybody read it before that level's barrier; next level's output)
+#ifdef WFST_NW_TRACE
+    if (mb.dbg && tid == 0 && sweep < MB_DBG_SWEEPS && level < 13) mb.dbg[((size_t)sweep * nb + j) * 16 + 2 + level] = (wall_clock64() << 12) | min(n_lv, 4095u);
+#endif
     if (n_lv == 0) break;
     // (8192-state blocks: a workgroup's share of the hand-over is twice as long — with the 4096-state limit the tail of a 1M-state
     // solve on half the device bounced back to the WIDE levels twice: 385 -> 350 us, 5 -> 3 launches; 2M states unchanged)
@@ -344,7 +352,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     }
     const uint4* __restrict__ in = wl + cur * NW_CAP;
     uint4* __restrict__ out = wl + (cur ^ 1u) * NW_CAP;
-    uint32_t* n_out = &s_n[cur ^ 1u];
+    uint32_t* n_out = &s_n[cnt_o];
     for (uint32_t r0 = 0; r0 < n_lv; r0 += (MB_THREADS / 16) * NW_UNROLL) {
       uint32_t i_[NW_UNROLL], end_[NW_UNROLL], h1_[NW_UNROLL];
       float d_[NW_UNROLL];
@@ -431,27 +439,26 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
       }
     }
     // what this level found beyond the threshold, for the shrink rule of the next levels
-    {
+    if (__any(far_new != 0u)) {  // (never in the tail: tau is +inf there)
       uint32_t f = far_new;
       for (int d = 32; d >= 1; d >>= 1) f += __shfl_xor(f, d);
-      if (lane == 0 && f) atomicAdd(&s_n[2], f);
+      if (lane == 0 && f) atomicAdd(&s_n[3], f);
       far_new = 0;
     }
     __syncthreads();  // the next list is complete; the current one is free
-    if (tid == 0) s_n[cur] = 0;
     prev2_n = prev_n;
     prev_n = n_lv;
     cur ^= 1u;
-    __syncthreads();
+    cnt_i = cnt_o;
   }
   // whatever is still listed waits for the next WIDE sweep (near states: it expands them at once)
   {
-    const uint32_t left = min(s_n[cur], NW_CAP);
+    const uint32_t left = min(s_n[cnt_i], NW_CAP);
     const uint4* __restrict__ in = wl + cur * NW_CAP;
     for (uint32_t e = tid; e < left; e += MB_THREADS) mbox_make_wait<LOG>(mb, in[e].x, in[e].z, false);
-    if (__any(left_any || left != 0u) && lane == 0) s_n[3] = 1u;
+    if (__any(left_any || left != 0u) && lane == 0) s_n[4] = 1u;
     __syncthreads();
-    if (tid == 0) atomicMax(improved, s_n[3] ? FLAG_NARROW_LEFT : FLAG_NARROW_CLEAN);
+    if (tid == 0) atomicMax(improved, s_n[4] ? FLAG_NARROW_LEFT : FLAG_NARROW_CLEAN);
     if (head) {  // the messages of the head: counts of the regions, like a WIDE sweep's publish
       bool any = false;
       for (uint32_t d = tid; d < nb; d += MB_THREADS) {
@@ -465,7 +472,7 @@ __device__ __forceinline__ void mbox_narrow(const uint32_t* __restrict__ offsets
     // otherwise the next sweep sees no near activations and widens the band.  High word: the states waiting beyond the
     // threshold in this block before the launch, and those this workgroup has made wait anywhere.
     if (tid == 0) {
-      const unsigned long long add = ((unsigned long long)(bfar + s_n[2]) << 32) | (grew ? near_low : 0u);
+      const unsigned long long add = ((unsigned long long)(bfar + s_n[3]) << 32) | (grew ? near_low : 0u);
       if (add) atomicAdd(nf, add);
     }
   }
@@ -504,7 +511,7 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_kernel(const uint32_t* _
   __shared__ uint16_t a_state[MB_B];  // states expanded in this sweep
   __shared__ uint32_t s_wany[MB_THREADS / 64];
   __shared__ uint32_t s_an, s_sent, s_npend, s_mind, s_nfar;
-  __shared__ uint32_t s_nw[4];
+  __shared__ uint32_t s_nw[8];
   __shared__ unsigned long long s_prof_arcs;
   constexpr uint32_t R = MB_B / MB_THREADS;  // states per thread
   constexpr uint32_t PW = MB_B / 32;         // pending words per block

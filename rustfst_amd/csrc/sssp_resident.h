@@ -79,9 +79,9 @@ __device__ __forceinline__ uint32_t quad_first(uint32_t v) {  // lane 4k's value
 struct ResScalars {
   unsigned long long tot[2][2];  // per level parity: near | far << 32, waiting | senders << 32 (sums over the headers)
   uint32_t lv[2][6];             // per level parity: an, sent, npend, nfar, spare, spare
-  uint32_t nw[4];
+  uint32_t nw[8];
   uint32_t abort_;
-  uint32_t pad_[7];
+  uint32_t pad_[3];
 };
 static_assert(sizeof(ResScalars) % 16 == 0, "the arrays behind the scalars stay 16-byte aligned");
 constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
@@ -468,6 +468,9 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       else s_lv[ps ^ 1u][tid - 2] = 0u;
     }
     const bool collect = mode == MODE_COLLECT;
+#ifdef WFST_RS_STAMP_ALT
+    RS_STAMP(1);
+#endif
 
     // ---------------- the marked states: near ones listed (and unmarked), far ones keep waiting
     {
@@ -500,7 +503,9 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       if (n_far && lane == 0) atomicAdd(&s_lv[ps][3], n_far);
     }
     __syncthreads();  // B2
+#ifndef WFST_RS_STAMP_ALT
     RS_STAMP(1);
+#endif
     const uint32_t an = s_lv[ps][0];
     last_an = an;
     if (collect) {
