@@ -1485,6 +1485,33 @@ def test_transpose_through_the_plan_on_ragged_rows(oracle, monkeypatch, n, max_d
     assert tied > 0
 
 
+@pytest.mark.parametrize("lps,umax", [("2", "4"), ("3", "2"), ("5", "4"), ("6", "2"), ("7", "4"), ("8", "2"), (None, None)],
+                         ids=["2x4", "3x2", "5x4", "6x2", "7x4", "8x2", "from_the_degrees"])
+def test_resident_rounds_with_every_lane_group_size(oracle, monkeypatch, lps, umax):
+    """rs_expand_round (sssp_resident.h) with 2 .. 8 lanes per listed state and 2 or 4 states per lane group, on rows of 0 .. 24
+    arcs: with few lanes most rows overflow the first pass (2 x lps arcs) and are finished by the long-row pass, with many
+    lanes some lanes of a group have no arc, and a lane's second arc may lie beyond its row.  Distances, hop counts and the
+    path bit-identical to the canonical oracle under the resident launches, twice per handle (the second solve runs as one
+    predicted batch), and — last case — with the group size the plan derives from the out-degrees itself (mbox_degree_kernel)."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "1")
+    if lps is not None:
+        monkeypatch.setenv("WFST_SSSP_LPS", lps)
+        monkeypatch.setenv("WFST_SSSP_UMAX", umax)
+    ctx = rustfst_amd.Context(0)
+    t = _ragged_transducer(120_000, 24, seed=5)
+    rng = np.random.default_rng(9)
+    t["arcs"]["weight"] = (rng.integers(0, 2048, len(t["arcs"])).astype(np.float32) / np.float32(256.0)).astype(np.float32)
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    assert np.isfinite(can.distance).sum() > 50_000
+    d = to_device(t, ctx)
+    for q in range(3):
+        dist, hops = d.shortest_distance(want_hops=True)
+        assert ctx.stats()["relax_kernel"] == 2 and ctx.stats()["resident_aborts"] == 0
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"lanes {lps}, states per group {umax}, query {q}")
+
+
 @pytest.mark.parametrize("plan", ["1", "0"], ids=["through_the_mailbox_plan", "two_atomic_passes"])
 def test_transpose_is_built_in_the_second_query(oracle, monkeypatch, plan):
     """The transpose for the backtrace is built inside the SECOND shortest_path query of a large FST (sssp.hip: reverse_csr):
