@@ -90,7 +90,7 @@ constexpr size_t res_lds_bytes(uint32_t log, uint32_t nb, uint32_t stg) {
 }
 
 // One round of a level's expansion: `lps` lanes per listed state (2 .. 8, chosen per FST from its out-degrees: MboxPlan::lps),
-// each lane fetching TWO arcs in one 16-byte load, U states per lane group in flight (U = 1, 2, 4, UMAX by the length of the
+// each lane fetching TWO arcs in one 16-byte load, U states per lane group in flight (U = 1, 2, 4 by the length of the
 // level's list: a thin level runs the short instances).  A wave holds 64 / lps groups (the lanes left over idle); rows of more
 // than 2 lps arcs are finished afterwards, one state at a time, from the bounds in LDS.  No arrays of flags, no branch around a
 // load (a lane without an arc reads arc 0 and drops it; a lane whose second arc lies beyond its row reads one arc too many and
