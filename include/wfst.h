@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WFST_ABI_VERSION 6 /* 6: wfst_ctx_set_resident_share; 5: wfst_ctx_get_sweep_modes, relax_kernel may be 3, wfst_stats gained tied_choices;
+#define WFST_ABI_VERSION 7 /* 7: wfst_fst_set_start; 6: wfst_ctx_set_resident_share; 5: wfst_ctx_get_sweep_modes, relax_kernel may be 3, wfst_stats gained tied_choices;
                              * 2: wfst_stats gained relax_kernel; 3: wfst_comm_* / wfst_gather_paths_*, ..._batch_packed;
                              * 4: wfst_stats gained resident_aborts, relax_kernel may be 2; wfst_comm_create_host, wfst_gather_records_begin */
 
@@ -243,6 +243,14 @@ wfst_status wfst_reverse(wfst_ctx* ctx, const wfst_fst* fst, wfst_fst** out);
  *      or olabel (OLabelCompare), followed by the reference's property update.  This is what makes an FST
  *      acceptable to wfst_compose (SortedMatcher needs the sorted bit). ---- */
 wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp);
+
+/* ---- set_start on a device-resident handle (MutableFst::set_start, rustfst/src/fst_impls/vector_fst/mutable_fst.rs:35-44;
+ *      FFI vec_fst_set_start, rustfst-ffi/src/fst/vector_fst.rs:26-33): KO "The state {state} doesn't exist" for a state beyond
+ *      the FST, otherwise the start state and the property word change as the reference's do (set_start_properties,
+ *      fst_properties/mutate_properties.rs:7-13); the arcs stay where they are in HBM and everything cached on the handle that
+ *      does not depend on the start state (region plan, transpose, packed arcs) is kept — a shortest_path query per source on
+ *      one resident FST is this call + wfst_shortest_path (ABI 7). ---- */
+wfst_status wfst_fst_set_start(wfst_ctx* ctx, wfst_fst* fst, uint32_t state);
 
 /* ---- fused batch: for each acceptor i: shortest_path(compose(acceptors[i], t)) — the loop a
  * caller writes around the two reference entry points; here one device-resident pipeline.

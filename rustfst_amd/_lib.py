@@ -99,6 +99,7 @@ SYMBOLS = [
     ("wfst_comm_allgather_end", C.c_int, [_vp, _vp]),
     ("wfst_comm_allgatherv", C.c_int, [_vp, _vp, _sz, _vp, _P(_vp), _P(_sz)]),
     ("wfst_fst_tr_sort", C.c_int, [_vp, _vp, C.c_int]),
+    ("wfst_fst_set_start", C.c_int, [_vp, _vp, C.c_uint32]),
     ("wfst_reverse", C.c_int, [_vp, _vp, _P(_vp)]),
     ("wfst_vec_fst_new", C.c_int, [_P(_vp)]),
     ("wfst_vec_fst_destroy", C.c_int, [_vp]),

@@ -437,6 +437,22 @@ wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp) {
   });
 }
 
+wfst_status wfst_fst_set_start(wfst_ctx* ctx, wfst_fst* fst, uint32_t state) {  // mutable_fst.rs:35-44
+  return wrap([&] {
+    if (!ctx || !fst) throw Error("null pointer");
+    if (state >= fst->n_states) throw Error("The state " + std::to_string(state) + " doesn't exist");
+    std::lock_guard<std::mutex> lk(fst->cache_mu);
+    if (fst->start != (int64_t)state) fst->is_string = false;  // (the string o T kernel's input is linear FROM its start state)
+    fst->start = (int64_t)state;
+    fst->props = props::set_start(fst->props);
+    fst->rev_host.reset();  // reverse(fst) marks the old start state final (reverse.rs:80-86)
+    fst->stable_sweeps.store(0, std::memory_order_relaxed);
+    fst->start_moved.store(1, std::memory_order_relaxed);
+    // (what a solve learned about the launch pattern of the LAST source says little about this one: the first query predicts
+    // from it all the same, and a solve that outruns its prediction is continued)
+  });
+}
+
 wfst_status wfst_compose_shortest_path_batch(wfst_ctx* ctx, const wfst_fst* const* acceptors, size_t n,
                                              const wfst_fst* t, const wfst_compose_config* ccfg,
                                              const wfst_shortest_path_config* scfg, wfst_fst** outs,

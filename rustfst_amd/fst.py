@@ -309,6 +309,12 @@ class DeviceFst:
         check(_lib.lib().wfst_fst_tr_sort(self.ctx._h, self._h, 1 if ilabel_cmp else 0), "Error during tr_sort")
         return self
 
+    def set_start(self, state: int) -> "DeviceFst":
+        """MutableFst::set_start (fst_impls/vector_fst/mutable_fst.rs:35-44) on the device-resident handle: the arcs stay in
+        HBM, the derived data that does not depend on the start state stays cached.  KO for a state beyond the FST."""
+        check(_lib.lib().wfst_fst_set_start(self.ctx._h, self._h, int(state)), "Error setting start state")
+        return self
+
     def shortest_distance(self, want_hops: bool = False):
         n = self.num_states
         dist = np.zeros(n, dtype=np.float32)

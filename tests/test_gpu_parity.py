@@ -1485,6 +1485,37 @@ def test_transpose_through_the_plan_on_ragged_rows(oracle, monkeypatch, n, max_d
     assert tied > 0
 
 
+def test_set_start_on_a_resident_handle_queries_from_any_source(oracle, monkeypatch):
+    """wfst_fst_set_start (MutableFst::set_start, mutable_fst.rs:35-44): one resident FST, a shortest-path query from each of
+    several sources — every result bit-identical to the canonical oracle's on an FST built with that start state, the
+    property word as the reference updates it, the derived data of the handle (region plan, transpose) reused; a state beyond
+    the FST is KO with the reference's message.  The launch pattern differs from source to source: solves that outrun the
+    prediction taken from the previous source are continued (no result depends on the prediction)."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "1")
+    ctx = rustfst_amd.Context(0)
+    t = synth.make_transducer(200_000, 8, 64, 0.0, seed=23)
+    d = to_device(t, ctx)
+    for q in range(3):
+        d.shortest_path()  # (plan, transpose and the predicted batch exist before the start state moves)
+    with pytest.raises(Exception, match="doesn't exist"):
+        d.set_start(200_000)
+    rng = np.random.default_rng(4)
+    for src in [int(x) for x in rng.integers(0, 200_000, 5)] + [0, 199_999]:
+        d.set_start(src)
+        ts = dict(t, start=src)
+        o = to_oracle(oracle, ts)
+        can = o.shortest_path_canonical()
+        for q in range(2):
+            got = d.shortest_path()
+            assert ctx.stats()["relax_kernel"] == 2
+            assert_flat_identical(got.to_flat(), can.to_flat(), f"source {src}, query {q}")
+        dist, hops = d.shortest_distance(want_hops=True)
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+        # set_start_properties (mutate_properties.rs:7-13) keeps everything but what is said relative to the start state
+        assert d.properties == int(t["props"]) & ~int(synth.INITIAL_CYCLIC | synth.ACCESSIBLE)
+
+
 @pytest.mark.parametrize("lps,umax", [("2", "4"), ("3", "2"), ("5", "4"), ("6", "2"), ("7", "4"), ("8", "2"), (None, None)],
                          ids=["2x4", "3x2", "5x4", "6x2", "7x4", "8x2", "from_the_degrees"])
 def test_resident_rounds_with_every_lane_group_size(oracle, monkeypatch, lps, umax):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(wfst_lib):
         assert hasattr(wfst_lib, n), f"libwfst_amd.so does not export {n}"
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert set(names) == bound, f"ctypes binding out of sync with wfst.h: {set(names) ^ bound}"
-    assert wfst_lib.wfst_abi_version() == 6
+    assert wfst_lib.wfst_abi_version() == 7
 
 
 def test_no_torch_types_in_the_abi():
