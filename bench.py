@@ -752,6 +752,42 @@ def main():
             dt.set_start(s1_start)
             for _ in range(3):
                 dt.shortest_path()
+        # ------------------------------------------------------------------ two queries at once: the resident lease of a device has
+        # two units, and a context set to half the device takes one (tools/two_queries.py)
+        two_q = None
+        if rank == 0 and not args.no_extras:
+            ch1, ch2 = rustfst_amd.Context(local_rank), rustfst_amd.Context(local_rank)
+            ch1.set_resident_share(1)
+            ch2.set_resident_share(1)
+            for _ in range(5):
+                ja, jb = dt.shortest_path_begin(ctx=ch1), dt.shortest_path_begin(ctx=ch2)
+                ra, rb = ja.finish(), jb.finish()
+            n_pairs = 100
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            for _ in range(n_pairs):
+                ja, jb = dt.shortest_path_begin(ctx=ch1), dt.shortest_path_begin(ctx=ch2)
+                ja.finish()
+                jb.finish()
+            s_pair = (time.perf_counter() - c0) / n_pairs
+            c0 = time.perf_counter()
+            for _ in range(n_pairs):
+                dt.shortest_path()
+                dt.shortest_path()
+            s_seq = (time.perf_counter() - c0) / n_pairs
+            same_path = ra.to_flat()["arcs"].tobytes() == rb.to_flat()["arcs"].tobytes() == dt.shortest_path().to_flat()["arcs"].tobytes()
+            if not same_path:
+                raise SystemExit("bench: two concurrent half-device queries returned another path than the whole-device query")
+            two_q = {"workload": "two shortest_path(T) queries in flight at once on two contexts with wfst_ctx_set_resident_share(ctx, 1) "
+                                 "(half the device each; begin, begin, end, end from one host thread; the same handle and source: what is "
+                                 "measured is the overlap) against the same two queries one after the other on the whole device",
+                     "ms_per_pair": round(1e3 * s_pair, 4), "queries_per_s": round(2 / s_pair, 1),
+                     "one_after_the_other_ms_per_pair": round(1e3 * s_seq, 4), "one_after_the_other_queries_per_s": round(2 / s_seq, 1),
+                     "resident_aborts": int(ch1.stats()["resident_aborts"] + ch2.stats()["resident_aborts"]),
+                     "relax_kernels": [int(ch1.stats()["relax_kernel"]), int(ch2.stats()["relax_kernel"])], "paths_identical": True}
+            del ja, jb, ra, rb, ch1, ch2
+            for _ in range(3):
+                dt.shortest_path()
         config2 = None
         if rank == 0 and not args.no_extras:
             t2 = synth.make_transducer(100_000, args.fanout, args.sigma, 0.0, seed=2)
@@ -1100,6 +1136,7 @@ def main():
             "config5": config5, "batch_sweep": batch_sweep, "step_512_acceptors": step_512,
             "config2_single_string": config2,
             "varied_sources": varied,
+            "two_queries_half_share": two_q,
             "reference_harness_split": harness,
             "roofline": roofline, "roofline_vs_size": rvs, "batch_kernel": batch_kernel, "cpu_baseline": cpu_baseline,
         }

@@ -374,9 +374,13 @@ wfst_status wfst_ctx_set_tie_order(wfst_ctx* ctx, int reference_order);
  * 245 workgroups for a 1M-state FST — the fastest solve, and nothing else of any size fits beside it: a kernel that holds
  * more than a dozen compute units when the launch arrives makes it WAIT (a 512-string fused batch holds 64 of them for
  * ~0.3 ms).  1 = half the device: blocks of 8192 states where that brings the workgroup count to at most half the compute
- * units (1M states: 123), one launch per level where it does not — the solve alone is ~1.6 x slower (1M states: 0.41 vs
- * 0.25 ms of kernels) and runs BESIDE a batch of that size instead of behind it.  The request class decides: a server
- * whose shortest_path queries share the GPU with large fused batches sets 1 on the context that runs the queries.
+ * units (1M states: 123), one launch per level where it does not — the solve alone is ~1.4 x slower (1M states: 0.32 vs
+ * 0.22 ms of kernels) and runs BESIDE a batch of that size instead of behind it — or beside ANOTHER half-device query: the
+ * device's resident lease has two units, a whole-device solve takes both, a half-device solve one, so two contexts set to 1
+ * answer two queries at the same time (1M states: 4.8 k queries/s against 3.8 k one after the other; a third concurrent
+ * query, or a whole-device one, takes one launch per level for that solve).  The request class decides: a server whose
+ * shortest_path queries share the GPU with large fused batches, or that answers many queries at once, sets 1 on the contexts
+ * that run the queries.
  * Same results either way (the keys are the fixed point whatever the block size).  The reference has no counterpart: its
  * algorithms run on one host thread (shortest_path.rs:173-239). */
 wfst_status wfst_ctx_set_resident_share(wfst_ctx* ctx, uint32_t share);

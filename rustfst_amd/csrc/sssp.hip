@@ -1037,13 +1037,15 @@ __global__ void sssp_export_kernel(const uint64_t* __restrict__ key, float* __re
   if (hops) hops[s] = k == KEY_INF ? 0xFFFFFFFFu : (uint32_t)k;
 }
 
-// One resident solve per device at a time: a grid that waits for its own workgroups must be resident as a whole, and two
-// such grids started together could each hold half of the CUs.  Inside a process the lease is a flag per device; between
-// processes it is an advisory lock on a file per device (flock, non-blocking: whoever does not get it takes one launch
-// per level for that solve).  Neither covers a tenant that is not this library: the wait limit of the launch does.
+// Resident solves of a device share a lease of TWO units: a grid that waits for its own workgroups must be resident as a
+// whole, so a whole-device grid (one workgroup on ~245 of 256 compute units) takes both units, and a half-device grid
+// (wfst_ctx_set_resident_share(ctx, 1): at most 128 workgroups) takes one — two of those fit the device together, and two
+// contexts that answer queries on half the device each run their solves side by side (tools/two_queries.py).  Inside a
+// process the lease is a counter per device; between processes it is an advisory lock on a file per device, held by a
+// process while any of its solves holds a unit (flock, non-blocking: whoever does not get it takes one launch per level
+// for that solve).  Neither covers a tenant that is not this library: the wait limit of the launch does.
 struct ResidentLease {
-  std::atomic<int>* slot = nullptr;
-  int lock_fd = -1;
+  int held_device = -1, held_units = 0;
   ResidentLease() = default;
   ResidentLease(const ResidentLease&) = delete;
   ResidentLease& operator=(const ResidentLease&) = delete;
@@ -1083,27 +1085,38 @@ struct ResidentLease {
     sl.fd = fd;
     return fd;
   }
-  bool acquire(int device) {
-    static std::atomic<int> busy[64];
-    std::atomic<int>* s = &busy[(unsigned)device & 63u];
-    int expect = 0;
-    if (!s->compare_exchange_strong(expect, 1)) return false;
-    const int fd = device_lock_fd(device);
-    if (fd >= 0 && ::flock(fd, LOCK_EX | LOCK_NB) != 0) {  // another process holds the device's resident slot
-      s->store(0);
-      return false;
+  struct Units { std::mutex mu; int used = 0; int fd = -1; };
+  static Units& units_of(int device) {
+    static Units u[64];
+    return u[(unsigned)device & 63u];
+  }
+  bool acquire(int device, int units = 2) {
+    release();
+    Units& u = units_of(device);
+    std::lock_guard<std::mutex> lk(u.mu);
+    if (u.used + units > 2) return false;
+    if (u.used == 0) {
+      const int fd = device_lock_fd(device);
+      if (fd >= 0 && ::flock(fd, LOCK_EX | LOCK_NB) != 0) return false;  // another process holds the device's resident slot
+      u.fd = fd;
     }
-    lock_fd = fd;
-    slot = s;
+    u.used += units;
+    held_device = device;
+    held_units = units;
     return true;
   }
   void release() {
-    if (slot) {
-      if (lock_fd >= 0) (void)::flock(lock_fd, LOCK_UN);
-      slot->store(0);
+    if (held_units) {
+      Units& u = units_of(held_device);
+      std::lock_guard<std::mutex> lk(u.mu);
+      u.used -= held_units;
+      if (u.used == 0 && u.fd >= 0) {
+        (void)::flock(u.fd, LOCK_UN);
+        u.fd = -1;
+      }
     }
-    lock_fd = -1;
-    slot = nullptr;
+    held_units = 0;
+    held_device = -1;
   }
   ~ResidentLease() { release(); }
 };
@@ -1162,7 +1175,7 @@ struct Solve {
   ResView rv{};
   uint32_t res_max_levels = RS_LEVEL_CAP;
   uint32_t res_lps_umax = 8u | (2u << 8);  // lanes per listed state | states per lane group of the widest round (sssp_resident.h)
-  ResidentLease lease;       // at most one resident solve per device at a time (two half-resident grids would wait for each other)
+  ResidentLease lease;       // units of the device's resident lease this solve holds (2 = whole device, 1 = half: two of those run together)
   // binned levels (sssp_binned.h): the dense levels of the atomic sweeps as an owner-computes pass, chosen per level on the device
   bool binned = false;
   std::shared_ptr<BinPlan> bplan;
@@ -1399,7 +1412,8 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
       else if (nb13 <= half && !std::getenv("WFST_SSSP_LOG12")) log = 13;
       else log = 0;
     }
-    if (want && log && !ctx->profiling && ctx->resident_allowed() && !big_env && sv.lease.acquire(ctx->device)) {
+    if (want && log && !ctx->profiling && ctx->resident_allowed() && !big_env &&
+        sv.lease.acquire(ctx->device, ctx->resident_share == 1u ? 1 : 2)) {
       want_res = true;
       sv.log = log;
     }

@@ -269,12 +269,12 @@ class DeviceFst:
         check(_lib.lib().wfst_shortest_path(self.ctx._h, self._h, cfg, C.byref(out)), "Error computing shortest path")
         return DeviceFst(out, self.ctx)
 
-    def shortest_path_begin(self, config: Optional["ShortestPathConfig"] = None) -> "ShortestPathJob":
-        """Queue shortest_path (nshortest = 1) on this FST's context and return at once
-        (wfst_shortest_path_begin); job.finish() returns what shortest_path() returns."""
+    def shortest_path_begin(self, config: Optional["ShortestPathConfig"] = None, ctx: Optional["Context"] = None) -> "ShortestPathJob":
+        """Queue shortest_path (nshortest = 1) on this FST's context (or on `ctx`: a handle may be queried from several
+        contexts of its device) and return at once (wfst_shortest_path_begin); job.finish() returns what shortest_path() returns."""
         job = C.c_void_p()
         cfg = config._c() if config is not None else None
-        check(_lib.lib().wfst_shortest_path_begin(self.ctx._h, self._h, cfg, C.byref(job)), "Error computing shortest path")
+        check(_lib.lib().wfst_shortest_path_begin((ctx or self.ctx)._h, self._h, cfg, C.byref(job)), "Error computing shortest path")
         return ShortestPathJob(job, self)
 
     def reverse(self) -> "DeviceFst":

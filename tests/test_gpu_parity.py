@@ -886,6 +886,51 @@ def test_resident_share_half_runs_beside_a_512_string_batch(oracle, order):
     assert ctx.stats()["relax_kernel"] == 2
 
 
+def test_two_half_device_queries_run_at_the_same_time(oracle, monkeypatch):
+    """The resident lease of a device has two units (sssp.hip ResidentLease): two contexts set to half the device
+    (wfst_ctx_set_resident_share(ctx, 1)) answer two shortest_path queries — different FSTs, different sources — AT THE SAME TIME,
+    both with resident launches, neither giving up; a third query queued while both are in flight finds no unit and takes one
+    launch per level; a whole-device context finds the lease taken while a half-device query runs.  Every path and every
+    distance bit-identical to the canonical oracle, in both enqueue orders, repeatedly."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "1")
+    ta = synth.make_transducer(300_000, 8, 64, 0.0, seed=31)
+    tb = dict(synth.make_transducer(260_000, 9, 64, 0.0, seed=32), start=12_345)
+    c1, c2, c3, cw = (rustfst_amd.Context(0) for _ in range(4))
+    for c in (c1, c2, c3):
+        c.set_resident_share(1)
+    da, db = to_device(ta, c1), to_device(tb, c2)
+    dc = to_device(ta, c3)
+    dw = to_device(tb, cw)
+    ca, cb = to_oracle(oracle, ta).shortest_path_canonical(), to_oracle(oracle, tb).shortest_path_canonical()
+    for d, c, can in ((da, c1, ca), (db, c2, cb), (dc, c3, ca), (dw, cw, cb)):
+        for q in range(3):  # (plan, transpose, predicted batch)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"alone, query {q}")
+        assert c.stats()["relax_kernel"] == 2
+    for rep in range(8):
+        first, second = ((da, db) if rep % 2 == 0 else (db, da))
+        j1 = first.shortest_path_begin()
+        j2 = second.shortest_path_begin()
+        j3 = dc.shortest_path_begin() if rep >= 4 else None  # both units are out: one launch per level
+        jw = dw.shortest_path_begin() if rep >= 6 else None  # wants both units
+        r1, r2 = j1.finish(), j2.finish()
+        assert c1.stats()["relax_kernel"] == 2 and c2.stats()["relax_kernel"] == 2, (rep, c1.stats()["relax_kernel"], c2.stats()["relax_kernel"])
+        ra, rb = (r1, r2) if rep % 2 == 0 else (r2, r1)
+        assert_flat_identical(ra.to_flat(), ca.to_flat(), f"rep {rep}: first FST")
+        assert_flat_identical(rb.to_flat(), cb.to_flat(), f"rep {rep}: second FST")
+        if j3 is not None:
+            assert_flat_identical(j3.finish().to_flat(), ca.to_flat(), f"rep {rep}: third query")
+            assert c3.stats()["relax_kernel"] == 1
+        if jw is not None:
+            assert_flat_identical(jw.finish().to_flat(), cb.to_flat(), f"rep {rep}: whole-device query")
+            assert cw.stats()["relax_kernel"] == 1
+    for c in (c1, c2, c3, cw):
+        assert c.stats()["resident_aborts"] == 0
+    for d, can in ((da, ca), (db, cb)):
+        dist, hops = d.shortest_distance(want_hops=True)
+        np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+        np.testing.assert_array_equal(hops, can.hops)
+
+
 def test_two_processes_solving_on_one_gpu():
     """Two PROCESSES query the same kind of FST on one GPU at the same time.  A resident launch needs every workgroup on a
     compute unit of its own, so only one process at a time may run one: the lease is an advisory file lock per device
