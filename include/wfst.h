@@ -249,7 +249,8 @@ wfst_status wfst_fst_tr_sort(wfst_ctx* ctx, wfst_fst* fst, int ilabel_cmp);
  *      the FST, otherwise the start state and the property word change as the reference's do (set_start_properties,
  *      fst_properties/mutate_properties.rs:7-13); the arcs stay where they are in HBM and everything cached on the handle that
  *      does not depend on the start state (region plan, transpose, packed arcs) is kept — a shortest_path query per source on
- *      one resident FST is this call + wfst_shortest_path (ABI 7). ---- */
+ *      one resident FST is this call + wfst_shortest_path (ABI 7).  Like every mutation of a handle: not while a query on it
+ *      is in flight on any context. ---- */
 wfst_status wfst_fst_set_start(wfst_ctx* ctx, wfst_fst* fst, uint32_t state);
 
 /* ---- fused batch: for each acceptor i: shortest_path(compose(acceptors[i], t)) — the loop a
