@@ -1221,17 +1221,19 @@ std::shared_ptr<MboxPlan> mbox_plan(wfst_ctx* ctx, const wfst_fst* f, uint32_t l
   HIP_CHECK(rocprim::exclusive_scan(temp.p, temp_bytes, hist.p, p->roff.p, 0u, cells + 1, rocprim::plus<uint32_t>(), st));
   mbox_transpose_kernel<<<(uint32_t)((cells + 255) / 256), 256, 0, st>>>(p->roff.p, nb, p->roff_t.p);
   // lanes per state of the resident kernel's expansion rounds (a lane takes two arcs): the fewest that cover all but 1/64 of
-  // the rows in one pass — a lane group without arcs is a lane group that keeps no row in flight
+  // the rows in one pass — a lane group without arcs is a lane group that keeps no row in flight — and leave at most 1/16 of
+  // the ARCS to the long-row pass (a few states with hundreds of arcs each, as in a decoding graph, would otherwise be walked 2 l
+  // arcs at a time by one lane group while the rest of its wave waits)
   {
-    DBuf<uint32_t> over(*ctx->pool, 8);
-    uint32_t h_over[8];
+    DBuf<uint32_t> over(*ctx->pool, 16);
+    uint32_t h_over[16];
     HIP_CHECK(hipMemsetAsync(over.p, 0, sizeof(h_over), st));
     mbox_degree_kernel<<<std::min<uint32_t>((n + 255) / 256, 1024u), 256, 0, st>>>(f->dev.offsets, n, over.p);
     HIP_CHECK(hipMemcpyAsync(h_over, over.p, sizeof(h_over), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     p->lps = 8;
     for (uint32_t l = 2; l < 8; ++l)
-      if (h_over[l] <= n / 64u) {
+      if (h_over[l] <= n / 64u && (uint64_t)h_over[8 + l] <= f->n_arcs / 16u && h_over[8 + l] != 0xFFFFFFFFu) {
         p->lps = l;
         break;
       }

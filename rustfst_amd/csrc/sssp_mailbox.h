@@ -100,18 +100,28 @@ __global__ void __launch_bounds__(1024) mbox_hist_kernel(const uint32_t* __restr
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) hist[(size_t)d * nb + j] = l_h[d];  // destination-major
 }
-// how many states have more than 2 l arcs, l = 2 .. 7 (the resident kernel's lanes per state: MboxPlan::lps)
+// how many states have more than 2 l arcs, l = 2 .. 7 (over[l]), and how many arcs those rows hold beyond their first 2 l
+// (over[8 + l], saturating): what the resident kernel's long-row pass would have to do with l lanes per state (MboxPlan::lps)
 __global__ void __launch_bounds__(256) mbox_degree_kernel(const uint32_t* __restrict__ offsets, uint32_t n, uint32_t* __restrict__ over) {
-  __shared__ uint32_t s_over[8];
-  if (threadIdx.x < 8) s_over[threadIdx.x] = 0;
+  __shared__ uint32_t s_over[16];
+  if (threadIdx.x < 16) s_over[threadIdx.x] = 0;
   __syncthreads();
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const uint32_t d = offsets[s + 1] - offsets[s];
     for (uint32_t l = 2; l < 8; ++l)
-      if (d > 2u * l) atomicAdd(&s_over[l], 1u);
+      if (d > 2u * l) {
+        atomicAdd(&s_over[l], 1u);
+        atomicAdd(&s_over[8 + l], d - 2u * l);
+      }
   }
   __syncthreads();
-  if (threadIdx.x >= 2 && threadIdx.x < 8 && s_over[threadIdx.x]) atomicAdd(&over[threadIdx.x], s_over[threadIdx.x]);
+  if (threadIdx.x >= 2 && threadIdx.x < 8) {
+    if (s_over[threadIdx.x]) atomicAdd(&over[threadIdx.x], s_over[threadIdx.x]);
+    if (s_over[8 + threadIdx.x]) {  // (a count of arcs: saturates instead of wrapping)
+      const uint32_t old = atomicAdd(&over[8 + threadIdx.x], s_over[8 + threadIdx.x]);
+      if (old + s_over[8 + threadIdx.x] < old) atomicMax(&over[8 + threadIdx.x], 0xFFFFFFFFu);
+    }
+  }
 }
 __global__ void mbox_transpose_kernel(const uint32_t* __restrict__ roff, uint32_t nb, uint32_t* __restrict__ roff_t) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

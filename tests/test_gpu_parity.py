@@ -1530,6 +1530,41 @@ def test_transpose_through_the_plan_on_ragged_rows(oracle, monkeypatch, n, max_d
     assert tied > 0
 
 
+def test_resident_rounds_on_heavy_tailed_out_degrees(oracle, monkeypatch):
+    """A decoding-graph-like degree profile: most states have 2 arcs, one in a hundred has 300 - 600.  The plan's rule for the
+    lanes per listed state (mbox_plan, sssp.hip) must not pick a narrow lane group from the MANY short rows when most ARCS sit in
+    the few long ones; whatever it picks, the long-row pass of rs_expand_round does most of the work here.  Distances, hop counts
+    and the path bit-identical to the canonical oracle under the resident launches, also with the narrowest group forced."""
+    monkeypatch.setenv("WFST_SSSP_MAILBOX", "1")
+    n, max_deg = 24_000, 600
+    t = synth.make_transducer(n, max_deg, 64, 0.0, seed=13)
+    rng = np.random.default_rng(13)
+    deg = np.full(n, 2, np.uint32)
+    heavy = rng.choice(n, n // 100, replace=False)
+    deg[heavy] = rng.integers(300, max_deg + 1, len(heavy)).astype(np.uint32)
+    deg[0] = max_deg
+    keep = np.tile(np.arange(max_deg, dtype=np.uint32), n) < np.repeat(deg, max_deg)
+    offsets = np.zeros(n + 1, np.uint32)
+    offsets[1:] = np.cumsum(deg, dtype=np.uint64).astype(np.uint32)
+    arcs = np.ascontiguousarray(t["arcs"][keep])
+    props = int(t["props"]) & ~(synth.ACCESSIBLE | synth.INITIAL_CYCLIC)
+    t = dict(n_states=n, start=0, offsets=offsets, arcs=arcs, finals=t["finals"], props=props)
+    assert len(arcs) > 100_000 and deg[heavy].sum() > len(arcs) // 2
+    can = to_oracle(oracle, t).shortest_path_canonical()
+    assert np.isfinite(can.distance).sum() > n // 2
+    for lps in (None, "2"):
+        if lps is not None:
+            monkeypatch.setenv("WFST_SSSP_LPS", lps)
+        ctx = rustfst_amd.Context(0)
+        d = to_device(t, ctx)
+        for q in range(3):
+            dist, hops = d.shortest_distance(want_hops=True)
+            assert ctx.stats()["relax_kernel"] == 2 and ctx.stats()["resident_aborts"] == 0
+            np.testing.assert_array_equal(dist.view(np.uint32), can.distance.view(np.uint32))
+            np.testing.assert_array_equal(hops, can.hops)
+            assert_flat_identical(d.shortest_path().to_flat(), can.to_flat(), f"lanes {lps}, query {q}")
+
+
 def test_set_start_on_a_resident_handle_queries_from_any_source(oracle, monkeypatch):
     """wfst_fst_set_start (MutableFst::set_start, mutable_fst.rs:35-44): one resident FST, a shortest-path query from each of
     several sources — every result bit-identical to the canonical oracle's on an FST built with that start state, the
