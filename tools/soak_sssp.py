@@ -28,6 +28,12 @@ while time.time() < t_end:
     os.environ["WFST_SSSP_DENSE_LOW"] = str(int(rng.choice([0, 50, 3000, 4_000_000_000])))
     os.environ["WFST_SSSP_BIN_LOG"] = str(int(rng.choice([13, 14])))
     os.environ["WFST_SSSP_BIN_HOPCAP"] = str(int(rng.choice([2, 5, 1 << 18])))
+    for var, choices in (("WFST_SSSP_LPS", ["", "", "2", "3", "5", "8"]), ("WFST_SSSP_UMAX", ["", "2", "4"])):  # lanes per state / states per group of the resident rounds
+        v = str(rng.choice(choices))
+        if v:
+            os.environ[var] = v
+        else:
+            os.environ.pop(var, None)
     os.environ["WFST_SSSP_RES_RETRY_MS"] = "0"
     os.environ["WFST_SSSP_TRANSPOSE_PLAN"] = str(int(rng.integers(0, 2)))
     hint = rng.choice(["", "0", "1"])
@@ -90,7 +96,7 @@ while time.time() < t_end:
         print("FAILED at seed", seed, "mode", mode, "delta", d, flush=True)
         raise
     except Exception:
-        print("FAILED at seed", seed, "mode", mode, "delta", d, "narrow", os.environ["WFST_SSSP_NARROW"], "hint", hint, "big", os.environ["WFST_SSSP_BIG"], "stg", os.environ["WFST_SSSP_STG"], "kind", kind, flush=True)
+        print("FAILED at seed", seed, "mode", mode, "delta", d, "narrow", os.environ["WFST_SSSP_NARROW"], "hint", hint, "big", os.environ["WFST_SSSP_BIG"], "stg", os.environ["WFST_SSSP_STG"], "kind", kind, "lps", os.environ.get("WFST_SSSP_LPS"), "umax", os.environ.get("WFST_SSSP_UMAX"), flush=True)
         raise
     counts[mode] = counts.get(mode, 0) + 1
     seed += 1
