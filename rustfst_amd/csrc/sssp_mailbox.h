@@ -256,8 +256,12 @@ __device__ __forceinline__ Sched mbox_sched_eval(const Ctl* ctl, const SchedRaw&
     return s;
   }
   // hand over when the near set is small and shrinking (the tail of the last band: whatever still waits beyond the
-  // threshold is counted in, so the growing head of a band never qualifies), or tiny either way
-  if (narrow_t && prev_mode == MODE_WIDE && cnt != 0u && cnt + s.far_total <= narrow_t &&
+  // threshold is counted in, so the growing head of a band never qualifies), or tiny either way — but never in the two
+  // levels behind the head of the search: a head that outgrew its workgroup posts near_low as its near count (to keep the
+  // threshold where it is), the few hundred activations of the first WIDE level then look like a shrinking tail, and the
+  // NARROW launch that follows grows straight back into the WIDE levels (27 of 96 random sources of the benchmark's transducer
+  // took five launches instead of three: tools/varied_sources.py)
+  if (narrow_t && sweep >= 3u && prev_mode == MODE_WIDE && cnt != 0u && cnt + s.far_total <= narrow_t &&
       (cnt < before || cnt + s.far_total <= min(narrow_t, NW_SMALL)))
     s.mode = MODE_COLLECT;
   if (cnt >= near_low) {

@@ -446,8 +446,8 @@ __global__ void __launch_bounds__(MB_THREADS) sssp_mbox_resident_kernel(const ui
       // the schedule of this level: mbox_sched_eval's rules on the same figures
       const float prev = tau_rec;
       uint32_t m = MODE_WIDE;
-      if (narrow_t && cnt != 0u && cnt + far_total <= narrow_t && (cnt < cnt_prev || cnt + far_total <= min(narrow_t, NW_SMALL)))
-        m = MODE_COLLECT;
+      if (narrow_t && sweep + lvl >= 3u && cnt != 0u && cnt + far_total <= narrow_t && (cnt < cnt_prev || cnt + far_total <= min(narrow_t, NW_SMALL)))
+        m = MODE_COLLECT;  // (never in the two levels behind the head: see mbox_sched_eval)
       if (lvl + 1u >= max_levels) m = MODE_COLLECT;  // (the launch is over: hand whatever is active to the next one)
       uint32_t st_new = 0;
       if (cnt >= near_low) {
