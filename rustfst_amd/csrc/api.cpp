@@ -446,8 +446,7 @@ wfst_status wfst_fst_set_start(wfst_ctx* ctx, wfst_fst* fst, uint32_t state) {  
     fst->start = (int64_t)state;
     fst->props = props::set_start(fst->props);
     fst->rev_host.reset();  // reverse(fst) marks the old start state final (reverse.rs:80-86)
-    fst->stable_sweeps.store(0, std::memory_order_relaxed);
-    fst->start_moved.store(1, std::memory_order_relaxed);
+    fst->stable_sweeps.store(0, std::memory_order_relaxed);  // (the next queries are queued with a spare launch again)
     // (what a solve learned about the launch pattern of the LAST source says little about this one: the first query predicts
     // from it all the same, and a solve that outruns its prediction is continued)
   });

@@ -297,7 +297,6 @@ struct wfst_fst {
   // the next solve gates that launch's bulk loads behind its mode / sleep decision
   mutable std::atomic<uint64_t> last_hint_mask{~0ull};
   mutable std::atomic<uint32_t> stable_sweeps{0};  // consecutive solves that needed exactly last_sweeps launches
-  mutable std::atomic<uint32_t> start_moved{0};    // wfst_fst_set_start since the last solve: that solve's launch count is another source's
   // the lazily built caches above may be requested from several contexts (threads) at once: built under this lock,
   // with buffers taken from the OWNER context's pool (this->ctx), which outlives the handle
   mutable std::mutex cache_mu;

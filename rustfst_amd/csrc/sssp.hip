@@ -1699,9 +1699,8 @@ struct SweepDriver {
     // a second batch is a host round trip and a re-run of the fused tail.
     // (the margin is dropped once three solves in a row needed the same count: wfst_fst::stable_sweeps)
     const uint32_t last_sweeps = f->last_sweeps.load(std::memory_order_relaxed);
-    // (a query from ANOTHER source than the last one — wfst_fst_set_start — gets two: its depth differs by a level or two, an
-    // idle launch is ~3 us, a second batch ~0.3 ms: bench.py `varied_sources`)
-    const uint32_t margin = f->start_moved.exchange(0, std::memory_order_relaxed) ? 2u : (f->stable_sweeps.load(std::memory_order_relaxed) >= 3 ? 0u : 1u);
+    // (wfst_fst_set_start resets the count of stable solves: a query from another source than the last one gets the spare launch back)
+    const uint32_t margin = f->stable_sweeps.load(std::memory_order_relaxed) >= 3 ? 0u : 1u;
     if (last_sweeps) first_count = std::min<uint32_t>(MAX_BATCH, sv->mbox ? last_sweeps + margin : ((last_sweeps + 1 + 1) & ~1u));
     predicted = last_sweeps != 0 && (sv->mbox ? last_sweeps <= first_count : last_sweeps < first_count);
     evs[0] = ctx->ev0;
