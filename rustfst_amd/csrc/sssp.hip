@@ -1372,7 +1372,15 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
   // near-far only pays on branching graphs (label-correcting re-relaxes them many times); on lattices every
   // arc is relaxed once anyway.  delta = 1.5 x mean arc weight; +inf = plain frontier sweeps.
   float delta = INF;
-  if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) delta = 1.5f * f->mean_weight;
+  if (!f->has_negative && f->mean_weight > 0.0f && n >= 65536 && f->n_arcs >= 2ull * n) {
+    delta = 1.5f * f->mean_weight;
+    // ... of a graph with ~10 arcs per state.  With more, a state's BEST arc is cheaper (the minimum of d weights) while the
+    // mean is not, the distances shrink and a band of 1.5 mean weights swallows the search: everything is near, everything is
+    // relaxed again and again.  The band narrows in proportion (1M states: fan-out 16 638 -> 364 us, 24: 1 262 -> ~550; <= 10
+    // arcs per state: unchanged, the schedule was swept there — tools/fan_sweep.py).
+    const double deg = (double)f->n_arcs / (double)n;
+    if (deg > 10.0) delta = (float)(delta * 10.0 / deg);
+  }
   if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
   if (!(delta > 0.0f)) delta = INF;
   sv.delta = delta;
@@ -1582,7 +1590,10 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
         // a resident level costs ~7 us when thin (a launch per level: ~10): the band's tail is cut a little later and the
         // hand-over to the NARROW launch comes a little earlier (measured on C3: 298.8 -> 289.5 us per solve)
         if (!std::getenv("WFST_SSSP_NEAR_LOW")) sv.near_low = std::min<uint32_t>(65536u, std::max<uint32_t>(4096u, n / 32u));
-        if (!std::getenv("WFST_SSSP_NARROW")) sv.narrow_t = 16384;
+        // (what the NARROW launch can hold is ~48 - 96 entries per workgroup: handing it more per workgroup than that sends the
+        // search back and forth between the modes — 150 k states, 37 blocks, threshold 16 384: 7.6 launches and 0.55 ms per
+        // query from random sources; with 64 per block 3 launches and 0.40 ms: tools/varied_sources.py)
+        if (!std::getenv("WFST_SSSP_NARROW")) sv.narrow_t = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, nb * (sv.log == 13 ? 128u : 64u)));
         static std::once_flag res_once[64];
         std::call_once(res_once[(unsigned)ctx->device & 63u], [] {
           HIP_CHECK(hipFuncSetAttribute((const void*)sssp_mbox_resident_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
