@@ -1376,10 +1376,12 @@ void relax_setup(wfst_ctx* ctx, const wfst_fst* f, Solve& sv) {
     delta = 1.5f * f->mean_weight;
     // ... of a graph with ~10 arcs per state.  With more, a state's BEST arc is cheaper (the minimum of d weights) while the
     // mean is not, the distances shrink and a band of 1.5 mean weights swallows the search: everything is near, everything is
-    // relaxed again and again.  The band narrows in proportion (1M states: fan-out 16 638 -> 364 us, 24: 1 262 -> ~550; <= 10
-    // arcs per state: unchanged, the schedule was swept there — tools/fan_sweep.py).
+    // relaxed again and again; with fewer, the band holds a few dozen states per level for many levels.  The band follows
+    // 10 / (arcs per state) — 1M states (tools/fan_sweep.py): fan-out 3 / 4 / 5 / 6 / 8: 247 / 254 / 223 / 236 / 229 -> 189 /
+    // 193 / 191 / 200 / 223 us; 12 / 16 / 24: 366 / 638 / 1 262 -> 275 / 327 / 523 — except between 8.5 and 10 arcs per state,
+    // where the schedule was swept on the benchmark's transducer and the unscaled band is the better one (fan-out 9: 233 against 256).
     const double deg = (double)f->n_arcs / (double)n;
-    if (deg > 10.0) delta = (float)(delta * 10.0 / deg);
+    if (deg > 10.0 || deg < 8.5) delta = (float)(delta * 10.0 / deg);
   }
   if (const char* e = std::getenv("WFST_SSSP_DELTA")) delta = (float)std::atof(e);  // experiments / tests
   if (!(delta > 0.0f)) delta = INF;
