@@ -227,6 +227,7 @@ struct MboxPlan {
   DBuf<uint32_t> roffh_t;  // [nb*nb]     source-major copy
   uint64_t res_units = 0;  // units of one parity buffer
   uint32_t lps = 8;        // lanes per listed state of the resident kernel's expansion rounds (from the out-degrees)
+  float mean_min_w = 0.0f; // mean over the states of their cheapest finite arc weight (0: unknown)
 };
 // Region plan of the binned levels of the atomic sweeps (sssp_binned.h): source states in G contiguous ranges of `sg`
 // states, destination states in `nbin` bins of 1 << logd; region (g -> b) holds one slot per arc from range g to bin b.

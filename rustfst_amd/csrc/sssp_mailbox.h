@@ -102,17 +102,35 @@ __global__ void __launch_bounds__(1024) mbox_hist_kernel(const uint32_t* __restr
 }
 // how many states have more than 2 l arcs, l = 2 .. 7 (over[l]), and how many arcs those rows hold beyond their first 2 l
 // (over[8 + l], saturating): what the resident kernel's long-row pass would have to do with l lanes per state (MboxPlan::lps)
-__global__ void __launch_bounds__(256) mbox_degree_kernel(const uint32_t* __restrict__ offsets, uint32_t n, uint32_t* __restrict__ over) {
+// ... and the sum of the states' CHEAPEST finite arc weights (minw[0], double) over the states that have one (minw[1]): what a
+// shortest path pays per hop is nearer to that than to the mean arc weight (the band of the near-far schedule, relax_setup)
+__global__ void __launch_bounds__(256) mbox_degree_kernel(const uint32_t* __restrict__ offsets, const uint2* __restrict__ wn, uint32_t n,
+                                                          uint32_t* __restrict__ over, double* __restrict__ minw) {
   __shared__ uint32_t s_over[16];
   if (threadIdx.x < 16) s_over[threadIdx.x] = 0;
   __syncthreads();
+  double msum = 0.0, mcnt = 0.0;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
     const uint32_t d = offsets[s + 1] - offsets[s];
+    float mn = INF;
+    for (uint32_t k = offsets[s]; k < offsets[s + 1]; ++k) mn = fminf(mn, __uint_as_float(wn[k].x));
+    if (mn < INF && mn > -INF) {
+      msum += (double)mn;
+      mcnt += 1.0;
+    }
     for (uint32_t l = 2; l < 8; ++l)
       if (d > 2u * l) {
         atomicAdd(&s_over[l], 1u);
         atomicAdd(&s_over[8 + l], d - 2u * l);
       }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    msum += __shfl_xor(msum, d);
+    mcnt += __shfl_xor(mcnt, d);
+  }
+  if ((threadIdx.x & 63u) == 0 && mcnt > 0.0) {
+    atomicAdd(&minw[0], msum);
+    atomicAdd(&minw[1], mcnt);
   }
   __syncthreads();
   if (threadIdx.x >= 2 && threadIdx.x < 8) {
